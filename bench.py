@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Headline benchmark: queries/sec (+ recall@10) of the dense-retrieval hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the hot path over one batch: 256 L2-normalised query vectors scored against the rank's
+row shard (10M x 768 fp16 per GPU by default = BASELINE.json configs[2]; N GPUs hold N x 10M rows = configs[3]
+at N = 8), fused MFMA scoring + top-10, and for N > 1 the RCCL all-gather of per-shard (score, id) candidates and
+the final merge.  Inputs (index, queries) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+The oracle (``oracle/``) is used here only (a) as the ``cpu_baseline`` timed on the host cores over a bounded sample
+and (b) as the checker for recall@10 -- never as the thing measured.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy rate)
+
+
+def build_shard(n, d, seed, device, chunk=1 << 18):
+    """Synthetic corpus shard generated ON the device: i.i.d. standard normal rows, L2-normalised in fp32, stored
+    fp16."""
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    buf = torch.empty((n, d), dtype=torch.float16, device=device)
+    for c0 in range(0, n, chunk):
+        c1 = min(n, c0 + chunk)
+        x = torch.randn((c1 - c0, d), generator=gen, device=device, dtype=torch.float32)
+        x /= x.norm(dim=1, keepdim=True)
+        buf[c0:c1] = x.to(torch.float16)
+    return buf
+
+
+def cpu_oracle_topk(shard, q16, k, rows=None, chunk_rows=1 << 19):
+    """Exact top-k of the oracle over the first ``rows`` rows of the device shard, streamed to the host in chunks."""
+    from oracle import retrieval as R
+    n = shard.shape[0] if rows is None else min(rows, shard.shape[0])
+    q = q16.astype(np.float32)
+    best_s = best_p = None
+    for c0 in range(0, n, chunk_rows):
+        c1 = min(n, c0 + chunk_rows)
+        xc = shard[c0:c1].cpu().numpy()
+        s, _, p = R.search(q, xc, k, dtype=R.DTYPE_F16)
+        p = p + c0
+        if best_s is None:
+            best_s, best_p = s, p
+        else:
+            ms = np.concatenate([best_s, s], axis=1)
+            mp = np.concatenate([best_p, p], axis=1)
+            o = np.lexsort((mp, -ms.astype(np.float64)), axis=1)[:, :k]
+            best_s = np.take_along_axis(ms, o, axis=1)
+            best_p = np.take_along_axis(mp, o, axis=1)
+    return best_s, best_p
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--docs-per-gpu", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
+    ap.add_argument("--verify-queries", type=int, default=16, help="queries checked against the CPU oracle over the FULL shard")
+    ap.add_argument("--no-cpu", action="store_true", help="skip cpu_baseline and the recall check (profiling runs)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the measured path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    from vietnamese_qa_system_amd import build
+    build.build()
+    from vietnamese_qa_system_amd.index import DeviceIndex
+    from vietnamese_qa_system_amd.sharded import sharded_index_searcher
+
+    n, d, b, k = args.docs_per_gpu, args.dim, args.batch, args.k
+    shard = build_shard(n, d, 1234 + rank, device)
+    index = DeviceIndex(shard, id_base=1 + rank * n, dtype="fp16", device=local_rank, borrow=(d % 64 == 0))
+    gq = torch.Generator(device=device)
+    gq.manual_seed(99)
+    q = torch.randn((b, d), generator=gq, device=device, dtype=torch.float32)
+    q = (q / q.norm(dim=1, keepdim=True)).to(torch.float16)
+    searcher = sharded_index_searcher(index)
+
+    def sync():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        out = searcher.search(q, k)
+    index.set_timing(True)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = searcher.search(q, k)
+    sync()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, launches = index.get_timing()
+    index.set_timing(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    info = index.launch_info(b, k)
+
+    result = None
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        qps = b * args.steps / elapsed  # every rank answers the same batch: whole-job queries/s over world*n rows
+        kern_ms = kernel_ms / max(launches, 1)
+        achieved = info.bytes_per_launch / (kern_ms * 1e-3) / 1e9 if launches else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as f:
+                traffic = json.load(f).get(f"{n}x{d}_f16_b{b}_k{k}")
+        result = {
+            "metric": "queries_per_sec", "value": round(qps, 1), "unit": "queries/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{world}x{n}x{d} fp16 index row-sharded, batch={b} queries, top-{k}, fused MFMA scoring + top-k"
+                                   + (", RCCL all-gather + merge" if world > 1 else ""),
+                       "docs_total": world * n, "docs_per_gpu": n, "dim": d, "batch": b, "k": k,
+                       "parallelism": f"row-shard x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "score_topk_f16_kernel<true>", "achieved": round(achieved, 1) if achieved else None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
+                         "traffic": traffic, "kernel_ms": round(kern_ms, 4), "launches": launches,
+                         "bytes_per_launch": info.bytes_per_launch, "flops_per_launch": info.flops_per_launch,
+                         "mfma_tflops": round(info.flops_per_launch / (kern_ms * 1e-3) / 1e12, 1) if launches else None},
+        }
+
+    # ---- outside the timed region: recall@10 against the CPU oracle and the CPU baseline (rank 0, N = 1 only for the
+    # baseline; the recall check runs on rank 0's shard through the single-shard path)
+    if rank == 0 and not args.no_cpu:
+        from oracle import retrieval as R
+        s_gpu, i_gpu, p_gpu = index.search(q, k, return_positions=True)
+        torch.cuda.synchronize(device)
+        q16 = q.cpu().numpy()
+        nv = min(args.verify_queries, b)
+        t1 = time.perf_counter()
+        ref_s, ref_p = cpu_oracle_topk(shard, q16[:nv], k)
+        verify_s = time.perf_counter() - t1
+        recall = R.recall_at_k(p_gpu[:nv].cpu().numpy(), ref_p)
+        score_err = float(np.abs(s_gpu[:nv].cpu().numpy() - ref_s).max())
+        result["recall_at_10"] = recall
+        result["recall_check"] = {"queries": nv, "rows": n, "max_abs_score_err": score_err, "oracle_seconds": round(verify_s, 1)}
+        if world == 1:
+            rows = min(args.cpu_sample_rows, n)
+            torch.set_num_threads(os.cpu_count())
+            t1 = time.perf_counter()
+            cpu_oracle_topk(shard, q16, k, rows=rows)
+            cpu_s = time.perf_counter() - t1
+            cpu_qps = b / (cpu_s * (n / rows))
+            result["cpu_baseline"] = {"value": round(cpu_qps, 3), "unit": "queries/s", "cores": os.cpu_count(), "kind": "port",
+                                      "sample": f"oracle/retrieval.py (numpy fp32 GEMM + exact top-k) on all {b} queries x the first "
+                                                f"{rows} rows of the shard in {cpu_s:.1f} s (includes the device->host copy of the sample); "
+                                                f"value = {b} / (t * {n}/{rows})"}
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    index.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

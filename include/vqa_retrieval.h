@@ -1,0 +1,144 @@
+/* vqa_retrieval.h -- C ABI of libvqa_retrieval.so (hand-written HIP for gfx950 / MI355X).
+ *
+ * Drop-in boundary for ONE path of vTuanpham/Vietnamese_QA_System: the dense retriever its
+ * inference_pipeline drives through a txtai-shaped object (reference:
+ * inference_pipeline/db_utils/heavy_ranker.py:78-101).  The reference has no FFI of its own (pure Python,
+ * scoring delegated to txtai -> faiss); these entry points are what a maintainer binds with ctypes to replace
+ * that delegation -- see INTEGRATION.md for the stub.  Plain pointers and sizes only; no torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative VQA_E* code on failure; the message is available from
+ *     vqa_last_error() (thread-local).  No C++ exception crosses the ABI, nothing calls exit/abort.
+ *   - all device work is enqueued asynchronously on the caller's hipStream_t (passed as void*); no hidden
+ *     hipDeviceSynchronize / hipMalloc in search/merge/forward calls (they are hipGraph-capturable).
+ *   - the caller allocates every output (device memory); the library owns only what it allocated in *_create.
+ *   - different handles may be used from different host threads; one handle is not re-entrant.
+ */
+#ifndef VQA_RETRIEVAL_H
+#define VQA_RETRIEVAL_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQA_VERSION 100 /* 0.1.0 */
+
+/* error codes */
+#define VQA_OK 0
+#define VQA_EINVAL (-1)  /* bad argument (shape, dtype, k, null pointer) */
+#define VQA_EHIP (-2)    /* a HIP runtime call failed (message carries hipGetErrorString) */
+#define VQA_ENOMEM (-3)  /* device allocation failed */
+#define VQA_ENODEV (-4)  /* no gfx950 device / wrong architecture */
+
+/* element types of index rows and query rows */
+#define VQA_F32 0
+#define VQA_F16 1
+#define VQA_FP8_E4M3 2 /* OCP e4m3fn (gfx950), one byte per element */
+
+/* vqa_index_create flags */
+#define VQA_ROWS_BORROW 1 /* rows is a DEVICE pointer that outlives the index; do not copy (needs d % 64 == 0) */
+
+/* limits of the fused scoring + top-k kernel */
+#define VQA_MAX_K 16       /* top-k per query handled in LDS candidate lists (BASELINE k = 10; reference k = 1) */
+#define VQA_QUERY_TILE 256 /* queries scored per pass over the index (BASELINE batch = 256) */
+
+typedef struct vqa_index vqa_index;     /* opaque: one row shard of the corpus on one device */
+typedef struct vqa_encoder vqa_encoder; /* opaque: question-encoder weights on one device */
+
+int vqa_version(void);
+const char* vqa_last_error(void);
+
+/* ---- index: replaces txtai's ANN backend (faiss IndexFlatIP + IDMap) behind Embeddings.index/load -----------
+ * heavy_ranker.py:86-94.  rows: [n, d] row-major, host or device pointer (hipMemcpyDefault), element type
+ * `dtype`, expected L2-normalised by the caller (txtai normalises at index time).  ids: [n] int64 external ids
+ * (host or device) or NULL, in which case id = id_base + row position (sqlite AUTOINCREMENT rowids start at 1,
+ * setup_db.py:14). */
+int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t d, int32_t dtype, const void* rows,
+                     const int64_t* ids_or_null, int64_t id_base, uint32_t flags);
+void vqa_index_destroy(vqa_index* index);
+int64_t vqa_index_size(const vqa_index* index);
+int32_t vqa_index_dim(const vqa_index* index);
+int32_t vqa_index_dtype(const vqa_index* index);
+
+/* ---- search: replaces the scoring + top-k inside Embeddings.search / batchsearch (heavy_ranker.py:98,100) ---
+ * q: [B, d] DEVICE pointer, element type q_dtype (VQA_F32 or VQA_F16; converted to the index element type with
+ * round-to-nearest-even inside the call).  Scores are fp32 inner products accumulated in fp32.
+ * out_scores [B, k] float and out_ids [B, k] int64 (device): best first; ties by row position ascending; when
+ * the shard holds fewer than k rows the tail is padded with (-inf, -1).  out_pos_or_null [B, k] int64 receives
+ * the row positions inside this shard (or NULL).  1 <= k <= VQA_MAX_K; any B >= 1 (processed in tiles of
+ * VQA_QUERY_TILE queries, one pass over the index per tile). */
+int vqa_index_search(vqa_index* index, const void* q, int32_t q_dtype, int32_t B, int32_t k, float* out_scores,
+                     int64_t* out_ids, int64_t* out_pos_or_null, void* hip_stream);
+
+/* ---- merge: final step after the RCCL all-gather of per-shard candidates (new in this build; the reference is
+ * single-process).  scores/ids: [R, B, k] device, each [k] list best first, padded with (-inf, -1); shards are
+ * contiguous row ranges in rank order, so ties resolve by (rank asc, slot asc) = global row position asc.
+ * out: [B, k_out] with k_out <= min(R*k, VQA_MAX_K * 8). */
+int vqa_merge_topk(const float* scores, const int64_t* ids, int32_t R, int32_t B, int32_t k, int32_t k_out,
+                   float* out_scores, int64_t* out_ids, void* hip_stream);
+
+/* ---- measurement hooks used by bench.py (roofline of the dominant kernel).  vqa_index_launch_info reports the
+ * geometry of the main scoring kernel so the algorithmic bytes/flops per launch can be stated.  With timing
+ * enabled, every vqa_index_search brackets its MAIN scoring-kernel launch with HIP events on the caller's stream
+ * (events are not capturable: leave timing off under hipGraph capture); vqa_index_get_timing waits for the last
+ * event, returns the summed kernel time and the number of launches since the previous call, and resets both. */
+typedef struct vqa_launch_info {
+    int32_t grid;          /* workgroups of the fused scoring kernel */
+    int32_t block;         /* threads per workgroup */
+    int32_t lds_bytes;     /* dynamic LDS per workgroup */
+    int32_t rows_per_tile; /* corpus rows scored per workgroup iteration */
+    int64_t rows_per_launch;  /* corpus rows the MAIN scoring kernel covers (n minus the rows of the seeding pass) */
+    int64_t bytes_per_launch; /* algorithmic bytes of that launch: rows_per_launch * d * sizeof(element) */
+    int64_t flops_per_launch; /* 2 * VQA_QUERY_TILE * rows_per_launch * d */
+    int32_t seed_grid;        /* workgroups (= tiles) of the seeding pass, 0 when the search is single pass */
+    int32_t reserved;
+} vqa_launch_info;
+int vqa_index_launch_info(const vqa_index* index, int32_t B, int32_t k, vqa_launch_info* out);
+int vqa_index_set_timing(vqa_index* index, int32_t enabled);
+int vqa_index_get_timing(vqa_index* index, double* kernel_ms_sum, int64_t* launches);
+
+/* ---- question encoder: replaces the transformer forward + pooling + L2-normalise inside txtai
+ * (model chosen by `path=` at heavy_ranker.py:80,83; DPR form at src/test.py:84-86 `.pooler_output`).
+ * RoBERTa/PhoBERT-base-shaped post-LN encoder.  All weight pointers are fp32, host or device, copied (and
+ * converted to fp16) at create time. */
+typedef struct vqa_encoder_config {
+    int32_t vocab_size, hidden, layers, heads, ffn, max_pos, type_vocab, pad_id;
+    float ln_eps;
+} vqa_encoder_config;
+
+typedef struct vqa_encoder_layer_weights {
+    const float *wq, *bq, *wk, *bk, *wv, *bv; /* [hidden, hidden] row-major [out, in] (torch Linear), [hidden] */
+    const float *wo, *bo;                     /* attention output projection */
+    const float *ln1_g, *ln1_b;               /* LayerNorm after attention residual */
+    const float *w1, *b1;                     /* [ffn, hidden], [ffn] */
+    const float *w2, *b2;                     /* [hidden, ffn], [hidden] */
+    const float *ln2_g, *ln2_b;               /* LayerNorm after FFN residual */
+} vqa_encoder_layer_weights;
+
+typedef struct vqa_encoder_weights {
+    const float *word_emb, *pos_emb, *type_emb; /* [vocab, hidden], [max_pos, hidden], [type_vocab, hidden] */
+    const float *emb_ln_g, *emb_ln_b;
+    const vqa_encoder_layer_weights* layer;     /* [layers] */
+} vqa_encoder_weights;
+
+#define VQA_POOL_CLS 0  /* DPR: last_hidden[:, 0, :] (transformers modeling_dpr.py DPREncoder.forward) */
+#define VQA_POOL_MEAN 1 /* sentence-transformers masked mean (the models heavy_ranker.py:80,83 actually load) */
+
+int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encoder_config* cfg, const vqa_encoder_weights* w,
+                       int32_t max_tokens /* B*L capacity of the activation workspace */);
+void vqa_encoder_destroy(vqa_encoder* enc);
+/* input_ids, attn_mask: [B, L] int32 device.  out: [B, hidden] fp32 device. */
+int vqa_encoder_forward(vqa_encoder* enc, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L,
+                        int32_t pooling, int32_t normalize, float* out, void* hip_stream);
+
+/* ---- helpers used by the host side when it builds an index from fp32 embeddings ------------------------------
+ * rows fp32 [n, d] device -> L2-normalised (optional) -> element type dtype, written to out (device). */
+int vqa_normalize_convert(const float* rows, int64_t n, int32_t d, int32_t normalize, int32_t dtype, void* out,
+                          void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQA_RETRIEVAL_H */

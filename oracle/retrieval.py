@@ -1,0 +1,255 @@
+"""CPU oracle for the dense-retrieval hot path (TEST INFRASTRUCTURE -- NOT PRODUCT CODE).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module.  The product path (``vietnamese_qa_system_amd``) never imports anything under ``oracle/`` and
+fails loudly when the HIP library is missing.
+
+What it restates
+----------------
+The reference delegates the whole path to ``txtai.Embeddings.search`` (call sites
+``inference_pipeline/db_utils/heavy_ranker.py:91-101``); txtai (unpinned, ``requirements.txt:74``) in turn
+delegates scoring/top-k to faiss ``IndexFlatIP``.  Neither library is in ``/root/reference`` nor installable
+here, so this file restates their *published* algorithm:
+
+* L2-normalise query and corpus rows in fp32 (txtai ``Embeddings.normalize``: ``e /= norm(e, axis=1)[:, None]``;
+  cosine intent evidenced by the reference itself at ``src/test.py:104`` ``cosine_similarity``),
+* exact fp32 inner product of every query with every stored row (faiss ``METRIC_INNER_PRODUCT``, flat index),
+* the k largest per query, best first (faiss heap result order), ids mapped through the id vector
+  (faiss ``IDMap``; external ids originate at ``heavy_ranker.py:76`` ``"id": row[0]`` = sqlite rowid,
+  ``setup_db.py:14``),
+* txtai's ``score > 0`` result filter is a host-side option (``min_score``), never part of scoring.
+
+Tie order is *defined* here (faiss leaves it unspecified): score descending, then corpus row position
+ascending.  For ``ids = arange(N) + base`` that equals "id ascending".
+
+PARITY STATUS: **parity unpinned by the reference** -- the reference has no test, fixture or golden vector
+for this path.  The oracle is instead pinned against two independent implementations
+available in this container (``tests/golden/make_golden.py``): ``torch.nn.functional.cosine_similarity``
+(the very call the reference makes at ``src/test.py:104``) and scikit-learn's brute-force cosine
+``NearestNeighbors``.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# --------------------------------------------------------------------------------------------------
+# storage dtypes of the index (what the GPU path keeps in HBM); the oracle always scores the SAME stored
+# values upcast to fp32, otherwise recall@10 = 1.0 is not well defined ("Same-dtype oracle").
+# --------------------------------------------------------------------------------------------------
+DTYPE_F32, DTYPE_F16, DTYPE_FP8_E4M3 = 0, 1, 2
+E4M3_MAX = 448.0
+
+
+def l2_normalize(x: np.ndarray) -> np.ndarray:
+    """Row-wise ``x / ||x||_2`` in fp32 (txtai ``normalize``; zero rows are left as zeros)."""
+    x = np.asarray(x, dtype=np.float32)
+    n = np.linalg.norm(x, axis=-1, keepdims=True).astype(np.float32)
+    n = np.where(n == 0, np.float32(1), n)
+    return (x / n).astype(np.float32)
+
+
+# ---- OCP fp8 e4m3fn (gfx950 uses OCP, not fnuz) -----------------------------------------------------
+
+def _e4m3_table() -> np.ndarray:
+    """All 256 e4m3fn code points decoded to fp32 (0x7f / 0xff are NaN)."""
+    codes = np.arange(256, dtype=np.uint32)
+    sign = np.where(codes & 0x80, -1.0, 1.0)
+    e = (codes >> 3) & 0xF
+    m = codes & 0x7
+    val = np.where(e == 0, (m / 8.0) * 2.0 ** -6, (1.0 + m / 8.0) * 2.0 ** (e.astype(np.float64) - 7))
+    val = sign * val
+    val[(codes & 0x7F) == 0x7F] = np.nan
+    return val.astype(np.float32)
+
+
+_E4M3 = _e4m3_table()
+
+
+def e4m3_decode(codes: np.ndarray) -> np.ndarray:
+    return _E4M3[np.asarray(codes, dtype=np.uint8)]
+
+
+def e4m3_encode(x: np.ndarray) -> np.ndarray:
+    """fp32 -> e4m3fn code, round-to-nearest-even, saturating to +-448 (the conversion the GPU build
+    uses when it quantises an index: ``v_cvt_pk_fp8_f32`` semantics with saturation)."""
+    x = np.asarray(x, dtype=np.float32)
+    sign = np.signbit(x)
+    a = np.minimum(np.abs(x).astype(np.float64), E4M3_MAX)
+    # spacing: subnormal/first binade 2^-9, otherwise 2^(floor(log2 a) - 3)
+    with np.errstate(divide="ignore"):
+        ex = np.floor(np.log2(np.where(a > 0, a, 1.0)))
+    ex = np.clip(ex, -6, 8)
+    step = 2.0 ** (ex - 3)
+    q = np.rint(a / step) * step  # np.rint = round half to even
+    q = np.minimum(q, E4M3_MAX)
+    # encode q exactly
+    with np.errstate(divide="ignore"):
+        e2 = np.floor(np.log2(np.where(q > 0, q, 1.0)))
+    e2 = np.clip(e2, -6, 8)
+    is_sub = q < 2.0 ** -6
+    mant = np.where(is_sub, np.rint(q / 2.0 ** -9), np.rint((q / 2.0 ** e2 - 1.0) * 8.0))
+    ebits = np.where(is_sub, 0, e2 + 7)
+    code = (ebits.astype(np.uint32) << 3) | mant.astype(np.uint32)
+    code = np.where(sign, code | 0x80, code)
+    code = np.where(np.isnan(x), 0x7F, code)
+    return code.astype(np.uint8)
+
+
+def quantize_rows(x: np.ndarray, dtype: int) -> np.ndarray:
+    """fp32 rows -> the values the index stores, returned in their storage representation
+    (float32 / float16 arrays, uint8 e4m3 codes)."""
+    x = np.asarray(x, dtype=np.float32)
+    if dtype == DTYPE_F32:
+        return x
+    if dtype == DTYPE_F16:
+        return x.astype(np.float16)
+    if dtype == DTYPE_FP8_E4M3:
+        return e4m3_encode(x)
+    raise ValueError(f"unknown dtype {dtype}")
+
+
+def stored_to_f32(xs: np.ndarray, dtype: int) -> np.ndarray:
+    if dtype == DTYPE_FP8_E4M3:
+        return e4m3_decode(xs)
+    return np.asarray(xs).astype(np.float32)
+
+
+# ---- scoring + exact top-k ------------------------------------------------------------------------------
+
+def _order_desc_pos_asc(scores: np.ndarray, pos: np.ndarray) -> np.ndarray:
+    """Indices that sort candidates by (score desc, position asc)."""
+    return np.lexsort((pos, -scores.astype(np.float64)))
+
+
+def search(q: np.ndarray, x_stored: np.ndarray, k: int, *, dtype: int = DTYPE_F32, ids: np.ndarray | None = None,
+           id_base: int = 0, chunk: int = 65536, acc: str = "f32"):
+    """faiss ``IndexFlatIP.search`` restated: scores = Q @ X^T (fp32, or fp64 when ``acc='f64'``), k largest per
+    query, best first, ties by row position ascending.
+
+    ``q``        [B, d] values already in the index's storage family (fp32 array of the values the GPU will
+                 see, i.e. already rounded to fp16/fp8 when the index is fp16/fp8).
+    ``x_stored`` [N, d] stored rows (``quantize_rows`` output).
+    Returns ``(scores [B, kk] float32, ids [B, kk] int64, pos [B, kk] int64)`` with ``kk = min(k, N)``.
+    The N axis is processed in chunks so the B x chunk block stays cache resident.
+    """
+    q = np.ascontiguousarray(q, dtype=np.float64 if acc == "f64" else np.float32)
+    n = x_stored.shape[0]
+    b = q.shape[0]
+    kk = min(k, n)
+    best_s = np.full((b, 0), 0, dtype=q.dtype)
+    best_p = np.zeros((b, 0), dtype=np.int64)
+    for c0 in range(0, n, chunk):
+        c1 = min(n, c0 + chunk)
+        xc = stored_to_f32(x_stored[c0:c1], dtype).astype(q.dtype, copy=False)
+        s = q @ xc.T  # [B, c]
+        c = c1 - c0
+        if c > kk:
+            # every score >= the kk-th largest survives (keeps all members of a boundary tie group)
+            part = np.partition(s, c - kk, axis=1)[:, c - kk]
+            keep = s >= part[:, None]
+            width = int(keep.sum(axis=1).max())
+            # gather survivors row by row, padded with -inf
+            order = np.argsort(~keep, axis=1, kind="stable")[:, :width]  # survivor positions, ascending
+            cs = np.take_along_axis(s, order, axis=1)
+            valid = np.take_along_axis(keep, order, axis=1)
+            cs = np.where(valid, cs, -np.inf)
+            cp = order.astype(np.int64) + c0
+        else:
+            cs = s
+            cp = np.broadcast_to(np.arange(c0, c1, dtype=np.int64), (b, c)).copy()
+        ms = np.concatenate([best_s, cs], axis=1)
+        mp = np.concatenate([best_p, cp], axis=1)
+        new_s = np.empty((b, kk), dtype=q.dtype)
+        new_p = np.empty((b, kk), dtype=np.int64)
+        for i in range(b):
+            o = _order_desc_pos_asc(ms[i], mp[i])[:kk]
+            new_s[i] = ms[i, o]
+            new_p[i] = mp[i, o]
+        best_s, best_p = new_s, new_p
+    out_ids = position_to_id(best_p, ids, id_base)
+    return best_s.astype(np.float32), out_ids, best_p
+
+
+def position_to_id(pos: np.ndarray, ids: np.ndarray | None, id_base: int = 0) -> np.ndarray:
+    """faiss ``IDMap``: external id of a row position (``ids[pos]``, or ``id_base + pos`` without an id vector;
+    a fresh sqlite AUTOINCREMENT table gives ``id_base = 1``, ``setup_db.py:14``)."""
+    pos = np.asarray(pos, dtype=np.int64)
+    if ids is None:
+        return pos + np.int64(id_base)
+    return np.asarray(ids, dtype=np.int64)[pos]
+
+
+def full_scores(q: np.ndarray, x_stored: np.ndarray, dtype: int = DTYPE_F32, acc: str = "f64") -> np.ndarray:
+    """Dense [B, N] score matrix (small N only) used by the tie-aware comparator."""
+    t = np.float64 if acc == "f64" else np.float32
+    return np.asarray(q, dtype=t) @ stored_to_f32(x_stored, dtype).astype(t).T
+
+
+def merge_shards(scores: np.ndarray, ids: np.ndarray, k: int):
+    """Final merge after the all-gather: ``scores``/``ids`` are [R, B, k_r] per-shard results (each already
+    sorted best first, padded with ``-inf`` / ``-1``); shards are contiguous row ranges in rank order, so the
+    global tie order (score desc, row position asc) is (score desc, rank asc, slot asc)."""
+    scores = np.asarray(scores, dtype=np.float32)
+    ids = np.asarray(ids, dtype=np.int64)
+    r, b, kr = scores.shape
+    flat_s = scores.transpose(1, 0, 2).reshape(b, r * kr)
+    flat_i = ids.transpose(1, 0, 2).reshape(b, r * kr)
+    seq = np.arange(r * kr, dtype=np.int64)  # rank-major, slot-minor
+    kk = min(k, r * kr)
+    out_s = np.empty((b, kk), dtype=np.float32)
+    out_i = np.empty((b, kk), dtype=np.int64)
+    for i in range(b):
+        o = _order_desc_pos_asc(flat_s[i], seq)[:kk]
+        out_s[i] = flat_s[i, o]
+        out_i[i] = flat_i[i, o]
+    return out_s, out_i
+
+
+def recall_at_k(got_ids: np.ndarray, ref_ids: np.ndarray) -> float:
+    """mean |got ∩ ref| / k over queries."""
+    got_ids = np.asarray(got_ids)
+    ref_ids = np.asarray(ref_ids)
+    hits = [len(set(g.tolist()) & set(r.tolist())) for g, r in zip(got_ids, ref_ids)]
+    return float(np.mean(hits)) / ref_ids.shape[1]
+
+
+# ---- tie-aware comparison (SURVEY.md section 8d "Parity protocol") ---------------------------------------------
+
+def check_topk(got_scores: np.ndarray, got_pos: np.ndarray, s_full: np.ndarray, k: int, *, score_tol: float = 1e-5,
+               tie_tol: float = 2e-6) -> None:
+    """Assert a GPU result against the dense fp64 oracle scores ``s_full`` [B, N].
+
+    * every returned score is within ``score_tol`` of the oracle score of the returned row,
+    * returned scores are non-increasing (within ``tie_tol``), rows are distinct,
+    * rank-by-rank: the id must equal the oracle id wherever the oracle's neighbouring gaps exceed ``tie_tol``;
+      inside a near-tie group only set membership is required: no row outside the result may beat the result's
+      last score by more than ``tie_tol``, and every returned row is within ``tie_tol`` of deserving its rank.
+    """
+    b, n = s_full.shape
+    kk = min(k, n)
+    got_scores = np.asarray(got_scores)[:, :kk]
+    got_pos = np.asarray(got_pos)[:, :kk]
+    order = np.argsort(-s_full, axis=1, kind="stable")  # score desc, position asc
+    for i in range(b):
+        gp = got_pos[i]
+        assert len(set(gp.tolist())) == kk, f"query {i}: duplicate rows {gp}"
+        assert gp.min() >= 0 and gp.max() < n, f"query {i}: row out of range {gp}"
+        ref_sc = s_full[i, gp]
+        err = np.abs(got_scores[i].astype(np.float64) - ref_sc).max()
+        assert err <= score_tol, f"query {i}: score error {err} > {score_tol}"
+        assert np.all(np.diff(ref_sc) <= tie_tol), f"query {i}: result not sorted: {ref_sc}"
+        ro = order[i]
+        ref_top = s_full[i, ro[: kk + 1]] if n > kk else np.append(s_full[i, ro[:kk]], -np.inf)
+        for j in range(kk):
+            lo_gap = ref_top[j] - ref_top[j + 1]
+            hi_gap = ref_top[j - 1] - ref_top[j] if j > 0 else np.inf
+            if lo_gap > tie_tol and hi_gap > tie_tol:
+                assert gp[j] == ro[j], f"query {i} rank {j}: got row {gp[j]} want {ro[j]} (gaps {hi_gap}, {lo_gap})"
+            else:
+                assert abs(ref_sc[j] - ref_top[j]) <= tie_tol, (
+                    f"query {i} rank {j}: row {gp[j]} score {ref_sc[j]} not within tie_tol of oracle {ref_top[j]}")
+        # nothing outside the result beats its last element by more than tie_tol
+        mask = np.ones(n, dtype=bool)
+        mask[gp] = False
+        if mask.any():
+            assert s_full[i, mask].max() <= ref_sc[-1] + tie_tol, f"query {i}: a better row was left out"

@@ -1,0 +1,119 @@
+"""ctypes binding of ``libvqa_retrieval.so`` (the C ABI declared in ``include/vqa_retrieval.h``).
+
+There is no CPU fallback: if the shared library is missing or a call fails this module raises.  PyTorch is used
+by the callers only for device memory and streams; no torch type crosses this boundary -- only raw device
+pointers (``tensor.data_ptr()``) and the ``hipStream_t`` of ``torch.cuda.current_stream()``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvqa_retrieval.so")
+
+VQA_F32, VQA_F16, VQA_FP8_E4M3 = 0, 1, 2
+VQA_ROWS_BORROW = 1
+VQA_QUERY_TILE = 256
+VQA_POOL_CLS, VQA_POOL_MEAN = 0, 1
+
+DTYPE_NAMES = {"fp32": VQA_F32, "f32": VQA_F32, "float32": VQA_F32, "fp16": VQA_F16, "f16": VQA_F16,
+               "float16": VQA_F16, "fp8": VQA_FP8_E4M3, "fp8_e4m3": VQA_FP8_E4M3, "e4m3": VQA_FP8_E4M3}
+DTYPE_BYTES = {VQA_F32: 4, VQA_F16: 2, VQA_FP8_E4M3: 1}
+
+# every symbol include/vqa_retrieval.h declares (tests/test_capi_symbols.py checks the two lists agree)
+EXPORTS = (
+    "vqa_version", "vqa_last_error", "vqa_index_create", "vqa_index_destroy", "vqa_index_size", "vqa_index_dim",
+    "vqa_index_dtype", "vqa_index_search", "vqa_merge_topk", "vqa_index_launch_info", "vqa_index_set_timing",
+    "vqa_index_get_timing", "vqa_encoder_create",
+    "vqa_encoder_destroy", "vqa_encoder_forward", "vqa_normalize_convert",
+)
+
+
+class VqaError(RuntimeError):
+    """A libvqa_retrieval call returned a negative status."""
+
+
+class LaunchInfo(ctypes.Structure):
+    _fields_ = [("grid", ctypes.c_int32), ("block", ctypes.c_int32), ("lds_bytes", ctypes.c_int32),
+                ("rows_per_tile", ctypes.c_int32), ("rows_per_launch", ctypes.c_int64),
+                ("bytes_per_launch", ctypes.c_int64), ("flops_per_launch", ctypes.c_int64),
+                ("seed_grid", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class EncoderConfig(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("vocab_size", "hidden", "layers", "heads", "ffn", "max_pos", "type_vocab",
+                                              "pad_id")] + [("ln_eps", ctypes.c_float)]
+
+
+_F = ctypes.POINTER(ctypes.c_float)
+
+
+class EncoderLayerWeights(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("wq", "bq", "wk", "bk", "wv", "bv", "wo", "bo", "ln1_g", "ln1_b", "w1",
+                                               "b1", "w2", "b2", "ln2_g", "ln2_b")]
+
+
+class EncoderWeights(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in ("word_emb", "pos_emb", "type_emb", "emb_ln_g", "emb_ln_b")] + [
+        ("layer", ctypes.POINTER(EncoderLayerWeights))]
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library (once).  Raises ``FileNotFoundError`` with the build hint when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: build it with `python -m vietnamese_qa_system_amd.build` "
+            "(hipcc, gfx950).  There is no CPU fallback for the retrieval path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    c = ctypes
+    lib.vqa_version.restype = c.c_int
+    lib.vqa_last_error.restype = c.c_char_p
+    lib.vqa_index_create.argtypes = [c.POINTER(c.c_void_p), c.c_int, c.c_int64, c.c_int32, c.c_int32, c.c_void_p,
+                                     c.c_void_p, c.c_int64, c.c_uint32]
+    lib.vqa_index_destroy.argtypes = [c.c_void_p]
+    lib.vqa_index_destroy.restype = None
+    lib.vqa_index_size.argtypes = [c.c_void_p]
+    lib.vqa_index_size.restype = c.c_int64
+    lib.vqa_index_dim.argtypes = [c.c_void_p]
+    lib.vqa_index_dim.restype = c.c_int32
+    lib.vqa_index_dtype.argtypes = [c.c_void_p]
+    lib.vqa_index_dtype.restype = c.c_int32
+    lib.vqa_index_search.argtypes = [c.c_void_p, c.c_void_p, c.c_int32, c.c_int32, c.c_int32, c.c_void_p, c.c_void_p,
+                                     c.c_void_p, c.c_void_p]
+    lib.vqa_merge_topk.argtypes = [c.c_void_p, c.c_void_p, c.c_int32, c.c_int32, c.c_int32, c.c_int32, c.c_void_p,
+                                   c.c_void_p, c.c_void_p]
+    lib.vqa_index_launch_info.argtypes = [c.c_void_p, c.c_int32, c.c_int32, c.POINTER(LaunchInfo)]
+    lib.vqa_index_set_timing.argtypes = [c.c_void_p, c.c_int32]
+    lib.vqa_index_get_timing.argtypes = [c.c_void_p, c.POINTER(c.c_double), c.POINTER(c.c_int64)]
+    lib.vqa_encoder_create.argtypes = [c.POINTER(c.c_void_p), c.c_int, c.POINTER(EncoderConfig),
+                                       c.POINTER(EncoderWeights), c.c_int32]
+    lib.vqa_encoder_destroy.argtypes = [c.c_void_p]
+    lib.vqa_encoder_destroy.restype = None
+    lib.vqa_encoder_forward.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int32, c.c_int32, c.c_int32, c.c_int32,
+                                        c.c_void_p, c.c_void_p]
+    lib.vqa_normalize_convert.argtypes = [c.c_void_p, c.c_int64, c.c_int32, c.c_int32, c.c_int32, c.c_void_p, c.c_void_p]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if fn.restype is c.c_int and name not in ("vqa_version",):
+            fn.restype = c.c_int
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    """Raise ``VqaError`` (ValueError-like for bad arguments) when a call failed."""
+    if status == 0:
+        return
+    msg = load().vqa_last_error().decode("utf-8", "replace")
+    if status == -1:
+        raise ValueError(f"{what}: {msg}")
+    if status == -3:
+        raise MemoryError(f"{what}: {msg}")
+    raise VqaError(f"{what} failed ({status}): {msg}")

@@ -1,0 +1,61 @@
+"""Builds libvqa_retrieval.so (hand-written HIP, gfx950 only) in-tree with hipcc.
+
+    python -m vietnamese_qa_system_amd.build [--force]
+
+The shared library is written to ``vietnamese_qa_system_amd/lib/`` so it travels with the source tree to the
+GPU box; it is git-ignored (``*.so``).  hipcc cross-compiles gfx950 without a GPU.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB_DIR = os.path.join(HERE, "lib")
+OBJ_DIR = os.path.join(HERE, "lib", "obj")
+LIB_PATH = os.path.join(LIB_DIR, "libvqa_retrieval.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-function"]
+
+
+def sources() -> list[str]:
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _deps_mtime() -> float:
+    files = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    files += [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE)]
+    return max(os.path.getmtime(f) for f in files)
+
+
+def _compile(src: str) -> str:
+    obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+    cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return obj
+
+
+def build(force: bool = False) -> str:
+    """Compile every .hip under csrc/ for gfx950 and link the C-ABI shared library.  Returns its path."""
+    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= _deps_mtime():
+        return LIB_PATH
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(_compile, sources()))
+    cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB_PATH, *objs]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,145 @@
+// K2 -- merges of sorted candidate lists (one workgroup per query), gfx950 only.
+//
+//  * merge_partials: the per-workgroup lists K1 flushed (vqa_key, [parts][256][k]) -> final top-k of the shard:
+//    fp32 score, external id (faiss IDMap step: ids[pos] or id_base + pos; ids originate at
+//    inference_pipeline/db_utils/heavy_ranker.py:76), row position; optionally the k-th best score per query
+//    (threshold seed for the second scoring pass).
+//  * merge_shards: the [R, B, k] (score, id) candidates after the RCCL all-gather -> [B, k_out]; ties resolve by
+//    (rank asc, slot asc) which is global row position ascending for contiguous row shards.
+// Selection: k rounds of "largest key strictly below the previous winner" (keys are distinct), each round one
+// wavefront-shuffle max reduction + a 4-entry LDS exchange between the waves.
+#include "vqa_common.h"
+
+namespace {
+
+constexpr int kMergeThreads = 256;
+
+__device__ __forceinline__ vqa_key wave_max_key(vqa_key v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const vqa_key o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// block-wide max of per-thread values; every thread gets the result.  red: LDS [4].
+__device__ __forceinline__ vqa_key block_max_key(vqa_key v, vqa_key* red) {
+    v = wave_max_key(v);
+    const int wave = threadIdx.x >> 6;
+    __syncthreads();  // previous round's readers are done with red[]
+    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    __syncthreads();
+    vqa_key m = red[0];
+#pragma unroll
+    for (int w = 1; w < kMergeThreads / 64; ++w) m = red[w] > m ? red[w] : m;
+    return m;
+}
+
+__global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa_key* __restrict__ partial, int parts,
+                                                                       int k, const long long* __restrict__ ids,
+                                                                       long long id_base, float* __restrict__ out_scores,
+                                                                       long long* __restrict__ out_ids,
+                                                                       long long* __restrict__ out_pos,
+                                                                       float* __restrict__ out_thr) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    vqa_key* keys = reinterpret_cast<vqa_key*>(smem);  // [parts * k]
+    vqa_key* red = keys + (size_t)parts * k;           // [4]
+    const int q = blockIdx.x;
+    const int m = parts * k;
+    for (int i = threadIdx.x; i < m; i += kMergeThreads) {
+        const int p = i / k, j = i - p * k;
+        keys[i] = partial[((size_t)p * VQA_QUERY_TILE + q) * k + j];
+    }
+    __syncthreads();
+    vqa_key prev = ~0ull;
+    for (int r = 0; r < k; ++r) {
+        vqa_key best = 0ull;
+        for (int i = threadIdx.x; i < m; i += kMergeThreads) {
+            const vqa_key v = keys[i];
+            best = (v < prev && v > best) ? v : best;
+        }
+        best = block_max_key(best, red);
+        if (threadIdx.x == 0) {
+            const bool empty = best == 0ull;
+            const long long pos = empty ? -1 : (long long)vqa_key_pos(best);
+            if (out_scores) out_scores[(size_t)q * k + r] = empty ? -INFINITY : vqa_key_score(best);
+            if (out_ids) out_ids[(size_t)q * k + r] = empty ? -1 : (ids ? ids[pos] : id_base + pos);
+            if (out_pos) out_pos[(size_t)q * k + r] = pos;
+            if (out_thr && r == k - 1) out_thr[q] = empty ? -INFINITY : vqa_key_score(best);
+        }
+        prev = best;  // 0 once the candidates are exhausted: later rounds stay empty
+        if (best == 0ull) prev = 0ull;
+    }
+}
+
+__global__ __launch_bounds__(kMergeThreads) void merge_shards_kernel(const float* __restrict__ scores,
+                                                                     const long long* __restrict__ ids, int R, int B,
+                                                                     int k, int k_out, float* __restrict__ out_scores,
+                                                                     long long* __restrict__ out_ids) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    vqa_key* keys = reinterpret_cast<vqa_key*>(smem);  // [R * k]
+    vqa_key* red = keys + (size_t)R * k;
+    const int q = blockIdx.x;
+    const int m = R * k;
+    for (int i = threadIdx.x; i < m; i += kMergeThreads) {
+        const int r = i / k, j = i - r * k;
+        const size_t src = ((size_t)r * B + q) * k + j;
+        // padded slots carry id -1: they must lose against every real candidate, including score -inf
+        keys[i] = ids[src] < 0 ? 0ull : vqa_make_key(scores[src], (uint32_t)i);
+    }
+    __syncthreads();
+    vqa_key prev = ~0ull;
+    for (int r = 0; r < k_out; ++r) {
+        vqa_key best = 0ull;
+        for (int i = threadIdx.x; i < m; i += kMergeThreads) {
+            const vqa_key v = keys[i];
+            best = (v < prev && v > best) ? v : best;
+        }
+        best = block_max_key(best, red);
+        if (threadIdx.x == 0) {
+            const bool empty = best == 0ull;
+            size_t src = 0;
+            if (!empty) {
+                const int i = (int)vqa_key_pos(best);
+                const int rr = i / k, j = i - rr * k;
+                src = ((size_t)rr * B + q) * k + j;
+            }
+            out_scores[(size_t)q * k_out + r] = empty ? -INFINITY : scores[src];
+            out_ids[(size_t)q * k_out + r] = empty ? -1 : ids[src];
+        }
+        prev = best;
+    }
+}
+
+}  // namespace
+
+int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t nq, int32_t k, const int64_t* ids,
+                              int64_t id_base, float* out_scores, int64_t* out_ids, int64_t* out_pos, float* out_thr,
+                              int32_t /*out_stride_q*/, hipStream_t stream) {
+    VQA_REQUIRE(parts >= 1 && nq >= 1 && nq <= VQA_QUERY_TILE && k >= 1, "merge_partials: bad shape parts=%d nq=%d k=%d",
+                parts, nq, k);
+    const size_t lds = ((size_t)parts * k + 4) * sizeof(vqa_key);
+    VQA_REQUIRE(lds <= 64 * 1024, "merge_partials: %d lists x k=%d do not fit in LDS", parts, k);
+    hipLaunchKernelGGL(merge_partials_kernel, dim3(nq), dim3(kMergeThreads), lds, stream, partial, parts, k,
+                       reinterpret_cast<const long long*>(ids), (long long)id_base, out_scores,
+                       reinterpret_cast<long long*>(out_ids), reinterpret_cast<long long*>(out_pos), out_thr);
+    VQA_HIP_CHECK(hipGetLastError());
+    return VQA_OK;
+}
+
+extern "C" int vqa_merge_topk(const float* scores, const int64_t* ids, int32_t R, int32_t B, int32_t k, int32_t k_out,
+                              float* out_scores, int64_t* out_ids, void* hip_stream) {
+    VQA_REQUIRE(scores && ids && out_scores && out_ids, "vqa_merge_topk: null pointer");
+    VQA_REQUIRE(R >= 1 && B >= 1 && k >= 1 && k_out >= 1, "vqa_merge_topk: bad shape R=%d B=%d k=%d k_out=%d", R, B, k,
+                k_out);
+    VQA_REQUIRE((long long)R * k <= 8 * 1024, "vqa_merge_topk: R*k=%lld candidates per query exceed 8192",
+                (long long)R * k);
+    VQA_REQUIRE(k_out <= R * k, "vqa_merge_topk: k_out=%d exceeds the R*k=%d candidates", k_out, R * k);
+    const size_t lds = ((size_t)R * k + 4) * sizeof(vqa_key);
+    hipLaunchKernelGGL(merge_shards_kernel, dim3(B), dim3(kMergeThreads), lds, (hipStream_t)hip_stream, scores,
+                       reinterpret_cast<const long long*>(ids), R, B, k, k_out, out_scores,
+                       reinterpret_cast<long long*>(out_ids));
+    VQA_HIP_CHECK(hipGetLastError());
+    return VQA_OK;
+}

@@ -1,0 +1,75 @@
+// Shared host/device helpers for libvqa_retrieval (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "vqa_retrieval.h"
+
+// ---- error plumbing (thread-local message, negative codes; nothing throws across the ABI) -----------------
+void vqa_set_error(const char* fmt, ...);
+#define VQA_HIP_CHECK(expr)                                                                       \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            vqa_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return VQA_EHIP;                                                                      \
+        }                                                                                         \
+    } while (0)
+#define VQA_REQUIRE(cond, ...)       \
+    do {                             \
+        if (!(cond)) {               \
+            vqa_set_error(__VA_ARGS__); \
+            return VQA_EINVAL;       \
+        }                            \
+    } while (0)
+
+// ---- candidate keys -----------------------------------------------------------------------------------------
+// A candidate (score, row position) is one u64 whose unsigned order is the result order
+// "score descending, then row position ascending":  key = ordered(score) << 32 | (0xFFFFFFFF - pos).
+// key 0 is "empty" (smaller than every real candidate, including score = -inf).
+typedef unsigned long long vqa_key;
+
+__host__ __device__ __forceinline__ uint32_t vqa_f32_ordered(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float vqa_ordered_f32(uint32_t o) {
+    uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+    return __builtin_bit_cast(float, u);
+}
+__host__ __device__ __forceinline__ vqa_key vqa_make_key(float score, uint32_t pos) {
+    return ((vqa_key)vqa_f32_ordered(score) << 32) | (vqa_key)(0xFFFFFFFFu - pos);
+}
+__host__ __device__ __forceinline__ float vqa_key_score(vqa_key k) { return vqa_ordered_f32((uint32_t)(k >> 32)); }
+__host__ __device__ __forceinline__ uint32_t vqa_key_pos(vqa_key k) { return 0xFFFFFFFFu - (uint32_t)k; }
+
+// ---- kernel launchers implemented in the .hip files ---------------------------------------------------------
+struct ScoreTopkArgs {
+    const void* x;        // [n, d_pad] index rows (element type per dtype)
+    const void* q;        // [VQA_QUERY_TILE, d_pad] staged query tile, same element type, zero padded
+    const float* thr_init; // [VQA_QUERY_TILE] starting thresholds or nullptr (-inf)
+    vqa_key* partial;     // [grid, VQA_QUERY_TILE, k] per-workgroup sorted partial lists (output)
+    int64_t n;            // rows in the shard
+    int32_t d_pad;        // padded row length in elements (multiple of 64)
+    int32_t nq;           // valid queries in the tile (1..VQA_QUERY_TILE)
+    int32_t k;
+    int32_t tile_begin;   // first corpus tile (of 256 rows) this launch covers
+    int32_t tile_end;     // one past the last
+    int32_t grid;         // workgroups
+};
+int vqa_launch_score_topk(int dtype, const ScoreTopkArgs& a, hipStream_t stream);
+int vqa_score_topk_lds_bytes(int dtype, int k);
+int vqa_score_topk_max_k(int dtype);
+
+// merge `parts` sorted partial lists per query -> final [B, k] (scores, external ids, positions) and/or thresholds
+int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t nq, int32_t k, const int64_t* ids,
+                              int64_t id_base, float* out_scores, int64_t* out_ids, int64_t* out_pos,
+                              float* out_thr /* k-th best score per query or nullptr */, int32_t out_stride_q,
+                              hipStream_t stream);
+
+int vqa_launch_stage_queries(const void* q, int32_t q_dtype, int32_t nq, int32_t d, int32_t d_pad, int32_t dtype,
+                             void* out /* [VQA_QUERY_TILE, d_pad] */, hipStream_t stream);
+int vqa_launch_pad_rows(const void* rows, int64_t n, int32_t d, int32_t d_pad, int32_t elem_bytes, void* out,
+                        hipStream_t stream);
