@@ -100,7 +100,7 @@ def main():
 
     n, d, b, k = args.docs_per_gpu, args.dim, args.batch, args.k
     shard = build_shard(n, d, 1234 + rank, device)
-    index = DeviceIndex(shard, id_base=1 + rank * n, dtype="fp16", device=local_rank, borrow=(d % 64 == 0))
+    index = DeviceIndex(shard, id_base=1 + rank * n, dtype="fp16", device=local_rank)
     gq = torch.Generator(device=device)
     gq.manual_seed(99)
     q = torch.randn((b, d), generator=gq, device=device, dtype=torch.float32)
@@ -149,7 +149,7 @@ def main():
                                    + (", RCCL all-gather + merge" if world > 1 else ""),
                        "docs_total": world * n, "docs_per_gpu": n, "dim": d, "batch": b, "k": k,
                        "parallelism": f"row-shard x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "score_topk_f16_kernel<true>", "achieved": round(achieved, 1) if achieved else None,
+            "roofline": {"bound": "hbm", "kernel": "score_topk_f16_kernel<1>", "achieved": round(achieved, 1) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "traffic": traffic, "kernel_ms": round(kern_ms, 4), "launches": launches,
                          "bytes_per_launch": info.bytes_per_launch, "flops_per_launch": info.flops_per_launch,

@@ -38,7 +38,7 @@ extern "C" {
 #define VQA_FP8_E4M3 2 /* OCP e4m3fn (gfx950), one byte per element */
 
 /* vqa_index_create flags */
-#define VQA_ROWS_BORROW 1 /* rows is a DEVICE pointer that outlives the index; do not copy (needs d % 64 == 0) */
+#define VQA_INDEX_HAS_IDS 1 /* reserve the id vector even though ids_or_null is NULL (filled later by vqa_index_set_rows) */
 
 /* limits of the fused scoring + top-k kernel */
 #define VQA_MAX_K 16       /* top-k per query handled in LDS candidate lists (BASELINE k = 10; reference k = 1) */
@@ -51,12 +51,19 @@ int vqa_version(void);
 const char* vqa_last_error(void);
 
 /* ---- index: replaces txtai's ANN backend (faiss IndexFlatIP + IDMap) behind Embeddings.index/load -----------
- * heavy_ranker.py:86-94.  rows: [n, d] row-major, host or device pointer (hipMemcpyDefault), element type
- * `dtype`, expected L2-normalised by the caller (txtai normalises at index time).  ids: [n] int64 external ids
- * (host or device) or NULL, in which case id = id_base + row position (sqlite AUTOINCREMENT rowids start at 1,
- * setup_db.py:14). */
-int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t d, int32_t dtype, const void* rows,
+ * heavy_ranker.py:86-94.  The index keeps its rows in HBM in a TILED fp16 layout (tiles of 256 rows x K-blocks of 32
+ * elements, each a contiguous 16 KiB block in the exact bank-conflict-free LDS image of the scoring kernel), so a
+ * search streams the shard as one sequential read.  vqa_index_create allocates a shard of n rows of length d and,
+ * when `rows` is not NULL, fills it: rows [n, d] row-major, host or device pointer, element type rows_dtype
+ * (VQA_F32 or VQA_F16; converted to the storage type with round-to-nearest-even), expected L2-normalised by the
+ * caller (txtai normalises at index time).  ids: [n] int64 external ids (host or device) or NULL, in which case
+ * id = id_base + row position (sqlite AUTOINCREMENT rowids start at 1, setup_db.py:14).
+ * vqa_index_set_rows (faiss `add_with_ids` counterpart) fills rows [first, first + count) later, chunk by chunk, so
+ * a 15-123 GB shard never needs a second full copy; it synchronises before returning. */
+int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t d, int32_t dtype, const void* rows, int32_t rows_dtype,
                      const int64_t* ids_or_null, int64_t id_base, uint32_t flags);
+int vqa_index_set_rows(vqa_index* index, int64_t first, int64_t count, const void* rows, int32_t rows_dtype,
+                       const int64_t* ids_or_null);
 void vqa_index_destroy(vqa_index* index);
 int64_t vqa_index_size(const vqa_index* index);
 int32_t vqa_index_dim(const vqa_index* index);

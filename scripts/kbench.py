@@ -1,0 +1,36 @@
+"""Dev helper: time vqa_index_search on a synthetic fp16 shard (no oracle, no checks).  VQA_LIB selects the library."""
+import argparse, os, sys, time
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vietnamese_qa_system_amd.index import DeviceIndex
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=10_000_000)
+ap.add_argument("--d", type=int, default=768)
+ap.add_argument("--b", type=int, default=256)
+ap.add_argument("--k", type=int, default=10)
+ap.add_argument("--steps", type=int, default=10)
+args = ap.parse_args()
+dev = torch.device("cuda", 0)
+gen = torch.Generator(device=dev); gen.manual_seed(1234)
+buf = torch.empty((args.n, args.d), dtype=torch.float16, device=dev)
+for c0 in range(0, args.n, 1 << 18):
+    c1 = min(args.n, c0 + (1 << 18))
+    x = torch.randn((c1 - c0, args.d), generator=gen, device=dev)
+    x /= x.norm(dim=1, keepdim=True)
+    buf[c0:c1] = x.half()
+ix = DeviceIndex(buf, dtype="fp16")
+q = torch.randn((args.b, args.d), generator=gen, device=dev)
+q = (q / q.norm(dim=1, keepdim=True)).half()
+for _ in range(3):
+    ix.search(q, args.k)
+ix.set_timing(True)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    ix.search(q, args.k)
+torch.cuda.synchronize()
+el = (time.perf_counter() - t0) / args.steps * 1e3
+ms, n = ix.get_timing()
+print(f"{os.environ.get('VQA_LIB', 'default'):60s} step {el:.3f} ms  main kernel {ms / max(n, 1):.3f} ms  "
+      f"-> {args.n * args.d * 2 / (ms / max(n, 1) * 1e-3) / 1e9:.0f} GB/s, {2 * 256 * args.n * args.d / (ms / max(n, 1) * 1e-3) / 1e12:.0f} TF", flush=True)

@@ -25,7 +25,7 @@ def _mk(n, d, b, seed):
 
 def _search(x16, q16, k, ids=None, id_base=0):
     from vietnamese_qa_system_amd.index import DeviceIndex
-    ix = DeviceIndex(torch.from_numpy(x16), ids=ids, id_base=id_base, dtype="fp16", device=0)
+    ix = DeviceIndex(x16, ids=ids, id_base=id_base, dtype="fp16", device=0)
     s, i, p = ix.search(torch.from_numpy(q16).cuda(), k, return_positions=True)
     torch.cuda.synchronize()
     out = s.cpu().numpy(), i.cpu().numpy(), p.cpu().numpy()
@@ -111,7 +111,7 @@ def test_two_pass_large(native_lib):
 def test_argument_errors(native_lib):
     from vietnamese_qa_system_amd.index import DeviceIndex
     x, q = _mk(100, 64, 2, seed=0)
-    ix = DeviceIndex(torch.from_numpy(x), dtype="fp16")
+    ix = DeviceIndex(x, dtype="fp16")
     with pytest.raises(ValueError):
         ix.search(torch.from_numpy(q).cuda(), 1000)
     with pytest.raises(ValueError):

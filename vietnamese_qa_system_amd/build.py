@@ -32,9 +32,9 @@ def _deps_mtime() -> float:
     return max(os.path.getmtime(f) for f in files)
 
 
-def _compile(src: str) -> str:
-    obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
-    cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
+def _compile(src: str, extra=(), tag: str = "") -> str:
+    obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + tag + ".o")
+    cmd = [HIPCC, *FLAGS, *extra, "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -55,6 +55,17 @@ def build(force: bool = False) -> str:
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     return LIB_PATH
+
+
+def build_variant(tag: str, defines: list[str]) -> str:
+    """Dev helper: a second copy of the library with extra -D flags (timing ablations), lib/libvqa_retrieval_<tag>.so."""
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    objs = [_compile(src, tuple(f"-D{d}" for d in defines), "_" + tag) for src in sources()]
+    out = os.path.join(LIB_DIR, f"libvqa_retrieval_{tag}.so")
+    r = subprocess.run([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", out, *objs], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    return out
 
 
 if __name__ == "__main__":

@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "vqa_common.h"
@@ -27,16 +28,18 @@ struct vqa_index {
     int device = 0;
     int64_t n = 0;
     int32_t d = 0, d_pad = 0, dtype = 0;
-    void* rows = nullptr;  // [n, d_pad]
-    bool rows_owned = false;
+    void* rows = nullptr;    // TILED layout: ceil(n/256) tiles x (d_pad/32) blocks of 16 KiB (convert.hip)
+    size_t rows_bytes = 0;
     int64_t* ids = nullptr;  // [n] or null
     int64_t id_base = 0;
     int num_cu = 0;
     int max_grid = 0;
     bool two_pass = true;
     // workspace (allocated once; search never allocates)
-    void* q_stage = nullptr;     // [256, d_pad] index element type
-    vqa_key* partial = nullptr;  // [2 * max_grid, 256, max_k]
+    void* q_stage = nullptr;     // one 256-row tile in TILED layout
+    void* q_rows = nullptr;      // staging for host -> device row chunks in set_rows (lazy)
+    size_t q_rows_bytes = 0;
+    vqa_key* partial = nullptr;  // [max_grid, 256, max(max_k, seeds per query)]: seed pass output, then main pass lists
     float* thr0 = nullptr;       // [256]
     // opt-in kernel timing (bench.py): event pairs around the main scoring kernel
     bool timing = false;
@@ -59,24 +62,72 @@ struct DeviceGuard {
 extern "C" void vqa_index_destroy(vqa_index* ix) {
     if (!ix) return;
     DeviceGuard g(ix->device);
-    if (ix->rows_owned && ix->rows) (void)hipFree(ix->rows);
+    if (ix->rows) (void)hipFree(ix->rows);
     if (ix->ids) (void)hipFree(ix->ids);
     if (ix->q_stage) (void)hipFree(ix->q_stage);
+    if (ix->q_rows) (void)hipFree(ix->q_rows);
     if (ix->partial) (void)hipFree(ix->partial);
     if (ix->thr0) (void)hipFree(ix->thr0);
     for (hipEvent_t e : ix->ev) (void)hipEventDestroy(e);
     delete ix;
 }
 
+extern "C" int vqa_index_set_rows(vqa_index* ix, int64_t first, int64_t count, const void* rows, int32_t src_dtype,
+                                  const int64_t* ids_or_null) {
+    VQA_REQUIRE(ix, "vqa_index_set_rows: index is null");
+    VQA_REQUIRE(first >= 0 && count >= 0 && first + count <= ix->n, "vqa_index_set_rows: rows [%lld, %lld) outside [0, %lld)",
+                (long long)first, (long long)(first + count), (long long)ix->n);
+    VQA_REQUIRE(src_dtype == VQA_F32 || src_dtype == VQA_F16, "vqa_index_set_rows: source element type %d is not f32/f16",
+                src_dtype);
+    VQA_REQUIRE((ids_or_null != nullptr) == (ix->ids != nullptr) || count == 0,
+                "vqa_index_set_rows: the index was created %s an id vector", ix->ids ? "with" : "without");
+    if (count == 0) return VQA_OK;
+    VQA_REQUIRE(rows, "vqa_index_set_rows: rows is null");
+    DeviceGuard guard(ix->device);
+    hipPointerAttribute_t attr;
+    bool on_device = hipPointerGetAttributes(&attr, rows) == hipSuccess && attr.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();  // an unregistered host pointer reports an error: not ours
+    const int seb = src_dtype == VQA_F32 ? 4 : 2;
+    if (on_device) {
+        int rc = vqa_launch_tile_rows(rows, src_dtype, first, count, count, ix->d, ix->d_pad, ix->rows, nullptr);
+        if (rc != VQA_OK) return rc;
+    } else {
+        // host rows: stage through a device buffer, 64 Mi elements at a time
+        const int64_t chunk_rows = std::max<int64_t>(1, (64ll << 20) / ix->d);
+        const size_t need = (size_t)std::min(chunk_rows, count) * ix->d * seb;
+        if (ix->q_rows_bytes < need) {
+            if (ix->q_rows) (void)hipFree(ix->q_rows);
+            ix->q_rows = nullptr;
+            ix->q_rows_bytes = 0;
+            if (hipMalloc(&ix->q_rows, need) != hipSuccess) {
+                vqa_set_error("vqa_index_set_rows: hipMalloc of %zu staging bytes failed", need);
+                return VQA_ENOMEM;
+            }
+            ix->q_rows_bytes = need;
+        }
+        for (int64_t c0 = 0; c0 < count; c0 += chunk_rows) {
+            const int64_t c = std::min(chunk_rows, count - c0);
+            VQA_HIP_CHECK(hipMemcpy(ix->q_rows, reinterpret_cast<const char*>(rows) + (size_t)c0 * ix->d * seb,
+                                    (size_t)c * ix->d * seb, hipMemcpyHostToDevice));
+            int rc = vqa_launch_tile_rows(ix->q_rows, src_dtype, first + c0, c, c, ix->d, ix->d_pad, ix->rows, nullptr);
+            if (rc != VQA_OK) return rc;
+            VQA_HIP_CHECK(hipStreamSynchronize(nullptr));
+        }
+    }
+    if (ids_or_null) VQA_HIP_CHECK(hipMemcpy(ix->ids + first, ids_or_null, (size_t)count * 8, hipMemcpyDefault));
+    VQA_HIP_CHECK(hipStreamSynchronize(nullptr));
+    return VQA_OK;
+}
+
 extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t d, int32_t dtype, const void* rows,
-                                const int64_t* ids_or_null, int64_t id_base, uint32_t flags) {
+                                int32_t rows_dtype, const int64_t* ids_or_null, int64_t id_base, uint32_t flags) {
     VQA_REQUIRE(out, "vqa_index_create: out is null");
     *out = nullptr;
-    VQA_REQUIRE(rows || n == 0, "vqa_index_create: rows is null");
     VQA_REQUIRE(n >= 0 && n < 0xFFFFFFFFll, "vqa_index_create: n=%lld outside [0, 2^32-1) rows per shard", (long long)n);
     VQA_REQUIRE(d >= 1 && d <= 65536, "vqa_index_create: d=%d", d);
     VQA_REQUIRE(dtype == VQA_F32 || dtype == VQA_F16 || dtype == VQA_FP8_E4M3, "vqa_index_create: dtype %d", dtype);
-    VQA_REQUIRE(dtype == VQA_F16, "vqa_index_create: only VQA_F16 rows are implemented in this build (dtype %d)", dtype);
+    VQA_REQUIRE(dtype == VQA_F16, "vqa_index_create: only VQA_F16 storage is implemented in this build (dtype %d)", dtype);
+    VQA_REQUIRE((flags & ~(uint32_t)VQA_INDEX_HAS_IDS) == 0, "vqa_index_create: unknown flags 0x%x", flags);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         vqa_set_error("vqa_index_create: no HIP device visible");
@@ -106,73 +157,43 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
     const char* tp = getenv("VQA_TWO_PASS");
     ix->two_pass = !(tp && tp[0] == '0');
     const int eb = elem_bytes(dtype);
-    const bool borrow = (flags & VQA_ROWS_BORROW) != 0;
     int rc = VQA_OK;
     do {
-        if (borrow) {
-            if (ix->d_pad != d) {
-                vqa_set_error("vqa_index_create: VQA_ROWS_BORROW needs d %% 64 == 0 (d=%d)", d);
-                rc = VQA_EINVAL;
-                break;
-            }
-            ix->rows = const_cast<void*>(rows);
-            ix->rows_owned = false;
-        } else if (n > 0) {
-            const size_t bytes = (size_t)n * ix->d_pad * eb;
-            if (hipMalloc(&ix->rows, bytes) != hipSuccess) {
-                vqa_set_error("vqa_index_create: hipMalloc of %zu bytes for the rows failed", bytes);
+        const int64_t tiles = (n + 255) / 256;
+        ix->rows_bytes = (size_t)tiles * 256 * ix->d_pad * eb;
+        if (n > 0) {
+            if (hipMalloc(&ix->rows, ix->rows_bytes) != hipSuccess) {
+                vqa_set_error("vqa_index_create: hipMalloc of %zu bytes for the rows failed", ix->rows_bytes);
                 rc = VQA_ENOMEM;
                 break;
             }
-            ix->rows_owned = true;
-            if (ix->d_pad == d) {
-                if (hipMemcpy(ix->rows, rows, bytes, hipMemcpyDefault) != hipSuccess) {
-                    vqa_set_error("vqa_index_create: copying the rows failed");
-                    rc = VQA_EHIP;
-                    break;
-                }
-            } else {
-                void* tmp = nullptr;
-                const size_t src_bytes = (size_t)n * d * eb;
-                if (hipMalloc(&tmp, src_bytes) != hipSuccess) {
-                    vqa_set_error("vqa_index_create: hipMalloc of %zu staging bytes failed", src_bytes);
-                    rc = VQA_ENOMEM;
-                    break;
-                }
-                hipError_t e = hipMemcpy(tmp, rows, src_bytes, hipMemcpyDefault);
-                if (e == hipSuccess) {
-                    rc = vqa_launch_pad_rows(tmp, n, d, ix->d_pad, eb, ix->rows, nullptr);
-                    if (rc == VQA_OK) e = hipDeviceSynchronize();
-                }
-                (void)hipFree(tmp);
-                if (rc != VQA_OK) break;
-                if (e != hipSuccess) {
-                    vqa_set_error("vqa_index_create: padding the rows failed: %s", hipGetErrorString(e));
-                    rc = VQA_EHIP;
-                    break;
-                }
+            // rows of the ragged last tile and the padded tail of every row must read as zeros
+            if (hipMemset(ix->rows, 0, ix->rows_bytes) != hipSuccess) {
+                vqa_set_error("vqa_index_create: clearing the rows failed");
+                rc = VQA_EHIP;
+                break;
             }
-        }
-        if (ids_or_null && n > 0) {
-            if (hipMalloc((void**)&ix->ids, (size_t)n * 8) != hipSuccess) {
+            if ((ids_or_null || (flags & VQA_INDEX_HAS_IDS)) && hipMalloc((void**)&ix->ids, (size_t)n * 8) != hipSuccess) {
                 vqa_set_error("vqa_index_create: hipMalloc for %lld ids failed", (long long)n);
                 rc = VQA_ENOMEM;
                 break;
             }
-            if (hipMemcpy(ix->ids, ids_or_null, (size_t)n * 8, hipMemcpyDefault) != hipSuccess) {
-                vqa_set_error("vqa_index_create: copying the ids failed");
+            if (ix->ids && !ids_or_null && hipMemset(ix->ids, 0xFF, (size_t)n * 8) != hipSuccess) {
+                vqa_set_error("vqa_index_create: clearing the ids failed");
                 rc = VQA_EHIP;
                 break;
             }
         }
         const int max_k = vqa_score_topk_max_k(dtype);
+        const int list_len = max_k > vqa_score_topk_seeds_per_query() ? max_k : vqa_score_topk_seeds_per_query();
         if (hipMalloc(&ix->q_stage, (size_t)VQA_QUERY_TILE * ix->d_pad * eb) != hipSuccess ||
-            hipMalloc((void**)&ix->partial, (size_t)2 * ix->max_grid * VQA_QUERY_TILE * max_k * sizeof(vqa_key)) != hipSuccess ||
+            hipMalloc((void**)&ix->partial, (size_t)ix->max_grid * VQA_QUERY_TILE * list_len * sizeof(vqa_key)) != hipSuccess ||
             hipMalloc((void**)&ix->thr0, VQA_QUERY_TILE * sizeof(float)) != hipSuccess) {
             vqa_set_error("vqa_index_create: workspace allocation failed");
             rc = VQA_ENOMEM;
             break;
         }
+        if (rows && n > 0) rc = vqa_index_set_rows(ix, 0, n, rows, rows_dtype, ids_or_null);
     } while (0);
     if (rc != VQA_OK) {
         vqa_index_destroy(ix);
@@ -187,23 +208,20 @@ extern "C" int32_t vqa_index_dim(const vqa_index* ix) { return ix ? ix->d : -1; 
 extern "C" int32_t vqa_index_dtype(const vqa_index* ix) { return ix ? ix->dtype : -1; }
 
 struct LaunchPlan {
-    int tiles = 0;   // corpus tiles of 256 rows
-    int grid0 = 0;   // workgroups of the seeding pass (0 = single pass)
-    int grid1 = 0;   // workgroups of the main pass
+    int tiles = 0;  // corpus tiles of 256 rows
+    int grid0 = 0;  // workgroups (= tiles) of the seed pass, 0 = no seeding
+    int grid1 = 0;  // workgroups of the main pass
 };
 
 static LaunchPlan plan_launch(const vqa_index* ix) {
     LaunchPlan p;
     p.tiles = (int)((ix->n + 255) / 256);
     p.grid1 = p.tiles < ix->max_grid ? p.tiles : ix->max_grid;
-    // Two passes when every workgroup has several tiles: the first `grid` tiles are searched alone, their exact
-    // k-th best score per query seeds the thresholds of the pass over the remaining tiles, so the main pass
-    // appends ~10 / (256 * grid) of the scores instead of starting every workgroup from -inf.
-    if (ix->two_pass && p.tiles >= 8 * ix->max_grid) {
-        p.grid0 = ix->max_grid;
-        const int rest = p.tiles - p.grid0;
-        p.grid1 = rest < ix->max_grid ? rest : ix->max_grid;
-    }
+    // Seed pass: the first min(tiles, CUs) tiles are scored once more by the MODE 0 kernel, which only keeps 16
+    // sub-maxima per query and tile; their k-th largest is a valid lower bound of the k-th best score and seeds every
+    // workgroup's thresholds, so the main pass appends ~k / (256 * grid) of the scores instead of flooding its
+    // candidate lists on each workgroup's first tiles.  Costs <= 256 tiles of extra scoring (0.65 % at 10M rows).
+    if (ix->two_pass) p.grid0 = p.grid1;
     return p;
 }
 
@@ -215,8 +233,7 @@ extern "C" int vqa_index_launch_info(const vqa_index* ix, int32_t B, int32_t k, 
     out->block = 512;
     out->lds_bytes = vqa_score_topk_lds_bytes(ix->dtype, k);
     out->rows_per_tile = 256;
-    const int64_t seed_rows = (int64_t)p.grid0 * 256 < ix->n ? (int64_t)p.grid0 * 256 : ix->n;
-    out->rows_per_launch = ix->n - seed_rows;
+    out->rows_per_launch = ix->n;
     out->bytes_per_launch = out->rows_per_launch * (int64_t)ix->d * elem_bytes(ix->dtype);
     out->flops_per_launch = 2 * (int64_t)VQA_QUERY_TILE * out->rows_per_launch * (int64_t)ix->d;
     out->seed_grid = p.grid0;
@@ -277,12 +294,12 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
         if (ix->n == 0) {  // empty shard: every slot is padding
             // reuse the merge kernel on one all-empty partial list
             VQA_HIP_CHECK(hipMemsetAsync(ix->partial, 0, (size_t)VQA_QUERY_TILE * k * sizeof(vqa_key), stream));
-            int rc = vqa_launch_merge_partials(ix->partial, 1, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr, k, stream);
+            int rc = vqa_launch_merge_partials(ix->partial, 1, k, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr, stream);
             if (rc != VQA_OK) return rc;
             continue;
         }
-        int rc = vqa_launch_stage_queries(reinterpret_cast<const char*>(q) + (size_t)q0 * ix->d * qeb, q_dtype, nq, ix->d,
-                                          ix->d_pad, ix->dtype, ix->q_stage, stream);
+        int rc = vqa_launch_tile_rows(reinterpret_cast<const char*>(q) + (size_t)q0 * ix->d * qeb, q_dtype, 0, VQA_QUERY_TILE, nq,
+                                      ix->d, ix->d_pad, ix->q_stage, stream);
         if (rc != VQA_OK) return rc;
         ScoreTopkArgs a;
         a.x = ix->rows;
@@ -291,31 +308,30 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
         a.d_pad = ix->d_pad;
         a.nq = nq;
         a.k = k;
-        int parts = 0;
         if (p.grid0 > 0) {
             a.thr_init = nullptr;
             a.partial = ix->partial;
             a.tile_begin = 0;
             a.tile_end = p.grid0;
             a.grid = p.grid0;
+            a.seed_only = true;
             rc = vqa_launch_score_topk(ix->dtype, a, stream);
             if (rc != VQA_OK) return rc;
-            rc = vqa_launch_merge_partials(ix->partial, p.grid0, nq, k, nullptr, 0, nullptr, nullptr, nullptr, ix->thr0, k,
-                                           stream);
+            rc = vqa_launch_merge_partials(ix->partial, p.grid0, vqa_score_topk_seeds_per_query(), nq, k, nullptr, 0, nullptr,
+                                           nullptr, nullptr, ix->thr0, stream);
             if (rc != VQA_OK) return rc;
-            parts = p.grid0;
         }
         a.thr_init = p.grid0 > 0 ? ix->thr0 : nullptr;
-        a.partial = ix->partial + (size_t)parts * VQA_QUERY_TILE * k;
-        a.tile_begin = p.grid0;
+        a.partial = ix->partial;
+        a.tile_begin = 0;
         a.tile_end = p.tiles;
         a.grid = p.grid1;
+        a.seed_only = false;
         if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
         rc = vqa_launch_score_topk(ix->dtype, a, stream);
         if (rc != VQA_OK) return rc;
         if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
-        parts += p.grid1;
-        rc = vqa_launch_merge_partials(ix->partial, parts, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr, k, stream);
+        rc = vqa_launch_merge_partials(ix->partial, p.grid1, k, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr, stream);
         if (rc != VQA_OK) return rc;
     }
     return VQA_OK;

@@ -1,6 +1,6 @@
 // Element-wise helpers around the index (HBM-bound, 16 B per lane where the shape allows), gfx950 only.
-//   * stage_queries : [nq, d] fp32|fp16 queries -> zero padded [256, d_pad] tile in the index element type
-//   * pad_rows      : [n, d] -> [n, d_pad] zero padded copy (index rows whose length is not a multiple of 64)
+//   * stage_queries : [nq, d] fp32|fp16 queries -> one zero padded 256-row tile in the index element type, TILED layout
+//   * tile_rows     : row-major [count, d] rows -> the TILED layout of the index (see vqa_common.h), zero padded
 //   * normalize_convert : fp32 rows -> L2-normalised (txtai normalises at index and at query time; cosine intent at
 //     /root/reference/src/test.py:104) -> fp32 | fp16 | fp8-e4m3 (OCP, saturating, round to nearest even)
 #include "vqa_common.h"
@@ -45,25 +45,33 @@ __device__ __forceinline__ uint8_t f32_to_e4m3(float f) {
     return (uint8_t)(sign | code);
 }
 
-template <typename SRC>
-__global__ void stage_queries_kernel(const SRC* __restrict__ q, int nq, int d, int d_pad, int dtype, void* __restrict__ out) {
-    const int total = VQA_QUERY_TILE * d_pad;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        const int r = i / d_pad, j = i - r * d_pad;
-        const float v = (r < nq && j < d) ? (float)q[(size_t)r * d + j] : 0.0f;
-        if (dtype == VQA_F16) reinterpret_cast<_Float16*>(out)[i] = (_Float16)v;
-        else if (dtype == VQA_F32) reinterpret_cast<float*>(out)[i] = v;
-        else reinterpret_cast<uint8_t*>(out)[i] = f32_to_e4m3(v);
-    }
+// TILED layout (fp16): tile t (256 rows), K-step kappa (32 elements) is one contiguous 16 KiB block at unit index
+// (t * KT + kappa) * 1024 (unit = 16 B = 8 elements); inside the block the unit of (row r, 8-element slot s) sits at
+// r * 4 + (s ^ 3 * bit3(r)) -- exactly the bank-conflict-free LDS image K1 wants, so K1's LDS-DMA reads 1 KiB
+// contiguous per wave-instruction and a tile's K-steps stream from HBM as one sequential 256 * d_pad * 2 byte run.
+__device__ __forceinline__ size_t tiled_unit(long long row, int kappa, int slot, int KT) {
+    const long long t = row >> 8;
+    const int r = (int)(row & 255);
+    return ((size_t)t * KT + kappa) * 1024 + (size_t)(r * 4 + (slot ^ (((r >> 3) & 1) * 3)));
 }
 
-template <typename T>
-__global__ void pad_rows_kernel(const T* __restrict__ rows, long long n, int d, int d_pad, T* __restrict__ out) {
-    const long long total = n * d_pad;
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+
+// rows: [count, d] row-major, SRC element type; row i goes to index row first + i.  One thread per 16-byte output unit.
+template <typename SRC>
+__global__ void tile_rows_kernel(const SRC* __restrict__ rows, long long first, long long count, long long valid, int d,
+                                 int KT, _Float16* __restrict__ out) {
+    const int units_per_row = KT * 4;
+    const long long total = count * units_per_row;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const long long r = i / d_pad;
-        const int j = (int)(i - r * d_pad);
-        out[i] = j < d ? rows[r * d + j] : T(0);
+        const long long ri = i / units_per_row;
+        const int u = (int)(i - ri * units_per_row);
+        const int kappa = u >> 2, slot = u & 3;
+        const int j0 = u * 8;
+        half8_t v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (ri < valid && j0 + e < d) ? (_Float16)rows[ri * d + j0 + e] : (_Float16)0;
+        *reinterpret_cast<half8_t*>(out + tiled_unit(first + ri, kappa, slot, KT) * 8) = v;
     }
 }
 
@@ -96,34 +104,22 @@ __global__ __launch_bounds__(256) void normalize_convert_kernel(const float* __r
 
 }  // namespace
 
-int vqa_launch_stage_queries(const void* q, int32_t q_dtype, int32_t nq, int32_t d, int32_t d_pad, int32_t dtype, void* out,
-                             hipStream_t stream) {
-    VQA_REQUIRE(q_dtype == VQA_F32 || q_dtype == VQA_F16, "query element type %d is not f32/f16", q_dtype);
-    const int threads = 256, blocks = (VQA_QUERY_TILE * d_pad + threads - 1) / threads;
-    if (q_dtype == VQA_F32)
-        hipLaunchKernelGGL(stage_queries_kernel<float>, dim3(blocks), dim3(threads), 0, stream,
-                           reinterpret_cast<const float*>(q), nq, d, d_pad, dtype, out);
-    else
-        hipLaunchKernelGGL(stage_queries_kernel<_Float16>, dim3(blocks), dim3(threads), 0, stream,
-                           reinterpret_cast<const _Float16*>(q), nq, d, d_pad, dtype, out);
-    VQA_HIP_CHECK(hipGetLastError());
-    return VQA_OK;
-}
-
-int vqa_launch_pad_rows(const void* rows, int64_t n, int32_t d, int32_t d_pad, int32_t elem_bytes, void* out,
-                        hipStream_t stream) {
+int vqa_launch_tile_rows(const void* rows, int32_t src_dtype, int64_t first, int64_t count, int64_t valid, int32_t d,
+                         int32_t d_pad, void* out, hipStream_t stream) {
+    VQA_REQUIRE(src_dtype == VQA_F32 || src_dtype == VQA_F16, "tile_rows: source element type %d is not f32/f16", src_dtype);
+    if (count == 0) return VQA_OK;
+    const int KT = d_pad / 32;
+    const long long total = (long long)count * KT * 4;
     const int threads = 256;
-    const long long total = (long long)n * d_pad;
     const int blocks = (int)((total + threads - 1) / threads < 65536 ? (total + threads - 1) / threads : 65536);
-    if (elem_bytes == 2)
-        hipLaunchKernelGGL(pad_rows_kernel<uint16_t>, dim3(blocks), dim3(threads), 0, stream,
-                           reinterpret_cast<const uint16_t*>(rows), (long long)n, d, d_pad, reinterpret_cast<uint16_t*>(out));
-    else if (elem_bytes == 4)
-        hipLaunchKernelGGL(pad_rows_kernel<uint32_t>, dim3(blocks), dim3(threads), 0, stream,
-                           reinterpret_cast<const uint32_t*>(rows), (long long)n, d, d_pad, reinterpret_cast<uint32_t*>(out));
+    if (src_dtype == VQA_F32)
+        hipLaunchKernelGGL(tile_rows_kernel<float>, dim3(blocks), dim3(threads), 0, stream,
+                           reinterpret_cast<const float*>(rows), (long long)first, (long long)count, (long long)valid, d, KT,
+                           reinterpret_cast<_Float16*>(out));
     else
-        hipLaunchKernelGGL(pad_rows_kernel<uint8_t>, dim3(blocks), dim3(threads), 0, stream,
-                           reinterpret_cast<const uint8_t*>(rows), (long long)n, d, d_pad, reinterpret_cast<uint8_t*>(out));
+        hipLaunchKernelGGL(tile_rows_kernel<_Float16>, dim3(blocks), dim3(threads), 0, stream,
+                           reinterpret_cast<const _Float16*>(rows), (long long)first, (long long)count, (long long)valid, d, KT,
+                           reinterpret_cast<_Float16*>(out));
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

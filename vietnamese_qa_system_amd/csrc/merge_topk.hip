@@ -37,19 +37,20 @@ __device__ __forceinline__ vqa_key block_max_key(vqa_key v, vqa_key* red) {
 }
 
 __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa_key* __restrict__ partial, int parts,
-                                                                       int k, const long long* __restrict__ ids,
+                                                                       int list_len, int k,
+                                                                       const long long* __restrict__ ids,
                                                                        long long id_base, float* __restrict__ out_scores,
                                                                        long long* __restrict__ out_ids,
                                                                        long long* __restrict__ out_pos,
                                                                        float* __restrict__ out_thr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    vqa_key* keys = reinterpret_cast<vqa_key*>(smem);  // [parts * k]
-    vqa_key* red = keys + (size_t)parts * k;           // [4]
+    vqa_key* keys = reinterpret_cast<vqa_key*>(smem);    // [parts * list_len]
+    vqa_key* red = keys + (size_t)parts * list_len;      // [4]
     const int q = blockIdx.x;
-    const int m = parts * k;
+    const int m = parts * list_len;
     for (int i = threadIdx.x; i < m; i += kMergeThreads) {
-        const int p = i / k, j = i - p * k;
-        keys[i] = partial[((size_t)p * VQA_QUERY_TILE + q) * k + j];
+        const int p = i / list_len, j = i - p * list_len;
+        keys[i] = partial[((size_t)p * VQA_QUERY_TILE + q) * list_len + j];
     }
     __syncthreads();
     vqa_key prev = ~0ull;
@@ -114,14 +115,14 @@ __global__ __launch_bounds__(kMergeThreads) void merge_shards_kernel(const float
 
 }  // namespace
 
-int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t nq, int32_t k, const int64_t* ids,
-                              int64_t id_base, float* out_scores, int64_t* out_ids, int64_t* out_pos, float* out_thr,
-                              int32_t /*out_stride_q*/, hipStream_t stream) {
-    VQA_REQUIRE(parts >= 1 && nq >= 1 && nq <= VQA_QUERY_TILE && k >= 1, "merge_partials: bad shape parts=%d nq=%d k=%d",
-                parts, nq, k);
-    const size_t lds = ((size_t)parts * k + 4) * sizeof(vqa_key);
-    VQA_REQUIRE(lds <= 64 * 1024, "merge_partials: %d lists x k=%d do not fit in LDS", parts, k);
-    hipLaunchKernelGGL(merge_partials_kernel, dim3(nq), dim3(kMergeThreads), lds, stream, partial, parts, k,
+int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t list_len, int32_t nq, int32_t k,
+                              const int64_t* ids, int64_t id_base, float* out_scores, int64_t* out_ids, int64_t* out_pos,
+                              float* out_thr, hipStream_t stream) {
+    VQA_REQUIRE(parts >= 1 && list_len >= 1 && nq >= 1 && nq <= VQA_QUERY_TILE && k >= 1,
+                "merge_partials: bad shape parts=%d list_len=%d nq=%d k=%d", parts, list_len, nq, k);
+    const size_t lds = ((size_t)parts * list_len + 4) * sizeof(vqa_key);
+    VQA_REQUIRE(lds <= 64 * 1024, "merge_partials: %d lists x %d keys do not fit in LDS", parts, list_len);
+    hipLaunchKernelGGL(merge_partials_kernel, dim3(nq), dim3(kMergeThreads), lds, stream, partial, parts, list_len, k,
                        reinterpret_cast<const long long*>(ids), (long long)id_base, out_scores,
                        reinterpret_cast<long long*>(out_ids), reinterpret_cast<long long*>(out_pos), out_thr);
     VQA_HIP_CHECK(hipGetLastError());

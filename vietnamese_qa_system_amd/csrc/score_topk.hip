@@ -5,72 +5,102 @@
 // exact inner product of the query with every stored row + k largest).
 //
 // Shape of the work: S[q, n] = sum_j Q[q, j] * X[n, j]   with Q [256, d] (one query tile), X [N, d] row-major.
-// One persistent workgroup (8 waves) walks corpus tiles of 256 rows:
-//   * per K-step of 64 elements, the X slice (256 rows x 128 B, from HBM) and the Q slice (256 rows x 128 B,
-//     L2 resident) are copied global -> LDS with 16-byte LDS-DMA (`global_load_lds_dwordx4`), double buffered;
-//     the LDS image is XOR-swizzled through the SOURCE address so ds_read_b128 fragment reads are conflict free;
-//   * wave (wm, wn) owns rows [128 wm, +128) x queries [64 wn, +64) as 8 x 4 tiles of v_mfma_f32_16x16x32_f16
-//     (A = corpus rows, B = queries, so a lane's 32 accumulators of one column group all belong to ONE query);
-//   * after the K loop the scores never leave registers: each lane compares its accumulators with the query's
-//     current threshold (k-th best score so far, kept in LDS); survivors are appended to the query's LDS
-//     candidate list with one LDS atomic, lists are compacted (rank-by-counting inside one wave) when they fill.
-// No B x N score matrix is ever written.  The per-workgroup lists are flushed once at the end and merged by K2.
+// X and Q are stored in HBM in the TILED layout of convert.hip: the slice of one 256-row tile and one K-step of 32
+// elements is a contiguous 16 KiB block, already in the XOR-swizzled image that makes every ds_read_b128 fragment
+// read bank-conflict free.  One persistent workgroup (8 waves, one per CU) walks corpus tiles; per K-step the X block
+// (HBM, sequential) and the Q block (L2 resident) go global -> LDS by 16-byte LDS-DMA, 1 KiB contiguous per
+// wave-instruction, into a 4-deep ring (3 K-steps in flight, counted vmcnt, never drained in the loop).
+// Wave (wm, wn) owns rows [128 wm, +128) x queries [64 wn, +64) as 8 x 4 tiles of v_mfma_f32_16x16x32_f16
+// (A = corpus rows, B = queries: a lane's 32 accumulators of one column group all belong to ONE query).
+// The two wave groups wm = 0 / wm = 1 (partners on each SIMD) run half a phase apart: while one group issues its
+// 16-MFMA cluster the other reads its next fragments from LDS and issues its LDS-DMA pieces (s_barrier ping-pong).
+// After the K loop the scores never leave registers: each lane compares its accumulators with the query's current
+// threshold (k-th best score so far, in LDS); survivors are appended to the query's LDS candidate list with one LDS
+// atomic; lists are compacted (rank-by-counting inside one wave) when they fill.  No B x N score matrix exists.
+//
+// Two instantiations:
+//   MODE 0 "seed": one tile per workgroup; writes, per query, the 16 sub-maxima of the tile (valid lower bounds:
+//                  each is the score of a distinct row); K2 turns their k-th largest into starting thresholds.
+//   MODE 1 "main": all tiles, thresholds seeded; flushes per-workgroup sorted top-k lists for K2 to merge.
+#include <type_traits>
+
 #include "vqa_common.h"
+
+#ifndef VQA_ABLATE
+// dev-only timing ablations (scripts/clock_probe.sh), bit mask; results are wrong when != 0:
+// 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no MFMA, 8 no epilogue, 16 s_sleep in place of the MFMAs,
+// 32 no Q pieces, 64 no loop barrier
+#define VQA_ABLATE 0
+#endif
 
 namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+typedef __attribute__((address_space(3))) char* lds_char_ptr;
 
-constexpr int kThreads = 512;           // 8 waves: 2 (row halves) x 4 (query quarters)
+constexpr int kThreads = 512;           // 8 waves: 2 (row halves = ping-pong groups) x 4 (query quarters)
 constexpr int kTileRows = 256;          // corpus rows per tile
 constexpr int kQ = VQA_QUERY_TILE;      // 256 queries per tile
-constexpr int kBK = 64;                 // K-step in elements
-constexpr int kRowBytes = kBK * 2;      // 128 B of fp16 per row per K-step
-constexpr int kOperandBytes = 256 * kRowBytes;  // 32 KiB: one operand slice
-constexpr int kStageBytes = 2 * kOperandBytes;  // X slice + Q slice
-constexpr int kPipeBytes = 2 * kStageBytes;     // double buffered: 128 KiB
+constexpr int kBK = 32;                 // K-step in elements
+constexpr int kRowBytes = kBK * 2;      // 64 B of fp16 per row per K-step
+constexpr int kOperandBytes = 256 * kRowBytes;  // 16 KiB: one operand slice (256 rows x one K-step)
+#ifndef VQA_RING_ALT
+constexpr int kSx = 6, kPx = 5;  // X ring: stages, K-steps issued ahead (HBM stream: deep); one stage idles per K-step
+constexpr int kSq = 2, kPq = 2;  // Q ring: stages, K-steps issued ahead (L2 resident: shallow)
+#else
+constexpr int kSx = 5, kPx = 4;
+constexpr int kSq = 3, kPq = 2;
+#endif
+constexpr int kXRingBytes = kSx * kOperandBytes;
+constexpr int kQRingBytes = kSq * kOperandBytes;
+constexpr int kPipeBytes = kXRingBytes + kQRingBytes;  // 128 KiB
 constexpr int kLdsTotal = 160 * 1024;
 constexpr int kCap = (kLdsTotal - kPipeBytes - 2 * kQ * 4) / (kQ * 8);  // 15 candidate slots per query
+constexpr int kExt = kOperandBytes / (kQ * 8);                           // 8 more in the idle X stage during an epilogue
 constexpr int kMaxK = kCap - 3;                                         // 12
+constexpr int kSeedsPerQuery = 16;
+static_assert(kPipeBytes == 128 * 1024, "ring sizes");
 
 constexpr int kOverBit = 1 << 30;  // "an append was refused" flag, kept in bit 30 of cnt[0] (LDS is fully used)
 constexpr int kCntMask = 0xFFFFFF;
 
 struct Lists {  // views into LDS: per query {threshold, count, kCap keys} = 128 B, 32 KiB in all
-    float* thr;      // [256] current k-th best score per query (+inf for padded queries)
-    int* cnt;        // [256] appends attempted since the last compaction (may exceed kCap when some were refused)
-    vqa_key* cand;   // [256][kCap]
+    float* thr;     // [256] current k-th best score per query (+inf for padded queries)
+    int* cnt;       // [256] appends attempted since the last compaction (may exceed the capacity when refused)
+    vqa_key* cand;  // [256][kCap]
+    vqa_key* ext;   // [256][kExt] spill area in the idle ring stage; only valid inside one tile's epilogue
 };
 
 __device__ __forceinline__ int list_count(const Lists& L, int q) { return L.cnt[q] & kCntMask; }
 
+__device__ __forceinline__ vqa_key list_get(const Lists& L, int q, int i) {
+    return i < kCap ? L.cand[q * kCap + i] : L.ext[q * kExt + (i - kCap)];
+}
+
 // ---- rank-by-counting compaction of one query's list by one wave ------------------------------------------
-// Keeps the k best of the (at most kCap) stored keys, sorted best first, and raises the threshold.
-__device__ __forceinline__ void compact_query(const Lists& L, int q, int k, int lane) {
+// Keeps the k best of the stored keys, sorted best first, and raises the threshold.
+__device__ __forceinline__ void compact_query(const Lists& L, int q, int k, int lane, int capacity) {
     const int raw = L.cnt[q];
     int n = raw & kCntMask;
-    n = n < kCap ? n : kCap;
-    vqa_key* c = L.cand + q * kCap;
-    const vqa_key mine = lane < n ? c[lane] : 0ull;
+    n = n < capacity ? n : capacity;
+    const vqa_key mine = lane < n ? list_get(L, q, lane) : 0ull;
     int rank = 0;
-    for (int j = 0; j < n; ++j) rank += (c[j] > mine) ? 1 : 0;  // broadcast reads; keys are distinct rows
-    if (lane < n && rank < k) c[rank] = mine;
+    for (int j = 0; j < n; ++j) rank += (list_get(L, q, j) > mine) ? 1 : 0;  // broadcast reads; keys are distinct
+    if (lane < n && rank < k) L.cand[q * kCap + rank] = mine;
     if (lane < n && rank == k - 1) L.thr[q] = vqa_key_score(mine);
     if (lane == 0) L.cnt[q] = (raw & kOverBit) | (n < k ? n : k);
 }
 
 // wave w compacts the queries [32 w, 32 w + 32) whose list length reached `water`
-__device__ __forceinline__ void compact_pass(const Lists& L, int wave, int lane, int k, int water) {
+__device__ __forceinline__ void compact_pass(const Lists& L, int wave, int lane, int k, int water, int capacity) {
     const int q0 = wave * 32;
     const int c = lane < 32 ? (L.cnt[q0 + lane] & kCntMask) : 0;
     unsigned long long need = __ballot(c >= water) & 0xFFFFFFFFull;
     while (need) {
         const int b = __builtin_ctzll(need);
         need &= need - 1;
-        compact_query(L, q0 + b, k, lane);
+        compact_query(L, q0 + b, k, lane, capacity);
     }
 }
 
@@ -78,6 +108,10 @@ __device__ __forceinline__ bool append_candidate(const Lists& L, int q, float v,
     const int slot = atomicAdd(&L.cnt[q], 1) & kCntMask;  // ds_add_rtn_u32
     if (slot < kCap) {
         L.cand[q * kCap + slot] = vqa_make_key(v, pos);
+        return true;
+    }
+    if (slot < kCap + kExt) {
+        L.ext[q * kExt + (slot - kCap)] = vqa_make_key(v, pos);
         return true;
     }
     return false;
@@ -94,7 +128,7 @@ __device__ __forceinline__ float select_acc(const f32x4 (&acc)[8][4], int ni, in
 // Append this lane's pending accumulators (bit mi*4+j of pend[ni]) that still beat their query's threshold.
 // Returns true when some append was refused (list full): the bit stays set for the next round.
 __device__ __forceinline__ bool process_pending(const Lists& L, const f32x4 (&acc)[8][4], uint32_t (&pend)[4], int wm,
-                                                int wn, int c, int g, long long row0) {
+                                                int wn, int c, int g, uint32_t row0) {
     bool refused = false;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -109,7 +143,7 @@ __device__ __forceinline__ bool process_pending(const Lists& L, const f32x4 (&ac
                 const float v = select_acc(acc, ni, b);
                 if (v >= th) {
                     const int r = wm * 128 + (b >> 2) * 16 + g * 4 + (b & 3);
-                    if (!append_candidate(L, q, v, (uint32_t)(row0 + r))) keep |= 1u << b;
+                    if (!append_candidate(L, q, v, row0 + (uint32_t)r)) keep |= 1u << b;
                 }
             }
             pend[ni] = keep;
@@ -119,78 +153,206 @@ __device__ __forceinline__ bool process_pending(const Lists& L, const f32x4 (&ac
     return refused;
 }
 
-// kSeeded = false: first pass (thresholds start at -inf); true: main pass seeded with the k-th best scores of the
-// first pass.  Same code; two instantiations so that profiles name the dominant (main) kernel separately.
-template <bool kSeeded>
+// ---- LDS-DMA: 4 wave-instructions, each 64 lanes x 16 B -> 1 KiB of LDS.  Global address = sbase + voff + i * 1024,
+// LDS address = lds_dst + i * 1024 + lane * 16 (M0 base + instruction offset + lane * 16, added by hardware): the
+// instruction offset moves both sides, so one M0 write serves the four.  Inline asm so that hipcc keeps no scoreboard
+// entry for the loads: all ordering is by the counted vmcnt waits below.  sbase / lds_dst are SALU-computed.
+__device__ __forceinline__ void glds16x4(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+        "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void block_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int MODE>
 __global__ __launch_bounds__(kThreads) void score_topk_f16_kernel(const _Float16* __restrict__ X,
                                                                   const _Float16* __restrict__ Qs,
                                                                   const float* __restrict__ thr_init,
-                                                                  vqa_key* __restrict__ partial, long long N, int D,
-                                                                  int nq, int k, int tile_begin, int tile_end) {
+                                                                  vqa_key* __restrict__ out, long long N, int D, int nq,
+                                                                  int k, int tile_begin, int tile_end) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lists L;
     L.thr = reinterpret_cast<float*>(smem + kPipeBytes);
     L.cnt = reinterpret_cast<int*>(smem + kPipeBytes + kQ * 4);
     L.cand = reinterpret_cast<vqa_key*>(smem + kPipeBytes + 2 * kQ * 4);
+    L.ext = nullptr;
+    const uint32_t smem_lds = (uint32_t)(size_t)(lds_char_ptr)smem;  // LDS byte address of the dynamic region
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave >> 2;  // corpus-row half
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2;  // corpus-row half = ping-pong group
     const int wn = wave & 3;   // query quarter
     const int c = lane & 15;
     const int g = lane >> 4;
 
-    if (tid < kQ) {
-        L.thr[tid] = tid < nq ? (kSeeded ? thr_init[tid] : -INFINITY) : INFINITY;
+    if (MODE == 1 && tid < kQ) {
+        L.thr[tid] = tid < nq ? (thr_init ? thr_init[tid] : -INFINITY) : INFINITY;
         L.cnt[tid] = 0;
     }
 
-    const int KS = D / kBK;
+    const int KT = D / kBK;
     const int first_tile = tile_begin + blockIdx.x;
-    const int ntile = first_tile < tile_end ? (tile_end - first_tile + gridDim.x - 1) / gridDim.x : 0;
-    const long long total_steps = (long long)ntile * KS;
+    const int ntile = first_tile < tile_end ? (tile_end - first_tile + (int)gridDim.x - 1) / (int)gridDim.x : 0;
+    const int total = ntile * KT;  // K-steps of this workgroup, numbered kappa = ti * KT + kt
 
-    // ---- staging geometry: wave-instruction i of wave w fills LDS units [(4w+i)*64, +64) of an operand slice
-    // (unit = 16 B; 8 units per 128-B row).  Lane l -> row (4w+i)*8 + (l>>3), swizzled slot l&7, source slot
-    // (l&7) ^ (row&7) = (l&7) ^ (l>>3).
-    const int st_row_in = lane >> 3;
-    const int st_src_slot = (lane & 7) ^ st_row_in;
-    const size_t row_bytes_g = (size_t)D * 2;
-
-    auto stage = [&](long long step) {
-        const int ti = (int)(step / KS);
-        const int ks = (int)(step - (long long)ti * KS);
-        const long long row0 = ((long long)first_tile + (long long)ti * gridDim.x) * kTileRows;
-        char* buf = smem + (step & 1) * kStageBytes;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (wave * 4 + i) * 8 + st_row_in;
-            long long gr = row0 + r;
-            gr = gr < N ? gr : N - 1;  // tail rows re-read the last row; masked in the epilogue
-            const char* src = reinterpret_cast<const char*>(X) + (size_t)gr * row_bytes_g + (size_t)ks * kRowBytes +
-                              st_src_slot * 16;
-            char* dst = buf + (wave * 4 + i) * 1024;  // wave-uniform base; hardware adds lane * 16
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+    // ---- LDS-DMA.  X and Q are stored in the TILED layout (convert.hip): the slice of one tile and K-step is a
+    // contiguous 16 KiB block that already is the swizzled LDS image.  vmcnt retires in issue order per wave, so the
+    // deep HBM stream and the shallow L2 stream are issued by DIFFERENT waves: group 1 (waves 4-7) loads X, kPx
+    // K-steps ahead into a kSx-stage ring; group 0 (waves 0-3) loads Q, kPq ahead into a kSq-stage ring.  Each wave
+    // moves a quarter of a slice per K-step: 4 wave-instructions reading 1 KiB contiguous each.
+    const int lw = wave & 3;
+    const uint32_t voff = (uint32_t)(lw * 4096 + lane * 16);
+    const uint32_t xring_lds = smem_lds, qring_lds = smem_lds + kXRingBytes;
+    // issue cursor of this wave: K-steps issued, K-step inside the tile, source block pointer, LDS destination
+    int ik = 0, i_kt = 0;
+    const size_t tile_jump = ((size_t)gridDim.x - 1) * KT * kOperandBytes;  // from a tile's last block to the next tile's
+    const char* x_src = reinterpret_cast<const char*>(X) + (size_t)first_tile * KT * kOperandBytes;
+    const char* q_src = reinterpret_cast<const char*>(Qs);
+    uint32_t i_dst = (wm ? xring_lds : qring_lds) + lw * 4096;
+    auto issue_x = [&]() {
+        if (ik >= total) return;
+        glds16x4(x_src, voff, i_dst);
+        ++ik;
+        x_src += kOperandBytes;
+        if (++i_kt == KT) {
+            i_kt = 0;
+            x_src += tile_jump;
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = (wave * 4 + i) * 8 + st_row_in;
-            const char* src = reinterpret_cast<const char*>(Qs) + (size_t)r * row_bytes_g + (size_t)ks * kRowBytes +
-                              st_src_slot * 16;
-            char* dst = buf + kOperandBytes + (wave * 4 + i) * 1024;
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)src, (lds_ptr_t)dst, 16, 0, 0);
+        i_dst += kOperandBytes;
+        if (i_dst >= xring_lds + kXRingBytes) i_dst -= kXRingBytes;
+    };
+    auto issue_q = [&]() {
+        if (ik >= total) return;
+        glds16x4(q_src, voff, i_dst);
+        ++ik;
+        q_src += kOperandBytes;
+        if (++i_kt == KT) {
+            i_kt = 0;
+            q_src = reinterpret_cast<const char*>(Qs);
+        }
+        i_dst += kOperandBytes;
+        if (i_dst >= qring_lds + kQRingBytes) i_dst -= kQRingBytes;
+    };
+    // wait until this wave's pieces of K-step kappa_needed have landed; it has then issued through
+    // kappa_needed + extra (4 instructions per K-step), fewer near the end of the stream
+    auto wait_pieces = [&](int kappa_needed) {
+        if (wm) {
+            if (kappa_needed + (kPx - 2) < total) wait_vmcnt<4 * (kPx - 2)>();
+            else wait_vmcnt<0>();
+        } else {
+            if (kappa_needed + (kPq - 2) < total) wait_vmcnt<4 * (kPq - 2)>();
+            else wait_vmcnt<0>();
         }
     };
 
-    // ---- fragment geometry: lane reads 16 B = 8 k-contiguous halves of row (base + c), k offset 32 kk + 8 g
-    const int frag_off0 = c * kRowBytes + (((0 + g) ^ (c & 7)) << 4);
-    const int frag_off1 = c * kRowBytes + (((4 + g) ^ (c & 7)) << 4);
-    const int a_base = wm * 128 * kRowBytes;                 // inside the X slice
-    const int b_base = kOperandBytes + wn * 64 * kRowBytes;  // inside the Q slice
+    // ---- fragment geometry: lane reads 16 B = 8 k-contiguous halves of row (base + c), k offset 8 g
+    const int frag_off = c * kRowBytes + ((g ^ (((c >> 3) & 1) * 3)) << 4);
+    [[maybe_unused]] const int a_base = wm * 128 * kRowBytes + frag_off;                // inside an X stage
+    [[maybe_unused]] const int b_base = kXRingBytes + wn * 64 * kRowBytes + frag_off;  // inside a Q stage
 
-    if (total_steps > 0) stage(0);
+    int sx = 0, sq = 0;  // ring stages of the K-step whose fragments are read next
+// fragment reads of the next K-step into register set (A, B); static register names, no references (SROA-friendly)
+#if VQA_ABLATE & 2
+#define VQA_READ_FRAGS(A, B)                                                                  \
+    do {                                                                                      \
+        for (int i_ = 0; i_ < 8; ++i_) { A[i_] = half8{}; asm volatile("" : "+v"(A[i_])); }   \
+        for (int i_ = 0; i_ < 4; ++i_) { B[i_] = half8{}; asm volatile("" : "+v"(B[i_])); }   \
+        if (++sx == kSx) sx = 0;                                                              \
+        if (++sq == kSq) sq = 0;                                                              \
+    } while (0)
+#else
+#define VQA_READ_FRAGS(A, B)                                                                                      \
+    do {                                                                                                          \
+        const char* xbuf_ = smem + sx * kOperandBytes;                                                            \
+        const char* qbuf_ = smem + sq * kOperandBytes;                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                          \
+            B[i_] = *reinterpret_cast<const half8*>(qbuf_ + b_base + i_ * 16 * kRowBytes);                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                          \
+            A[i_] = *reinterpret_cast<const half8*>(xbuf_ + a_base + i_ * 16 * kRowBytes);                        \
+        if (++sx == kSx) sx = 0;                                                                                  \
+        if (++sq == kSq) sq = 0;                                                                                  \
+    } while (0)
+#endif
+#if VQA_ABLATE & 4
+#define VQA_MFMA(ACC, A, B) asm volatile("" : "+v"(ACC) : "v"(A), "v"(B))
+#else
+#define VQA_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, ACC, 0, 0, 0)
+#endif
+#define VQA_MMA(A, B)                                                           \
+    do {                                                                        \
+        _Pragma("unroll") for (int mi_ = 0; mi_ < 8; ++mi_)                     \
+            _Pragma("unroll") for (int ni_ = 0; ni_ < 4; ++ni_) VQA_MFMA(acc[mi_][ni_], A[mi_], B[ni_]); \
+    } while (0)
+#if VQA_ABLATE & 1
+#define VQA_ISSUE() (void)0
+#elif VQA_ABLATE & 32
+#define VQA_ISSUE() do { if (wm) issue_x(); } while (0)
+#else
+#define VQA_ISSUE() do { if (wm) issue_x(); else issue_q(); } while (0)
+#endif
+#if VQA_ABLATE & 64
+#define VQA_LOOP_BARRIER() (void)0
+#else
+#define VQA_LOOP_BARRIER() block_barrier()
+#endif
+#ifdef VQA_NO_SB
+#define VQA_SB() (void)0
+#else
+#define VQA_SB() __builtin_amdgcn_sched_barrier(0)
+#endif
+// One K-step: fragments in (CA, CB) are multiplied; the next K-step's go to (NA, NB) when PREFETCH.
+#define VQA_KSTEP(CA, CB, NA, NB, KAPPA, PREFETCH)                 \
+    do {                                                           \
+        if (!kMemFirst) {                                          \
+            VQA_MMA(CA, CB);                                       \
+            VQA_SB();                                              \
+            if (PREFETCH) VQA_READ_FRAGS(NA, NB);                  \
+            VQA_ISSUE();                                           \
+        } else {                                                   \
+            if (PREFETCH) VQA_READ_FRAGS(NA, NB);                  \
+            VQA_ISSUE();                                           \
+            VQA_SB();                                              \
+            VQA_MMA(CA, CB);                                       \
+        }                                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
+        wait_pieces((KAPPA) + 2);                                  \
+        VQA_LOOP_BARRIER();                                        \
+    } while (0)
 
+    // prologue: the first kP K-steps of this wave's stream; K-steps 0 and 1 landed
+    if (wm) {
+        for (int i = 0; i < kPx; ++i) issue_x();
+    } else {
+        for (int i = 0; i < kPq; ++i) issue_q();
+    }
+    wait_pieces(1);
+    block_barrier();
+
+    // The whole tile loop exists twice (group 0: memory instructions first, group 1: matrix instructions first) and
+    // the wave-uniform branch sits OUTSIDE it: a diamond around each K-step makes hipcc spill the accumulators.
+    auto tile_loop = [&](auto mem_first_tag) __attribute__((always_inline)) {
+    constexpr bool kMemFirst = decltype(mem_first_tag)::value;
     for (int ti = 0; ti < ntile; ++ti) {
         f32x4 acc[8][4];
 #pragma unroll
@@ -198,34 +360,68 @@ __global__ __launch_bounds__(kThreads) void score_topk_f16_kernel(const _Float16
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-        for (int ks = 0; ks < KS; ++ks) {
-            const long long step = (long long)ti * KS + ks;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my LDS-DMA pieces of `step` have landed
-            __syncthreads();                                   // everyone's have; buffer (step+1)&1 is free
-            if (step + 1 < total_steps) stage(step + 1);
-            const char* buf = smem + (step & 1) * kStageBytes;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int fo = kk == 0 ? frag_off0 : frag_off1;
-                half8 a[8], b[4];
-#pragma unroll
-                for (int mi = 0; mi < 8; ++mi)
-                    a[mi] = *reinterpret_cast<const half8*>(buf + a_base + mi * 16 * kRowBytes + fo);
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
-                    b[ni] = *reinterpret_cast<const half8*>(buf + b_base + ni * 16 * kRowBytes + fo);
-#pragma unroll
-                for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
-            }
+        // One barrier per K-step.  Iteration kappa: (R) read the fragments of kappa + 1 into the other register set,
+        // (D) issue this wave's LDS-DMA pieces of kappa + kP, (M) 32 MFMAs of kappa; then lgkmcnt(0) (the stage of
+        // kappa + 1 may be refilled after the barrier), a counted vmcnt (this wave's pieces of kappa + 2 landed) and
+        // the barrier.  Group 0 runs R, D, M and group 1 runs M, R, D, so on every SIMD one wave starts with the
+        // matrix pipe while its partner starts with memory instructions.
+        half8 a0[8], b0[4], a1[8], b1[4];
+        VQA_READ_FRAGS(a0, b0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        block_barrier();  // every wave holds its first fragments before a piece of K-step + kS may overwrite the stage
+        for (int kt = 0; kt < KT; kt += 2) {  // KT is even (d_pad is a multiple of 64)
+            const int kappa = ti * KT + kt;
+            VQA_KSTEP(a0, b0, a1, b1, kappa, true);
+            VQA_KSTEP(a1, b1, a0, b0, kappa + 1, kt + 2 < KT);
         }
 
-        // ---- epilogue: threshold filter + candidate append; scores stay in registers --------------------------
+        // ---- epilogue; scores stay in registers ------------------------------------------------------------------
         // acc[mi][ni][j] = score(row = row0 + 128 wm + 16 mi + 4 g + j, query = 64 wn + 16 ni + c)
-        const long long row0 = ((long long)first_tile + (long long)ti * gridDim.x) * kTileRows;
-        const long long rows_left = N - row0;  // rows of this tile that exist (may exceed 256)
+        const uint32_t row0 = ((uint32_t)first_tile + (uint32_t)ti * gridDim.x) * kTileRows;  // n < 2^32 rows
+        const long long left = N - (long long)row0;
+        const int rows_left = left < kTileRows ? (int)left : kTileRows;
+        if (rows_left < kTileRows) {  // ragged last tile of the shard: rows past the end never compete (NaN fails every
+                                      // >= / > test below and is ignored by fmaxf, even against a -inf threshold)
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool dead = wm * 128 + mi * 16 + g * 4 + j >= rows_left;
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[mi][ni][j] = dead ? __builtin_nanf("") : acc[mi][ni][j];
+                }
+        }
+        if (MODE == 0) {
+            // 16 sub-maxima per query and tile: (row half wm, lane group g, mi half) -> seeds [tile][query][16]
+            vqa_key* seeds = out + (size_t)blockIdx.x * kQ * kSeedsPerQuery;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int q = wn * 64 + ni * 16 + c;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float m = -INFINITY;
+                    int arg = 0;
+#pragma unroll
+                    for (int mi = 4 * h; mi < 4 * h + 4; ++mi)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int r = wm * 128 + mi * 16 + g * 4 + j;
+                            const float v = acc[mi][ni][j];
+                            if (v > m) {
+                                m = v;
+                                arg = r;
+                            }
+                        }
+                    const bool valid = m > -INFINITY && q < nq;
+                    seeds[q * kSeedsPerQuery + wm * 8 + g * 2 + h] = valid ? vqa_make_key(m, row0 + (uint32_t)arg) : 0ull;
+                }
+            }
+            continue;
+        }
+        // X stage of the tile's last K-step: every read of it completed before the re-align barrier and its next
+        // refill (K-step + kSx) is issued in the next tile's first L segment
+        L.ext = reinterpret_cast<vqa_key*>(smem + (sx == 0 ? kSx - 1 : sx - 1) * kOperandBytes);
+        static_assert(kPx < kSx, "the X stage of the K-step just computed must idle until the next K-step's pieces are issued");
         uint32_t pend[4];
         bool any = false;
 #pragma unroll
@@ -240,20 +436,25 @@ __global__ __launch_bounds__(kThreads) void score_topk_f16_kernel(const _Float16
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int r = wm * 128 + mi * 16 + g * 4 + j;
-                        bits |= (acc[mi][ni][j] >= th && r < rows_left) ? (1u << (mi * 4 + j)) : 0u;
-                    }
+                    for (int j = 0; j < 4; ++j) bits |= (acc[mi][ni][j] >= th) ? (1u << (mi * 4 + j)) : 0u;
             }
             pend[ni] = bits;
             any |= bits != 0;
+#if VQA_ABLATE & 8
+            asm volatile("" : "+v"(m));
+            pend[ni] = 0;
+            any = false;
+#endif
         }
+        // every wave passed the re-align barrier after its last fragment reads completed, so the idle stage (L.ext)
+        // is free: a list holds up to kCap + kExt keys inside this epilogue and is back below kCap when it ends
+        // (water <= kCap: every list that spilled into L.ext is compacted).
         if (any && process_pending(L, acc, pend, wm, wn, c, g, row0)) atomicOr(&L.cnt[0], kOverBit);
         __syncthreads();
         for (;;) {
             const int over = L.cnt[0] & kOverBit;
             // normal tiles: compact lists that are nearly full; after a refusal: compact everything above k
-            compact_pass(L, wave, lane, k, over ? k + 1 : k + (kCap - k + 1) / 2);
+            compact_pass(L, wave, lane, k, over ? k + 1 : k + (kCap - k + 1) / 2, kCap + kExt);
             __syncthreads();
             if (!over) break;
             if (tid == 0) L.cnt[0] &= ~kOverBit;
@@ -263,14 +464,19 @@ __global__ __launch_bounds__(kThreads) void score_topk_f16_kernel(const _Float16
         }
     }
 
+    };
+    if (wm) tile_loop(std::false_type{});
+    else tile_loop(std::true_type{});
+
+    if (MODE == 0) return;
     // ---- flush: every list sorted best first, k keys per query (0 = empty) ------------------------------------
     __syncthreads();
-    compact_pass(L, wave, lane, k, 1);
+    compact_pass(L, wave, lane, k, 1, kCap);
     __syncthreads();
-    vqa_key* out = partial + (size_t)blockIdx.x * kQ * k;
+    vqa_key* dst = out + (size_t)blockIdx.x * kQ * k;
     for (int i = tid; i < kQ * k; i += kThreads) {
         const int q = i / k, j = i - q * k;
-        out[i] = j < list_count(L, q) ? L.cand[q * kCap + j] : 0ull;
+        dst[i] = j < list_count(L, q) ? L.cand[q * kCap + j] : 0ull;
     }
 }
 
@@ -287,25 +493,28 @@ int vqa_score_topk_max_k(int dtype) {
     return kMaxK;
 }
 
+int vqa_score_topk_seeds_per_query() { return kSeedsPerQuery; }
+
 int vqa_launch_score_topk(int dtype, const ScoreTopkArgs& a, hipStream_t stream) {
     VQA_REQUIRE(dtype == VQA_F16, "score_topk: only fp16 rows are implemented (dtype %d)", dtype);
-    VQA_REQUIRE(a.d_pad > 0 && a.d_pad % kBK == 0, "score_topk: padded row length %d is not a multiple of %d", a.d_pad, kBK);
+    VQA_REQUIRE(a.d_pad > 0 && a.d_pad % 64 == 0, "score_topk: padded row length %d is not a multiple of 64", a.d_pad);
     VQA_REQUIRE(a.k >= 1 && a.k <= kMaxK, "score_topk: k=%d outside [1, %d]", a.k, kMaxK);
     VQA_REQUIRE(a.nq >= 1 && a.nq <= kQ, "score_topk: nq=%d outside [1, %d]", a.nq, kQ);
     VQA_REQUIRE(a.grid >= 1 && a.tile_end > a.tile_begin, "score_topk: empty launch");
+    VQA_REQUIRE(!a.seed_only || a.tile_end - a.tile_begin <= a.grid, "score_topk: the seed pass takes one tile per workgroup");
     const int lds = vqa_score_topk_lds_bytes(dtype, a.k);
     static bool attr_set_dev[64] = {};
     int dev = 0;
     VQA_HIP_CHECK(hipGetDevice(&dev));
     bool& attr_set = attr_set_dev[dev & 63];
     if (!attr_set) {
-        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_f16_kernel<false>),
+        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_f16_kernel<0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_f16_kernel<true>),
+        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_f16_kernel<1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    auto kern = a.thr_init ? score_topk_f16_kernel<true> : score_topk_f16_kernel<false>;
+    auto kern = a.seed_only ? score_topk_f16_kernel<0> : score_topk_f16_kernel<1>;
     hipLaunchKernelGGL(kern, dim3(a.grid), dim3(kThreads), lds, stream, reinterpret_cast<const _Float16*>(a.x),
                        reinterpret_cast<const _Float16*>(a.q), a.thr_init, a.partial, (long long)a.n, a.d_pad, a.nq, a.k,
                        a.tile_begin, a.tile_end);

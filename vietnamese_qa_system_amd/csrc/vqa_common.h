@@ -47,8 +47,8 @@ __host__ __device__ __forceinline__ uint32_t vqa_key_pos(vqa_key k) { return 0xF
 
 // ---- kernel launchers implemented in the .hip files ---------------------------------------------------------
 struct ScoreTopkArgs {
-    const void* x;        // [n, d_pad] index rows (element type per dtype)
-    const void* q;        // [VQA_QUERY_TILE, d_pad] staged query tile, same element type, zero padded
+    const void* x;        // index rows in TILED layout (convert.hip): ceil(n/256) tiles x (d_pad/32) blocks of 16 KiB
+    const void* q;        // staged query tile, same layout (one tile), zero padded
     const float* thr_init; // [VQA_QUERY_TILE] starting thresholds or nullptr (-inf)
     vqa_key* partial;     // [grid, VQA_QUERY_TILE, k] per-workgroup sorted partial lists (output)
     int64_t n;            // rows in the shard
@@ -58,18 +58,20 @@ struct ScoreTopkArgs {
     int32_t tile_begin;   // first corpus tile (of 256 rows) this launch covers
     int32_t tile_end;     // one past the last
     int32_t grid;         // workgroups
+    bool seed_only = false;  // MODE 0: one tile per workgroup, writes 16 sub-maxima per query and tile to `partial`
 };
 int vqa_launch_score_topk(int dtype, const ScoreTopkArgs& a, hipStream_t stream);
 int vqa_score_topk_lds_bytes(int dtype, int k);
 int vqa_score_topk_max_k(int dtype);
+int vqa_score_topk_seeds_per_query();
 
-// merge `parts` sorted partial lists per query -> final [B, k] (scores, external ids, positions) and/or thresholds
-int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t nq, int32_t k, const int64_t* ids,
-                              int64_t id_base, float* out_scores, int64_t* out_ids, int64_t* out_pos,
-                              float* out_thr /* k-th best score per query or nullptr */, int32_t out_stride_q,
-                              hipStream_t stream);
+// `parts` key lists of `list_len` keys per query ([parts][256][list_len]) -> the k best per query:
+// final [nq, k] (scores, external ids, positions) and/or the k-th best score per query (-inf when fewer exist)
+int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t list_len, int32_t nq, int32_t k,
+                              const int64_t* ids, int64_t id_base, float* out_scores, int64_t* out_ids, int64_t* out_pos,
+                              float* out_thr, hipStream_t stream);
 
-int vqa_launch_stage_queries(const void* q, int32_t q_dtype, int32_t nq, int32_t d, int32_t d_pad, int32_t dtype,
-                             void* out /* [VQA_QUERY_TILE, d_pad] */, hipStream_t stream);
-int vqa_launch_pad_rows(const void* rows, int64_t n, int32_t d, int32_t d_pad, int32_t elem_bytes, void* out,
-                        hipStream_t stream);
+// row-major [valid, d] f32|f16 rows (device) -> TILED fp16 layout of the index at rows [first, first + count);
+// rows valid..count-1 are written as zeros (query tile: first = 0, count = 256, valid = nq)
+int vqa_launch_tile_rows(const void* rows, int32_t src_dtype, int64_t first, int64_t count, int64_t valid, int32_t d,
+                         int32_t d_pad, void* out, hipStream_t stream);

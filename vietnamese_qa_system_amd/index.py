@@ -14,7 +14,7 @@ import torch
 
 from . import _native as N
 
-_TORCH_DTYPE = {N.VQA_F32: torch.float32, N.VQA_F16: torch.float16}
+_SRC_DTYPE = {torch.float32: N.VQA_F32, torch.float16: N.VQA_F16}
 
 
 def _require_gpu(device: int) -> None:
@@ -36,67 +36,91 @@ def resolve_dtype(dtype) -> int:
         raise ValueError(f"unknown index dtype {dtype!r}; expected one of {sorted(N.DTYPE_NAMES)}") from None
 
 
-class DeviceIndex:
-    """One row shard of the corpus in HBM, searched by the fused MFMA scoring + top-k kernel.
+def _as_tensor(a, what: str) -> torch.Tensor:
+    t = torch.from_numpy(np.ascontiguousarray(a)) if isinstance(a, np.ndarray) else a
+    if not isinstance(t, torch.Tensor):
+        raise ValueError(f"{what} must be a torch tensor or numpy array")
+    return t
 
-    ``vectors`` [n, d]: a torch tensor (cpu or cuda) or numpy array holding either values already in the storage
-    type (``float16`` for ``dtype='fp16'``) or ``float32`` embeddings, which are L2-normalised (when
-    ``normalize=True``, txtai's behaviour) and converted on the device.  ``ids`` [n] int64 external ids or ``None``
-    (id = ``id_base`` + row position; sqlite AUTOINCREMENT rowids start at 1, ``setup_db.py:14``).
+
+class DeviceIndex:
+    """One row shard of the corpus in HBM (tiled fp16 layout), searched by the fused MFMA scoring + top-k kernel.
+
+    ``DeviceIndex(vectors, ids)`` builds a shard from ``vectors`` [n, d] (torch tensor on any device or numpy array,
+    ``float32`` or ``float16``); ``normalize=True`` L2-normalises float32 rows on the device first (txtai's behaviour
+    at index time).  ``ids`` [n] int64 external ids or ``None`` (id = ``id_base`` + row position; sqlite
+    AUTOINCREMENT rowids start at 1, ``setup_db.py:14``).  ``DeviceIndex.empty(n, d)`` + :meth:`set_rows` fills a
+    large shard chunk by chunk without a second full copy.
     """
 
-    def __init__(self, vectors, ids=None, *, id_base: int = 0, dtype="fp16", device: int = 0, normalize: bool = False,
-                 borrow: bool = False):
+    def __init__(self, vectors=None, ids=None, *, id_base: int = 0, dtype="fp16", device: int = 0, normalize: bool = False,
+                 n: Optional[int] = None, d: Optional[int] = None, with_ids: Optional[bool] = None):
         self._handle = ctypes.c_void_p()
         self.device = int(device)
         _require_gpu(self.device)
         self._lib = N.load()
         self.dtype = resolve_dtype(dtype)
-        dev = torch.device("cuda", self.device)
-        v = torch.from_numpy(np.ascontiguousarray(vectors)) if isinstance(vectors, np.ndarray) else vectors
-        if not isinstance(v, torch.Tensor) or v.dim() != 2:
-            raise ValueError("vectors must be a 2-D torch tensor or numpy array [n, d]")
-        n, d = int(v.shape[0]), int(v.shape[1])
-        stored_t = _TORCH_DTYPE.get(self.dtype)
-        if self.dtype == N.VQA_FP8_E4M3:
-            stored_t = torch.uint8
-        with torch.cuda.device(dev):
-            if v.dtype == stored_t and not normalize:
-                rows = v.contiguous()
-            elif v.dtype == torch.float32:
-                src = v.to(dev).contiguous()
-                rows = torch.empty((n, d), dtype=stored_t, device=dev)
-                if n:
-                    stream = torch.cuda.current_stream(dev).cuda_stream
-                    N.check(self._lib.vqa_normalize_convert(src.data_ptr(), n, d, int(bool(normalize)), self.dtype,
-                                                            rows.data_ptr(), stream), "vqa_normalize_convert")
-                    torch.cuda.current_stream(dev).synchronize()
-                del src
-            else:
-                raise ValueError(f"vectors of dtype {v.dtype} cannot back a {dtype} index "
-                                 f"(pass float32 embeddings or values already stored as {stored_t})")
-            ids_t = None
-            if ids is not None:
-                ids_t = torch.as_tensor(np.asarray(ids) if not isinstance(ids, torch.Tensor) else ids).to(torch.int64)
-                if ids_t.numel() != n:
-                    raise ValueError(f"{ids_t.numel()} ids for {n} rows")
-                ids_t = ids_t.contiguous()
-            # by default the library copies the rows into its own allocation and torch's buffer is released;
-            # borrow=True (device rows, d % 64 == 0) shares the caller's tensor instead: no second copy of a
-            # 15-123 GB shard.  The tensor is kept alive by this object.
-            flags = 0
-            self._borrowed = None
-            if borrow:
-                if not rows.is_cuda or rows.device.index != self.device:
-                    raise ValueError("borrow=True needs the rows on the index's device")
-                flags = N.VQA_ROWS_BORROW
-                self._borrowed = rows
-            N.check(self._lib.vqa_index_create(ctypes.byref(self._handle), self.device, n, d, self.dtype,
-                                               rows.data_ptr() if n else None,
-                                               ids_t.data_ptr() if ids_t is not None and n else None, int(id_base), flags),
+        if vectors is not None:
+            v = _as_tensor(vectors, "vectors")
+            if v.dim() != 2:
+                raise ValueError("vectors must be 2-D [n, d]")
+            n, d = int(v.shape[0]), int(v.shape[1])
+        elif n is None or d is None:
+            raise ValueError("either vectors or (n, d) must be given")
+        has_ids = bool(with_ids) if with_ids is not None else ids is not None
+        with torch.cuda.device(self.device):
+            N.check(self._lib.vqa_index_create(ctypes.byref(self._handle), self.device, int(n), int(d), self.dtype, None,
+                                               N.VQA_F16, None, int(id_base), N.VQA_INDEX_HAS_IDS if has_ids else 0),
                     "vqa_index_create")
-        self.n, self.d = n, d
-        self.id_base = int(id_base)
+        self.n, self.d, self.id_base, self.has_ids = int(n), int(d), int(id_base), has_ids
+        if vectors is not None and n:
+            self.set_rows(0, v, ids, normalize=normalize)
+
+    @classmethod
+    def empty(cls, n: int, d: int, *, id_base: int = 0, dtype="fp16", device: int = 0, with_ids: bool = False) -> "DeviceIndex":
+        """A shard of ``n`` zero rows to be filled with :meth:`set_rows`."""
+        return cls(None, None, id_base=id_base, dtype=dtype, device=device, n=n, d=d, with_ids=with_ids)
+
+    # -- filling -------------------------------------------------------------------------------------------------
+    def set_rows(self, first: int, vectors, ids=None, *, normalize: bool = False, chunk_rows: int = 1 << 20) -> None:
+        """Write ``vectors`` [count, d] (float32/float16, host or device) to rows [first, first + count)."""
+        if not self._handle.value:
+            raise RuntimeError("index is closed")
+        v = _as_tensor(vectors, "vectors")
+        if v.dim() != 2 or int(v.shape[1]) != self.d:
+            raise ValueError(f"vectors must be [count, {self.d}]")
+        if v.dtype not in _SRC_DTYPE:
+            raise ValueError(f"vectors must be float32 or float16, got {v.dtype}")
+        count = int(v.shape[0])
+        if first < 0 or first + count > self.n:
+            raise ValueError(f"rows [{first}, {first + count}) outside the shard of {self.n} rows")
+        ids_t = None
+        if ids is not None:
+            ids_t = _as_tensor(ids, "ids").to(torch.int64).contiguous()
+            if ids_t.numel() != count:
+                raise ValueError(f"{ids_t.numel()} ids for {count} rows")
+        if (ids_t is not None) != self.has_ids and count:
+            raise ValueError("ids must be given exactly when the index was created with ids")
+        dev = torch.device("cuda", self.device)
+        with torch.cuda.device(dev):
+            for c0 in range(0, count, chunk_rows):
+                c1 = min(count, c0 + chunk_rows)
+                rows = v[c0:c1].contiguous()
+                if normalize:
+                    # x / ||x|| in fp32 on the device, then the library rounds to the storage type
+                    src = rows.to(dev, dtype=torch.float32)
+                    out = torch.empty_like(src)
+                    stream = torch.cuda.current_stream(dev)
+                    N.check(self._lib.vqa_normalize_convert(src.data_ptr(), c1 - c0, self.d, 1, N.VQA_F32, out.data_ptr(),
+                                                            stream.cuda_stream), "vqa_normalize_convert")
+                    stream.synchronize()
+                    rows = out
+                chunk_ids = ids_t[c0:c1].contiguous() if ids_t is not None else None
+                if rows.is_cuda:
+                    torch.cuda.current_stream(rows.device).synchronize()  # set_rows runs on the null stream
+                N.check(self._lib.vqa_index_set_rows(self._handle, first + c0, c1 - c0, rows.data_ptr(), _SRC_DTYPE[rows.dtype],
+                                                     chunk_ids.data_ptr() if chunk_ids is not None else None),
+                        "vqa_index_set_rows")
 
     # -- lifetime ------------------------------------------------------------------------------------------------
     def close(self) -> None:
@@ -134,9 +158,9 @@ class DeviceIndex:
             ids = torch.empty((b, k), dtype=torch.int64, device=dev)
             pos = torch.empty((b, k), dtype=torch.int64, device=dev) if return_positions else None
             stream = torch.cuda.current_stream(dev).cuda_stream
-            N.check(self._lib.vqa_index_search(self._handle, q.data_ptr(), N.VQA_F32 if q.dtype == torch.float32 else N.VQA_F16,
-                                               b, int(k), scores.data_ptr(), ids.data_ptr(),
-                                               pos.data_ptr() if pos is not None else None, stream), "vqa_index_search")
+            N.check(self._lib.vqa_index_search(self._handle, q.data_ptr(), _SRC_DTYPE[q.dtype], b, int(k), scores.data_ptr(),
+                                               ids.data_ptr(), pos.data_ptr() if pos is not None else None, stream),
+                    "vqa_index_search")
         return scores, ids, pos
 
     def set_timing(self, enabled: bool) -> None:
