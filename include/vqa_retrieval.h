@@ -64,6 +64,9 @@ int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t d, int32_t 
                      const int64_t* ids_or_null, int64_t id_base, uint32_t flags);
 int vqa_index_set_rows(vqa_index* index, int64_t first, int64_t count, const void* rows, int32_t rows_dtype,
                        const int64_t* ids_or_null);
+/* export (Embeddings.save, heavy_ranker.py:87): rows [first, first + count) back as row-major fp16 [count, d] (host or
+ * device pointer) and, optionally, their ids; synchronises before returning. */
+int vqa_index_get_rows(vqa_index* index, int64_t first, int64_t count, void* out_rows_f16, int64_t* out_ids_or_null);
 void vqa_index_destroy(vqa_index* index);
 int64_t vqa_index_size(const vqa_index* index);
 int32_t vqa_index_dim(const vqa_index* index);

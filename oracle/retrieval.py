@@ -159,10 +159,11 @@ def search(q: np.ndarray, x_stored: np.ndarray, k: int, *, dtype: int = DTYPE_F3
             cp = np.broadcast_to(np.arange(c0, c1, dtype=np.int64), (b, c)).copy()
         ms = np.concatenate([best_s, cs], axis=1)
         mp = np.concatenate([best_p, cp], axis=1)
-        new_s = np.empty((b, kk), dtype=q.dtype)
-        new_p = np.empty((b, kk), dtype=np.int64)
+        keep_n = min(kk, ms.shape[1])  # fewer than kk candidates exist while chunk < kk
+        new_s = np.empty((b, keep_n), dtype=q.dtype)
+        new_p = np.empty((b, keep_n), dtype=np.int64)
         for i in range(b):
-            o = _order_desc_pos_asc(ms[i], mp[i])[:kk]
+            o = _order_desc_pos_asc(ms[i], mp[i])[:keep_n]
             new_s[i] = ms[i, o]
             new_p[i] = mp[i, o]
         best_s, best_p = new_s, new_p

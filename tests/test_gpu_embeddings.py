@@ -1,0 +1,125 @@
+"""The txtai-shaped Embeddings boundary end to end on the GPU (vectors in, results out), the on-disk format, the
+content join, the driver counterpart, and the element-wise helpers -- against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import retrieval as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _corpus(n=3000, d=768, b=20, seed=21):
+    rng = np.random.default_rng(seed)
+    return rng.standard_normal((n, d)).astype(np.float32), rng.standard_normal((b, d)).astype(np.float32)
+
+
+def test_normalize_convert_matches_oracle(native_lib):
+    from vietnamese_qa_system_amd.index import DeviceIndex
+    x, _ = _corpus(2000, 100)
+    x[5] = 0  # zero row stays zero
+    ix = DeviceIndex(x, dtype="fp16", normalize=True)
+    rows, ids = ix.get_rows()
+    ref = R.l2_normalize(x)
+    assert ids is None and rows.shape == (2000, 100)
+    # the norm's summation order differs (wave shuffle vs numpy pairwise): allow one fp16 ulp
+    assert np.abs(rows.astype(np.float32) - ref.astype(np.float16).astype(np.float32)).max() <= 2 ** -11
+    assert (rows == ref.astype(np.float16)).mean() > 0.999
+    assert np.all(rows[5] == 0)
+    ix.close()
+
+
+def test_set_rows_get_rows_roundtrip_chunked(native_lib):
+    from vietnamese_qa_system_amd.index import DeviceIndex
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((1000, 72)).astype(np.float16)  # d not a multiple of 64; ragged last tile
+    ids = rng.permutation(10_000)[:1000].astype(np.int64)
+    ix = DeviceIndex.empty(1000, 72, with_ids=True)
+    ix.set_rows(0, x[:300], ids[:300])
+    ix.set_rows(300, torch.from_numpy(x[300:]).cuda(), ids[300:])  # device source
+    rows, got_ids = ix.get_rows()
+    assert np.array_equal(rows, x) and np.array_equal(got_ids, ids)
+    q = rng.standard_normal((3, 72)).astype(np.float16)
+    s, i, p = ix.search(torch.from_numpy(q).cuda(), 5, return_positions=True)
+    torch.cuda.synchronize()
+    R.check_topk(s.cpu().numpy(), p.cpu().numpy(), R.full_scores(q.astype(np.float32), x, R.DTYPE_F16), 5, score_tol=2e-4,
+                 tie_tol=2e-5)  # un-normalised rows: scores ~ 70 x larger than unit vectors
+    assert np.array_equal(i.cpu().numpy(), ids[p.cpu().numpy()])
+    with pytest.raises(ValueError):
+        ix.set_rows(900, x[:200], ids[:200])
+    ix.close()
+
+
+def test_embeddings_vectors_in_results_out(native_lib):
+    from vietnamese_qa_system_amd import Embeddings
+    x, q = _corpus()
+    ids = list(range(1, x.shape[0] + 1))  # sqlite rowids (setup_db.py:14)
+    emb = Embeddings(min_score=None)
+    emb.index_vectors(ids, x)
+    assert emb.count() == 3000
+    res = emb.batchsearch(q, 10)
+    x16 = R.l2_normalize(x).astype(np.float16)
+    q16 = R.l2_normalize(q).astype(np.float16)
+    ref_s, ref_i, _ = R.search(q16.astype(np.float32), x16, 10, dtype=R.DTYPE_F16, id_base=1)
+    got_i = np.array([[h[0] for h in r] for r in res])
+    got_s = np.array([[h[1] for h in r] for r in res], dtype=np.float32)
+    assert R.recall_at_k(got_i, ref_i) > 0.995  # device-side normalisation may flip a last-ulp near-tie
+    assert np.abs(got_s - ref_s).max() < 1e-4
+    assert all(isinstance(h[0], int) and isinstance(h[1], float) for h in res[0])
+    one = emb.search(q[0], 1)  # heavy_ranker.py:98 calling pattern: one query, limit 1
+    assert one[0][0] == res[0][0][0]
+    assert len(emb.search(q[0])) == 3  # txtai default limit
+    with pytest.raises(ValueError):
+        emb.search(q[:2], 1)
+    with pytest.raises(ValueError):
+        emb.batchsearch(q[:, :10], 1)
+
+
+def test_embeddings_min_score_filter_is_host_side(native_lib):
+    from vietnamese_qa_system_amd import Embeddings
+    x, q = _corpus(50, 64, 4)
+    emb = Embeddings()  # txtai default: drop score <= 0
+    emb.index_vectors(None, x)
+    for r in emb.batchsearch(q, 12):
+        assert all(sc > 0 for _, sc in r) and len(r) <= 12
+    emb.min_score = None
+    assert all(len(r) == 12 for r in emb.batchsearch(q, 12))
+
+
+def test_embeddings_save_load_content_and_driver(native_lib, tmp_path):
+    from vietnamese_qa_system_amd import Embeddings, heavy_ranker, docstore
+    x, q = _corpus(400, 128, 6)
+    docs = [{"id": i + 1, "text": f"tài liệu số {i + 1}", "source": "wiki"} for i in range(400)]
+    emb = Embeddings(content=True, path="sentence-transformers/paraphrase-multilingual-mpnet-base-v2", min_score=None)
+    emb.index(docs, vectors=x)
+    before = emb.batchsearch(q, 5)
+    assert set(before[0][0]) == {"id", "text", "score"} and before[0][0]["text"] == docs[before[0][0]["id"] - 1]["text"]
+    emb.save(str(tmp_path / "mpnet"))
+    emb2 = Embeddings().load(str(tmp_path / "mpnet"))  # heavy_ranker.py:91-94
+    emb2.min_score = None
+    after = emb2.batchsearch(q, 5)
+    assert after == before
+    assert emb2.content and emb2.count() == 400
+    # driver counterpart of heavy_ranker.py:97-115 with two "models" (same index twice -> always agreeing ids)
+    db = str(tmp_path / "documents.db")
+    docstore.write_documents(db, docs)
+    out = heavy_ranker.rank_queries(emb2, emb2, (q, q), db)
+    for row in out:
+        assert row["id_a"] == row["id_b"] and row["doc_a"] == docs[row["id_a"] - 1]["text"]
+        assert row["match"] == (row["score_a"] + row["score_b"] > 0.4)
+
+
+def test_embeddings_string_ids_and_text_encoder_hook(native_lib):
+    from vietnamese_qa_system_amd import Embeddings
+    x, _ = _corpus(64, 64, 1)
+    table = {f"text {i}": torch.from_numpy(x[i]) for i in range(64)}
+
+    def fake_encoder(texts):  # stands in for a tokenizer + question encoder: list[str] -> [B, d]
+        return torch.stack([table[t] for t in texts])
+
+    emb = Embeddings(encoder=fake_encoder, min_score=None)
+    emb.index([(f"doc-{i}", f"text {i}", None) for i in range(64)])
+    hit = emb.search("text 17", 1)[0]
+    assert hit[0] == "doc-17" and abs(hit[1] - 1.0) < 2e-3
+    with pytest.raises(RuntimeError, match="no text encoder"):
+        Embeddings().index([{"id": 1, "text": "x"}])

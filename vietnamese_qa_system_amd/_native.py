@@ -23,7 +23,7 @@ DTYPE_BYTES = {VQA_F32: 4, VQA_F16: 2, VQA_FP8_E4M3: 1}
 
 # every symbol include/vqa_retrieval.h declares (tests/test_capi_symbols.py checks the two lists agree)
 EXPORTS = (
-    "vqa_version", "vqa_last_error", "vqa_index_create", "vqa_index_set_rows", "vqa_index_destroy", "vqa_index_size", "vqa_index_dim",
+    "vqa_version", "vqa_last_error", "vqa_index_create", "vqa_index_set_rows", "vqa_index_get_rows", "vqa_index_destroy", "vqa_index_size", "vqa_index_dim",
     "vqa_index_dtype", "vqa_index_search", "vqa_merge_topk", "vqa_index_launch_info", "vqa_index_set_timing",
     "vqa_index_get_timing", "vqa_encoder_create",
     "vqa_encoder_destroy", "vqa_encoder_forward", "vqa_normalize_convert",
@@ -78,6 +78,7 @@ def load() -> ctypes.CDLL:
     lib.vqa_index_create.argtypes = [c.POINTER(c.c_void_p), c.c_int, c.c_int64, c.c_int32, c.c_int32, c.c_void_p,
                                      c.c_int32, c.c_void_p, c.c_int64, c.c_uint32]
     lib.vqa_index_set_rows.argtypes = [c.c_void_p, c.c_int64, c.c_int64, c.c_void_p, c.c_int32, c.c_void_p]
+    lib.vqa_index_get_rows.argtypes = [c.c_void_p, c.c_int64, c.c_int64, c.c_void_p, c.c_void_p]
     lib.vqa_index_destroy.argtypes = [c.c_void_p]
     lib.vqa_index_destroy.restype = None
     lib.vqa_index_size.argtypes = [c.c_void_p]

@@ -203,6 +203,48 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
     return VQA_OK;
 }
 
+extern "C" int vqa_index_get_rows(vqa_index* ix, int64_t first, int64_t count, void* out_rows_f16, int64_t* out_ids_or_null) {
+    VQA_REQUIRE(ix, "vqa_index_get_rows: index is null");
+    VQA_REQUIRE(first >= 0 && count >= 0 && first + count <= ix->n, "vqa_index_get_rows: rows [%lld, %lld) outside [0, %lld)",
+                (long long)first, (long long)(first + count), (long long)ix->n);
+    if (count == 0) return VQA_OK;
+    VQA_REQUIRE(out_rows_f16, "vqa_index_get_rows: out is null");
+    DeviceGuard guard(ix->device);
+    hipPointerAttribute_t attr;
+    const bool on_device = hipPointerGetAttributes(&attr, out_rows_f16) == hipSuccess && attr.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();
+    if (on_device) {
+        int rc = vqa_launch_untile_rows(ix->rows, first, count, ix->d, ix->d_pad, out_rows_f16, nullptr);
+        if (rc != VQA_OK) return rc;
+    } else {
+        const int64_t chunk_rows = std::max<int64_t>(1, (64ll << 20) / ix->d);
+        const size_t need = (size_t)std::min(chunk_rows, count) * ix->d * 2;
+        if (ix->q_rows_bytes < need) {
+            if (ix->q_rows) (void)hipFree(ix->q_rows);
+            ix->q_rows = nullptr;
+            ix->q_rows_bytes = 0;
+            if (hipMalloc(&ix->q_rows, need) != hipSuccess) {
+                vqa_set_error("vqa_index_get_rows: hipMalloc of %zu staging bytes failed", need);
+                return VQA_ENOMEM;
+            }
+            ix->q_rows_bytes = need;
+        }
+        for (int64_t c0 = 0; c0 < count; c0 += chunk_rows) {
+            const int64_t c = std::min(chunk_rows, count - c0);
+            int rc = vqa_launch_untile_rows(ix->rows, first + c0, c, ix->d, ix->d_pad, ix->q_rows, nullptr);
+            if (rc != VQA_OK) return rc;
+            VQA_HIP_CHECK(hipMemcpy(reinterpret_cast<char*>(out_rows_f16) + (size_t)c0 * ix->d * 2, ix->q_rows,
+                                    (size_t)c * ix->d * 2, hipMemcpyDeviceToHost));
+        }
+    }
+    if (out_ids_or_null) {
+        VQA_REQUIRE(ix->ids, "vqa_index_get_rows: the index has no id vector (ids are id_base + position)");
+        VQA_HIP_CHECK(hipMemcpy(out_ids_or_null, ix->ids + first, (size_t)count * 8, hipMemcpyDefault));
+    }
+    VQA_HIP_CHECK(hipStreamSynchronize(nullptr));
+    return VQA_OK;
+}
+
 extern "C" int64_t vqa_index_size(const vqa_index* ix) { return ix ? ix->n : -1; }
 extern "C" int32_t vqa_index_dim(const vqa_index* ix) { return ix ? ix->d : -1; }
 extern "C" int32_t vqa_index_dtype(const vqa_index* ix) { return ix ? ix->dtype : -1; }

@@ -75,6 +75,17 @@ __global__ void tile_rows_kernel(const SRC* __restrict__ rows, long long first, 
     }
 }
 
+// inverse of tile_rows: TILED fp16 -> row-major [count, d] fp16 (index export for Embeddings.save)
+__global__ void untile_rows_kernel(const _Float16* __restrict__ tiled, long long first, long long count, int d, int KT,
+                                   _Float16* __restrict__ out) {
+    const long long total = count * d;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long ri = i / d;
+        const int j = (int)(i - ri * d);
+        out[i] = tiled[tiled_unit(first + ri, j >> 5, (j >> 3) & 3, KT) * 8 + (j & 7)];
+    }
+}
+
 // one wave per row: sum of squares by wavefront shuffles, then scale + convert
 __global__ __launch_bounds__(256) void normalize_convert_kernel(const float* __restrict__ rows, long long n, int d,
                                                                 int normalize, int dtype, void* __restrict__ out) {
@@ -120,6 +131,18 @@ int vqa_launch_tile_rows(const void* rows, int32_t src_dtype, int64_t first, int
         hipLaunchKernelGGL(tile_rows_kernel<_Float16>, dim3(blocks), dim3(threads), 0, stream,
                            reinterpret_cast<const _Float16*>(rows), (long long)first, (long long)count, (long long)valid, d, KT,
                            reinterpret_cast<_Float16*>(out));
+    VQA_HIP_CHECK(hipGetLastError());
+    return VQA_OK;
+}
+
+int vqa_launch_untile_rows(const void* tiled, int64_t first, int64_t count, int32_t d, int32_t d_pad, void* out,
+                           hipStream_t stream) {
+    if (count == 0) return VQA_OK;
+    const long long total = (long long)count * d;
+    const int threads = 256;
+    const int blocks = (int)((total + threads - 1) / threads < 65536 ? (total + threads - 1) / threads : 65536);
+    hipLaunchKernelGGL(untile_rows_kernel, dim3(blocks), dim3(threads), 0, stream, reinterpret_cast<const _Float16*>(tiled),
+                       (long long)first, (long long)count, d, d_pad / 32, reinterpret_cast<_Float16*>(out));
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

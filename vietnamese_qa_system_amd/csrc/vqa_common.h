@@ -75,3 +75,6 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
 // rows valid..count-1 are written as zeros (query tile: first = 0, count = 256, valid = nq)
 int vqa_launch_tile_rows(const void* rows, int32_t src_dtype, int64_t first, int64_t count, int64_t valid, int32_t d,
                          int32_t d_pad, void* out, hipStream_t stream);
+// TILED fp16 rows [first, first + count) -> row-major [count, d] fp16 (device)
+int vqa_launch_untile_rows(const void* tiled, int64_t first, int64_t count, int32_t d, int32_t d_pad, void* out,
+                           hipStream_t stream);

@@ -122,6 +122,18 @@ class DeviceIndex:
                                                      chunk_ids.data_ptr() if chunk_ids is not None else None),
                         "vqa_index_set_rows")
 
+    def get_rows(self, first: int = 0, count: Optional[int] = None) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+        """Stored rows [first, first + count) as a host ``float16`` array [count, d] (and their ids, if the index has an
+        id vector) -- the export used by ``Embeddings.save``."""
+        if not self._handle.value:
+            raise RuntimeError("index is closed")
+        count = self.n - first if count is None else int(count)
+        rows = np.empty((count, self.d), dtype=np.float16)
+        ids = np.empty((count,), dtype=np.int64) if self.has_ids else None
+        N.check(self._lib.vqa_index_get_rows(self._handle, int(first), count, rows.ctypes.data if count else None,
+                                             ids.ctypes.data if ids is not None and count else None), "vqa_index_get_rows")
+        return rows, ids
+
     # -- lifetime ------------------------------------------------------------------------------------------------
     def close(self) -> None:
         if getattr(self, "_handle", None) is not None and self._handle.value:

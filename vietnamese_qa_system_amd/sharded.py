@@ -51,8 +51,9 @@ class ShardedSearcher:
         if self._gs is None or self._gs.shape[1:] != (b, k) or self._gs.device != s.device:
             self._gs = torch.empty((self.world, b, k), dtype=torch.float32, device=s.device)
             self._gi = torch.empty((self.world, b, k), dtype=torch.int64, device=s.device)
-        dist.all_gather_into_tensor(self._gs, s.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(self._gi, i.contiguous(), group=self.group)
+        # output viewed as the concatenation along dim 0 ([R * B, k]): same memory as [R, B, k], accepted by RCCL and gloo
+        dist.all_gather_into_tensor(self._gs.view(self.world * b, k), s.contiguous(), group=self.group)
+        dist.all_gather_into_tensor(self._gi.view(self.world * b, k), i.contiguous(), group=self.group)
         return self.merge(self._gs, self._gi, k)
 
 
