@@ -1,0 +1,82 @@
+"""HIP question encoder (through the C ABI) against the numpy oracle, which is itself pinned to HF transformers by
+tests/test_oracle_encoder.py.  Tolerance (fp16 storage, fp32 accumulation, stated per SURVEY.md section 7): pooled vectors
+within 2e-2 absolute and cosine >= 0.999 of the fp64 oracle; retrieval with the encoded queries returns the oracle's
+top-1 ids."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoder as E
+from oracle import retrieval as R
+
+pytestmark = pytest.mark.gpu
+
+TINY = dict(vocab_size=100, hidden=64, layers=2, heads=4, ffn=128, max_pos=40, type_vocab=1, pad_id=1, ln_eps=1e-5)
+
+
+def _cos(a, b):
+    return (a * b).sum(-1) / (np.linalg.norm(a, axis=-1) * np.linalg.norm(b, axis=-1))
+
+
+def test_tiny_fixture_all_poolings(native_lib, golden_dir):
+    from vietnamese_qa_system_amd.encoder import QuestionEncoder
+    g = np.load(f"{golden_dir}/enc_tiny.npz")
+    w = {k[2:]: g[k] for k in g.files if k.startswith("w.")}
+    enc = QuestionEncoder(w, TINY, max_tokens=64)
+    ids, mask = g["input_ids"], g["attention_mask"]
+    cls_raw = enc.forward(ids, mask, pooling="cls", normalize=False).cpu().numpy()
+    assert np.abs(cls_raw - g["dpr_pooler_output"]).max() < 2e-2      # HF DPR pooler_output
+    assert _cos(cls_raw, g["dpr_pooler_output"]).min() > 0.9995
+    for pooling in ("cls", "mean"):
+        got = enc.forward(ids, mask, pooling=pooling, normalize=True).cpu().numpy()
+        ref = E.encode(w, TINY, ids, mask, pooling=pooling)
+        assert np.abs(np.linalg.norm(got, axis=1) - 1).max() < 1e-5
+        assert _cos(got, ref).min() > 0.9995 and np.abs(got - ref).max() < 5e-3
+    with pytest.raises(ValueError):
+        enc.forward(np.zeros((40, 12), np.int32), np.ones((40, 12), np.int32))  # 480 tokens > max_tokens
+    with pytest.raises(ValueError):
+        enc.forward(ids, mask, pooling="max")
+    enc.close()
+
+
+@pytest.mark.parametrize("layers,b,l", [(2, 8, 32), (12, 12, 24)])
+def test_phobert_base_shape_vs_oracle(native_lib, layers, b, l):
+    from vietnamese_qa_system_amd.encoder import QuestionEncoder
+    cfg = dict(E.PHOBERT_BASE, layers=layers)
+    w = E.synthetic_weights(cfg, seed=5, layers=layers)
+    ids, mask = E.synthetic_tokens(cfg, b, l, seed=9)
+    enc = QuestionEncoder(w, cfg, max_tokens=b * l)
+    for pooling in ("cls", "mean"):
+        got = enc.forward(ids, mask, pooling=pooling).cpu().numpy()
+        ref = E.encode(w, cfg, ids, mask, pooling=pooling)
+        assert _cos(got, ref).min() > 0.999, (pooling, _cos(got, ref).min())
+        assert np.abs(got - ref).max() < 2e-2
+    enc.close()
+
+
+def test_encoder_feeds_retrieval(native_lib):
+    """configs[1] in miniature: encoder forward -> fp16 index search; ids must match the all-oracle pipeline."""
+    from vietnamese_qa_system_amd import Embeddings
+    from vietnamese_qa_system_amd.encoder import QuestionEncoder, TextEncoder
+    cfg = dict(E.PHOBERT_BASE, layers=2)
+    w = E.synthetic_weights(cfg, seed=2, layers=2)
+    ids, mask = E.synthetic_tokens(cfg, 48, 16, seed=4)
+    table = {f"q{i}": (ids[i], mask[i]) for i in range(48)}
+
+    def tokenizer(texts):
+        return np.stack([table[t][0] for t in texts]), np.stack([table[t][1] for t in texts])
+
+    enc = QuestionEncoder(w, cfg, max_tokens=48 * 16)
+    ref_q = E.encode(w, cfg, ids, mask, pooling="mean").astype(np.float32)
+    rng = np.random.default_rng(0)
+    # corpus = slightly noisy copies of the query embeddings (cosine ~0.998 to their own query, <= 0.96 to any other --
+    # random-weight embeddings are close to each other) + distractors: every query has a clear nearest document
+    docs = np.concatenate([ref_q + 0.002 * rng.standard_normal(ref_q.shape).astype(np.float32),
+                           rng.standard_normal((2000, 768)).astype(np.float32) / 28])
+    emb = Embeddings(encoder=TextEncoder(tokenizer, enc, pooling="mean"), min_score=None)
+    emb.index_vectors(list(range(1, docs.shape[0] + 1)), docs)
+    res = emb.batchsearch([f"q{i}" for i in range(48)], 1)
+    x16 = R.l2_normalize(docs).astype(np.float16)
+    _, ref_ids, _ = R.search(R.l2_normalize(ref_q).astype(np.float16).astype(np.float32), x16, 1, dtype=R.DTYPE_F16, id_base=1)
+    assert [r[0][0] for r in res] == ref_ids[:, 0].tolist() == list(range(1, 49))
+    enc.close()

@@ -1,0 +1,53 @@
+"""The encoder oracle (plain numpy, no transformers import) against the golden vectors HF RobertaModel /
+DPRQuestionEncoder produced in the build container (tests/golden/make_golden_encoder.py)."""
+import numpy as np
+
+from oracle import encoder as E
+
+TINY = dict(vocab_size=100, hidden=64, layers=2, heads=4, ffn=128, max_pos=40, type_vocab=1, pad_id=1, ln_eps=1e-5)
+
+
+def _tiny(golden_dir):
+    g = np.load(f"{golden_dir}/enc_tiny.npz")
+    return g, {k[2:]: g[k] for k in g.files if k.startswith("w.")}
+
+
+def test_tiny_roberta_last_hidden_state(golden_dir):
+    g, w = _tiny(golden_dir)
+    out = E.forward(w, TINY, g["input_ids"], g["attention_mask"])
+    assert np.abs(out - g["last_hidden_state"]).max() < 5e-6
+
+
+def test_tiny_dpr_pooler_output_is_cls(golden_dir):
+    g, w = _tiny(golden_dir)
+    pooled = E.encode(w, TINY, g["input_ids"], g["attention_mask"], pooling="cls", l2=False)
+    assert np.abs(pooled - g["dpr_pooler_output"]).max() < 5e-6
+
+
+def test_position_ids_skip_padding():
+    ids = np.array([[0, 5, 6, 2, 1, 1], [0, 2, 1, 1, 1, 1]])
+    assert E.position_ids(ids, 1).tolist() == [[2, 3, 4, 5, 1, 1], [2, 3, 1, 1, 1, 1]]
+
+
+def test_phobert_shaped_layer(golden_dir):
+    p = np.load(f"{golden_dir}/enc_phobert_layer.npz")
+    cfg = dict(E.PHOBERT_BASE, layers=1)
+    w = {k: v.astype(np.float64) for k, v in E.synthetic_weights(cfg, seed=1234, layers=1).items()}
+    out = E.layer_forward(w, cfg, 0, p["hidden_in"].astype(np.float64), p["attention_mask"])
+    assert np.abs(out - p["hidden_out"]).max() < 5e-6
+
+
+def test_mean_pool_and_normalize():
+    h = np.arange(24, dtype=np.float64).reshape(2, 3, 4)
+    m = np.array([[1, 1, 0], [1, 0, 0]])
+    assert np.allclose(E.pool(h, m, "mean"), [[2, 3, 4, 5], [12, 13, 14, 15]])
+    n = E.normalize(np.array([[3.0, 4.0], [0.0, 0.0]]))
+    assert np.allclose(n, [[0.6, 0.8], [0, 0]])
+
+
+def test_synthetic_tokens_shape():
+    ids, mask = E.synthetic_tokens(E.PHOBERT_BASE, 16, 32, seed=3)
+    assert ids.shape == (16, 32) and (ids[:, 0] == 0).all()
+    lens = mask.sum(1)
+    assert lens.min() >= 8 and lens.max() <= 32
+    assert all(ids[i, lens[i] - 1] == 2 and (ids[i, lens[i]:] == 1).all() for i in range(16))

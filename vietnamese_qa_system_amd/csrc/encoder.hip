@@ -1,14 +1,509 @@
-// Question-encoder entry points (placeholder until the encoder kernels land in this round).
+// K3 -- question-encoder forward (RoBERTa / PhoBERT-base-shaped post-LN transformer), gfx950 only.
+//
+// Replaces the transformer forward + pooling + L2-normalise that txtai runs for every query inside
+// `embeddings.search` (reference call sites inference_pipeline/db_utils/heavy_ranker.py:98-101; model chosen by `path=`
+// at :80,83; DPR form at src/test.py:84-86 `q_model(input_ids).pooler_output`).  Algorithm = HF RoBERTa
+// (modeling_roberta.py: embeddings with pad-offset position ids, post-LN layers, erf GELU, LN eps from the config).
+//
+// Kernels (all hand-written, fp16 storage, fp32 accumulation / statistics):
+//   embed_ln        word + position + type embeddings -> LayerNorm                      (one wave per token)
+//   gemm_nt<EPI>    C[M,N] = A[M,K] . W[N,K]^T + bias (+ erf GELU); v_mfma_f32_16x16x32_f16, 128x128x32 tiles,
+//                   register-staged double-buffered LDS image, XOR-swizzled for conflict-free ds_read_b128
+//   attention       per (sequence, head): softmax(q k^T / sqrt(dh) + mask) v, K/V in LDS, wavefront-shuffle softmax
+//   add_ln          residual add + LayerNorm                                             (one wave per token)
+//   pool_normalize  CLS row or masked mean -> fp32 -> x / ||x||                          (one wave per sequence)
+#include <new>
+#include <vector>
+
 #include "vqa_common.h"
 
-extern "C" int vqa_encoder_create(vqa_encoder** out, int, const vqa_encoder_config*, const vqa_encoder_weights*, int32_t) {
-    if (out) *out = nullptr;
-    vqa_set_error("vqa_encoder_create: the encoder kernels are not part of this build yet");
-    return VQA_EINVAL;
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
 }
-extern "C" void vqa_encoder_destroy(vqa_encoder*) {}
-extern "C" int vqa_encoder_forward(vqa_encoder*, const int32_t*, const int32_t*, int32_t, int32_t, int32_t, int32_t, float*,
-                                   void*) {
-    vqa_set_error("vqa_encoder_forward: the encoder kernels are not part of this build yet");
-    return VQA_EINVAL;
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// ---- LayerNorm of one row held as kMaxPer values per lane (element j = lane + 64 i; slots with j >= H hold 0).
+// All loops are fully unrolled over kMaxPer with j < H predicates so x[] stays in registers.
+constexpr int kMaxPer = 32;  // hidden <= 2048
+
+__device__ __forceinline__ void row_layer_norm(float (&x)[kMaxPer], int H, int lane, const float* __restrict__ g,
+                                               const float* __restrict__ b, float eps, _Float16* __restrict__ out) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i) s += x[i];
+    const float mu = wave_sum(s) / H;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i) {
+        const float dlt = (lane + 64 * i < H) ? x[i] - mu : 0.f;
+        v += dlt * dlt;
+    }
+    const float rstd = rsqrtf(wave_sum(v) / H + eps);
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i) {
+        const int j = lane + 64 * i;
+        if (j < H) out[j] = (_Float16)((x[i] - mu) * rstd * g[j] + b[j]);
+    }
+}
+
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ ids, int T, int L, int H, int pad_id,
+                                                       const float* __restrict__ word, const float* __restrict__ pos,
+                                                       const float* __restrict__ type0, const float* __restrict__ g,
+                                                       const float* __restrict__ b, float eps, _Float16* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    const int seq = t / L, l = t - seq * L;
+    const int id = ids[t];
+    // RoBERTa position id: pad + (number of non-pad tokens up to and including this one), pad tokens keep pad
+    int cnt = 0;
+    for (int j = lane; j <= l; j += 64) cnt += ids[seq * L + j] != pad_id;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    const int pid = id != pad_id ? cnt + pad_id : pad_id;
+    float x[kMaxPer];
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i) {
+        const int j = lane + 64 * i;
+        x[i] = j < H ? word[(size_t)id * H + j] + pos[(size_t)pid * H + j] + type0[j] : 0.f;
+    }
+    row_layer_norm(x, H, lane, g, b, eps, out + (size_t)t * H);
+}
+
+__global__ __launch_bounds__(256) void add_ln_kernel(const _Float16* __restrict__ a, const _Float16* __restrict__ res, int T,
+                                                     int H, const float* __restrict__ g, const float* __restrict__ b,
+                                                     float eps, _Float16* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    float x[kMaxPer];
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i) {
+        const int j = lane + 64 * i;
+        x[i] = j < H ? (float)a[(size_t)t * H + j] + (float)res[(size_t)t * H + j] : 0.f;
+    }
+    row_layer_norm(x, H, lane, g, b, eps, out + (size_t)t * H);
+}
+
+// ---- GEMM: C[M, N] = A[M, K] . W[N, K]^T + bias[N]; EPI 0: identity, 1: erf GELU.  K % 32 == 0. ---------------------
+constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 32;
+constexpr int kGemmTileBytes = kGemmBM * kGemmBK * 2;  // 8 KiB per operand per stage
+
+__device__ __forceinline__ int swz_off(int row, int slot) { return row * 64 + ((slot ^ (((row >> 3) & 1) * 3)) << 4); }
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+                                                      const float* __restrict__ bias, _Float16* __restrict__ C, int M, int N,
+                                                      int K) {
+    __shared__ __attribute__((aligned(16))) char lds[4 * kGemmTileBytes];  // [stage][A | W]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int c = lane & 15, g = lane >> 4;
+    const int bm = blockIdx.y * kGemmBM, bn = blockIdx.x * kGemmBN;
+    // staging: unit u = tid + 256 i -> row u >> 2, 16-byte slot u & 3
+    int st_row[2], st_slot[2];
+    const _Float16* a_src[2];
+    const _Float16* w_src[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int u = tid + 256 * i;
+        st_row[i] = u >> 2;
+        st_slot[i] = u & 3;
+        const int ar = bm + st_row[i] < M ? bm + st_row[i] : M - 1;  // clamped rows are computed and discarded
+        const int wrow = bn + st_row[i] < N ? bn + st_row[i] : N - 1;
+        a_src[i] = A + (size_t)ar * K + st_slot[i] * 8;
+        w_src[i] = W + (size_t)wrow * K + st_slot[i] * 8;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int KT = K / kGemmBK;
+    half8 ra[2], rw[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        ra[i] = *reinterpret_cast<const half8*>(a_src[i]);
+        rw[i] = *reinterpret_cast<const half8*>(w_src[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        *reinterpret_cast<half8*>(lds + swz_off(st_row[i], st_slot[i])) = ra[i];
+        *reinterpret_cast<half8*>(lds + kGemmTileBytes + swz_off(st_row[i], st_slot[i])) = rw[i];
+    }
+    __syncthreads();
+    const int frag = swz_off(c, g);  // row base multiple of 16 keeps bit3(row) = bit3(c)
+    for (int kt = 0; kt < KT; ++kt) {
+        const char* cur = lds + (kt & 1) * 2 * kGemmTileBytes;
+        char* nxt = lds + ((kt + 1) & 1) * 2 * kGemmTileBytes;
+        if (kt + 1 < KT) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ra[i] = *reinterpret_cast<const half8*>(a_src[i] + (size_t)(kt + 1) * kGemmBK);
+                rw[i] = *reinterpret_cast<const half8*>(w_src[i] + (size_t)(kt + 1) * kGemmBK);
+            }
+        }
+        half8 a[4], b[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) a[mi] = *reinterpret_cast<const half8*>(cur + (wr * 64 + mi * 16) * 64 + frag);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+            b[ni] = *reinterpret_cast<const half8*>(cur + kGemmTileBytes + (wc * 64 + ni * 16) * 64 + frag);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        if (kt + 1 < KT) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                *reinterpret_cast<half8*>(nxt + swz_off(st_row[i], st_slot[i])) = ra[i];
+                *reinterpret_cast<half8*>(nxt + kGemmTileBytes + swz_off(st_row[i], st_slot[i])) = rw[i];
+            }
+        }
+        __syncthreads();
+    }
+    // epilogue: acc[mi][ni][j] = C[bm + wr*64 + mi*16 + 4g + j][bn + wc*64 + ni*16 + c]
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = bn + wc * 64 + ni * 16 + c;
+        if (n >= N) continue;
+        const float bv = bias[n];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = bm + wr * 64 + mi * 16 + g * 4 + j;
+                if (m >= M) continue;
+                float v = acc[mi][ni][j] + bv;
+                if (EPI == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                C[(size_t)m * N + n] = (_Float16)v;
+            }
+    }
+}
+
+// ---- attention: one workgroup per (sequence, head); K and V of the head in LDS (fp32), one wave per query row ------
+__global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ mask,
+                                                        int L, int H, int heads, _Float16* __restrict__ ctx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int dh = H / heads;           // <= 64... any dh <= 128 works with the loops below
+    float* ks = reinterpret_cast<float*>(smem);   // [L][dh + 1]
+    float* vs = ks + (size_t)L * (dh + 1);        // [L][dh + 1]
+    float* ps = vs + (size_t)L * (dh + 1);        // [4 waves][L] probabilities of the wave's current row
+    float* qs = ps + 4 * L;                       // [4 waves][dh]
+    const int seq = blockIdx.x / heads, head = blockIdx.x - seq * heads;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t row_stride = (size_t)3 * H;
+    const _Float16* base = qkv + (size_t)seq * L * row_stride + head * dh;
+    for (int i = tid; i < L * dh; i += 256) {
+        const int l = i / dh, d = i - l * dh;
+        ks[l * (dh + 1) + d] = (float)base[(size_t)l * row_stride + H + d];
+        vs[l * (dh + 1) + d] = (float)base[(size_t)l * row_stride + 2 * H + d];
+    }
+    __syncthreads();
+    const float scale = rsqrtf((float)dh);
+    for (int r = wave; r < L; r += 4) {
+        float* q = qs + wave * dh;
+        for (int d = lane; d < dh; d += 64) q[d] = (float)base[(size_t)r * row_stride + d];
+        __builtin_amdgcn_wave_barrier();
+        // scores for keys j = lane, lane + 64, ...
+        float mx = -INFINITY;
+        for (int j = lane; j < L; j += 64) {
+            float s = 0.f;
+            for (int d = 0; d < dh; ++d) s += q[d] * ks[j * (dh + 1) + d];
+            s = mask[seq * L + j] ? s * scale : -INFINITY;  // HF adds finfo.min: the masked key's weight is exactly 0
+            ps[wave * L + j] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int j = lane; j < L; j += 64) {
+            const float e = __expf(ps[wave * L + j] - mx);
+            ps[wave * L + j] = e;
+            sum += e;
+        }
+        sum = wave_sum(sum);
+        __builtin_amdgcn_wave_barrier();
+        const float inv = 1.0f / sum;
+        for (int d = lane; d < dh; d += 64) {
+            float o = 0.f;
+            for (int j = 0; j < L; ++j) o += ps[wave * L + j] * vs[j * (dh + 1) + d];
+            ctx[((size_t)seq * L + r) * H + head * dh + d] = (_Float16)(o * inv);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_normalize_kernel(const _Float16* __restrict__ hidden, const int* __restrict__ mask,
+                                                             int B, int L, int H, int pooling, int normalize,
+                                                             float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (seq >= B) return;
+    float x[kMaxPer];
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i) x[i] = 0.f;
+    if (pooling == VQA_POOL_CLS) {
+#pragma unroll
+        for (int i = 0; i < kMaxPer; ++i) {
+            const int j = lane + 64 * i;
+            if (j < H) x[i] = (float)hidden[(size_t)seq * L * H + j];
+        }
+    } else {
+        int cnt = 0;
+        for (int l = 0; l < L; ++l) {
+            if (!mask[seq * L + l]) continue;
+            ++cnt;
+#pragma unroll
+            for (int i = 0; i < kMaxPer; ++i) {
+                const int j = lane + 64 * i;
+                if (j < H) x[i] += (float)hidden[((size_t)seq * L + l) * H + j];
+            }
+        }
+        const float inv = 1.0f / fmaxf((float)cnt, 1e-9f);
+#pragma unroll
+        for (int i = 0; i < kMaxPer; ++i) x[i] *= inv;
+    }
+    float nrm = 1.0f;
+    if (normalize) {
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < kMaxPer; ++i) ss += x[i] * x[i];
+        nrm = sqrtf(wave_sum(ss));
+        if (!(nrm > 0.f)) nrm = 1.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i) {
+        const int j = lane + 64 * i;
+        if (j < H) out[(size_t)seq * H + j] = x[i] / nrm;
+    }
+}
+
+}  // namespace
+
+struct vqa_encoder {
+    int device = 0;
+    vqa_encoder_config cfg{};
+    int max_tokens = 0;
+    // fp32 parameters
+    float *word = nullptr, *pos = nullptr, *type0 = nullptr, *emb_g = nullptr, *emb_b = nullptr;
+    struct Layer {
+        _Float16 *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
+        float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+        float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+    };
+    std::vector<Layer> layers;
+    std::vector<void*> allocs;
+    // activations
+    _Float16 *x = nullptr, *qkv = nullptr, *ctx = nullptr, *tmp = nullptr, *ffn = nullptr;
+};
+
+namespace {
+
+struct DevGuard {
+    int prev = -1;
+    explicit DevGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        (void)hipSetDevice(dev);
+    }
+    ~DevGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+int dev_alloc(vqa_encoder* e, void** p, size_t bytes) {
+    if (hipMalloc(p, bytes ? bytes : 1) != hipSuccess) {
+        vqa_set_error("vqa_encoder_create: hipMalloc of %zu bytes failed", bytes);
+        return VQA_ENOMEM;
+    }
+    e->allocs.push_back(*p);
+    return VQA_OK;
+}
+
+// fp32 source (host or device) -> fp32 device copy
+int upload_f32(vqa_encoder* e, const float* src, size_t n, float** out) {
+    VQA_REQUIRE(src, "vqa_encoder_create: a weight pointer is null");
+    int rc = dev_alloc(e, (void**)out, n * 4);
+    if (rc != VQA_OK) return rc;
+    VQA_HIP_CHECK(hipMemcpy(*out, src, n * 4, hipMemcpyDefault));
+    return VQA_OK;
+}
+
+// fp32 source -> fp16 device copy at dst (element offset), through a temporary fp32 device buffer
+int upload_f16(vqa_encoder* e, const float* src, size_t n, _Float16* dst) {
+    VQA_REQUIRE(src, "vqa_encoder_create: a weight pointer is null");
+    float* tmp = nullptr;
+    if (hipMalloc((void**)&tmp, n * 4) != hipSuccess) {
+        vqa_set_error("vqa_encoder_create: staging hipMalloc of %zu bytes failed", n * 4);
+        return VQA_ENOMEM;
+    }
+    hipError_t err = hipMemcpy(tmp, src, n * 4, hipMemcpyDefault);
+    int rc = VQA_OK;
+    if (err == hipSuccess) {
+        const int32_t chunk = 256;  // element-wise conversion, no normalisation: rows of 256 elements (n % 32 == 0)
+        const int64_t rows = (int64_t)(n / chunk);
+        if (rows) rc = vqa_normalize_convert(tmp, rows, chunk, 0, VQA_F16, dst, nullptr);
+        if (rc == VQA_OK && n % chunk)
+            rc = vqa_normalize_convert(tmp + rows * chunk, 1, (int32_t)(n % chunk), 0, VQA_F16, dst + rows * chunk, nullptr);
+        if (rc == VQA_OK) err = hipDeviceSynchronize();
+    }
+    (void)hipFree(tmp);
+    if (rc != VQA_OK) return rc;
+    if (err != hipSuccess) {
+        vqa_set_error("vqa_encoder_create: weight conversion failed: %s", hipGetErrorString(err));
+        return VQA_EHIP;
+    }
+    return VQA_OK;
+}
+
+template <int EPI>
+int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, _Float16* C, int M, int N, int K, hipStream_t s) {
+    dim3 grid((N + kGemmBN - 1) / kGemmBN, (M + kGemmBM - 1) / kGemmBM);
+    hipLaunchKernelGGL(gemm_nt_kernel<EPI>, grid, dim3(256), 0, s, A, W, bias, C, M, N, K);
+    VQA_HIP_CHECK(hipGetLastError());
+    return VQA_OK;
+}
+
+}  // namespace
+
+extern "C" void vqa_encoder_destroy(vqa_encoder* e) {
+    if (!e) return;
+    DevGuard g(e->device);
+    for (void* p : e->allocs) (void)hipFree(p);
+    delete e;
+}
+
+extern "C" int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encoder_config* cfg, const vqa_encoder_weights* w,
+                                  int32_t max_tokens) {
+    VQA_REQUIRE(out, "vqa_encoder_create: out is null");
+    *out = nullptr;
+    VQA_REQUIRE(cfg && w && w->layer, "vqa_encoder_create: null config / weights");
+    VQA_REQUIRE(cfg->hidden >= 32 && cfg->hidden <= 64 * kMaxPer && cfg->hidden % 32 == 0, "vqa_encoder_create: hidden=%d must be a multiple of 32 in [32, %d]",
+                cfg->hidden, 64 * kMaxPer);
+    VQA_REQUIRE(cfg->ffn >= 32 && cfg->ffn % 32 == 0, "vqa_encoder_create: ffn=%d must be a multiple of 32", cfg->ffn);
+    VQA_REQUIRE(cfg->heads >= 1 && cfg->hidden % cfg->heads == 0 && cfg->hidden / cfg->heads <= 128,
+                "vqa_encoder_create: heads=%d does not divide hidden=%d into head sizes <= 128", cfg->heads, cfg->hidden);
+    VQA_REQUIRE(cfg->layers >= 1 && cfg->vocab_size >= 1 && cfg->max_pos >= 2 && cfg->type_vocab >= 1 && max_tokens >= 1,
+                "vqa_encoder_create: bad sizes");
+    VQA_REQUIRE(cfg->pad_id >= 0 && cfg->pad_id < cfg->vocab_size, "vqa_encoder_create: pad_id=%d", cfg->pad_id);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+        vqa_set_error("vqa_encoder_create: no HIP device visible");
+        return VQA_ENODEV;
+    }
+    VQA_REQUIRE(device >= 0 && device < ndev, "vqa_encoder_create: device %d of %d", device, ndev);
+    DevGuard guard(device);
+    vqa_encoder* e = new (std::nothrow) vqa_encoder();
+    if (!e) {
+        vqa_set_error("vqa_encoder_create: host allocation failed");
+        return VQA_ENOMEM;
+    }
+    e->device = device;
+    e->cfg = *cfg;
+    e->max_tokens = max_tokens;
+    const size_t H = cfg->hidden, F = cfg->ffn;
+    int rc = VQA_OK;
+    do {
+        if ((rc = upload_f32(e, w->word_emb, (size_t)cfg->vocab_size * H, &e->word)) != VQA_OK) break;
+        if ((rc = upload_f32(e, w->pos_emb, (size_t)cfg->max_pos * H, &e->pos)) != VQA_OK) break;
+        if ((rc = upload_f32(e, w->type_emb, H, &e->type0)) != VQA_OK) break;
+        if ((rc = upload_f32(e, w->emb_ln_g, H, &e->emb_g)) != VQA_OK) break;
+        if ((rc = upload_f32(e, w->emb_ln_b, H, &e->emb_b)) != VQA_OK) break;
+        e->layers.resize(cfg->layers);
+        for (int i = 0; i < cfg->layers && rc == VQA_OK; ++i) {
+            const vqa_encoder_layer_weights& lw = w->layer[i];
+            vqa_encoder::Layer& L = e->layers[i];
+            if ((rc = dev_alloc(e, (void**)&L.wqkv, 3 * H * H * 2)) != VQA_OK) break;
+            if ((rc = upload_f16(e, lw.wq, H * H, L.wqkv)) != VQA_OK) break;
+            if ((rc = upload_f16(e, lw.wk, H * H, L.wqkv + H * H)) != VQA_OK) break;
+            if ((rc = upload_f16(e, lw.wv, H * H, L.wqkv + 2 * H * H)) != VQA_OK) break;
+            if ((rc = dev_alloc(e, (void**)&L.bqkv, 3 * H * 4)) != VQA_OK) break;
+            VQA_REQUIRE(lw.bq && lw.bk && lw.bv, "vqa_encoder_create: a bias pointer of layer %d is null", i);
+            if (hipMemcpy(L.bqkv, lw.bq, H * 4, hipMemcpyDefault) != hipSuccess ||
+                hipMemcpy(L.bqkv + H, lw.bk, H * 4, hipMemcpyDefault) != hipSuccess ||
+                hipMemcpy(L.bqkv + 2 * H, lw.bv, H * 4, hipMemcpyDefault) != hipSuccess) {
+                vqa_set_error("vqa_encoder_create: copying qkv biases of layer %d failed", i);
+                rc = VQA_EHIP;
+                break;
+            }
+            if ((rc = dev_alloc(e, (void**)&L.wo, H * H * 2)) != VQA_OK) break;
+            if ((rc = upload_f16(e, lw.wo, H * H, L.wo)) != VQA_OK) break;
+            if ((rc = dev_alloc(e, (void**)&L.w1, F * H * 2)) != VQA_OK) break;
+            if ((rc = upload_f16(e, lw.w1, F * H, L.w1)) != VQA_OK) break;
+            if ((rc = dev_alloc(e, (void**)&L.w2, H * F * 2)) != VQA_OK) break;
+            if ((rc = upload_f16(e, lw.w2, H * F, L.w2)) != VQA_OK) break;
+            if ((rc = upload_f32(e, lw.bo, H, &L.bo)) != VQA_OK) break;
+            if ((rc = upload_f32(e, lw.b1, F, &L.b1)) != VQA_OK) break;
+            if ((rc = upload_f32(e, lw.b2, H, &L.b2)) != VQA_OK) break;
+            if ((rc = upload_f32(e, lw.ln1_g, H, &L.ln1_g)) != VQA_OK) break;
+            if ((rc = upload_f32(e, lw.ln1_b, H, &L.ln1_b)) != VQA_OK) break;
+            if ((rc = upload_f32(e, lw.ln2_g, H, &L.ln2_g)) != VQA_OK) break;
+            if ((rc = upload_f32(e, lw.ln2_b, H, &L.ln2_b)) != VQA_OK) break;
+        }
+        if (rc != VQA_OK) break;
+        const size_t T = max_tokens;
+        if ((rc = dev_alloc(e, (void**)&e->x, T * H * 2)) != VQA_OK) break;
+        if ((rc = dev_alloc(e, (void**)&e->qkv, T * 3 * H * 2)) != VQA_OK) break;
+        if ((rc = dev_alloc(e, (void**)&e->ctx, T * H * 2)) != VQA_OK) break;
+        if ((rc = dev_alloc(e, (void**)&e->tmp, T * H * 2)) != VQA_OK) break;
+        if ((rc = dev_alloc(e, (void**)&e->ffn, T * F * 2)) != VQA_OK) break;
+    } while (0);
+    if (rc != VQA_OK) {
+        vqa_encoder_destroy(e);
+        return rc;
+    }
+    *out = e;
+    return VQA_OK;
+}
+
+extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L,
+                                   int32_t pooling, int32_t normalize, float* out, void* hip_stream) {
+    VQA_REQUIRE(e, "vqa_encoder_forward: encoder is null");
+    VQA_REQUIRE(input_ids && attn_mask && out, "vqa_encoder_forward: null pointer");
+    VQA_REQUIRE(B >= 1 && L >= 1, "vqa_encoder_forward: B=%d L=%d", B, L);
+    VQA_REQUIRE((long long)B * L <= e->max_tokens, "vqa_encoder_forward: B*L=%lld exceeds the workspace of %d tokens",
+                (long long)B * L, e->max_tokens);
+    VQA_REQUIRE(L + e->cfg.pad_id + 1 <= e->cfg.max_pos, "vqa_encoder_forward: L=%d needs position %d, the table has %d rows", L,
+                L + e->cfg.pad_id, e->cfg.max_pos);
+    VQA_REQUIRE(pooling == VQA_POOL_CLS || pooling == VQA_POOL_MEAN, "vqa_encoder_forward: pooling %d", pooling);
+    hipStream_t s = (hipStream_t)hip_stream;
+    DevGuard guard(e->device);
+    const int T = B * L, H = e->cfg.hidden, F = e->cfg.ffn, heads = e->cfg.heads, dh = H / heads;
+    const float eps = e->cfg.ln_eps;
+    const int row_blocks = (T + 3) / 4;
+    hipLaunchKernelGGL(embed_ln_kernel, dim3(row_blocks), dim3(256), 0, s, input_ids, T, L, H, e->cfg.pad_id, e->word, e->pos,
+                       e->type0, e->emb_g, e->emb_b, eps, e->x);
+    VQA_HIP_CHECK(hipGetLastError());
+    const size_t attn_lds = ((size_t)2 * L * (dh + 1) + 4 * L + 4 * dh) * sizeof(float);
+    VQA_REQUIRE(attn_lds <= 160 * 1024, "vqa_encoder_forward: L=%d with head size %d needs %zu bytes of LDS", L, dh, attn_lds);
+    if (attn_lds > 64 * 1024)
+        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds));
+    for (const vqa_encoder::Layer& Ly : e->layers) {
+        int rc = launch_gemm<0>(e->x, Ly.wqkv, Ly.bqkv, e->qkv, T, 3 * H, H, s);
+        if (rc != VQA_OK) return rc;
+        hipLaunchKernelGGL(attention_kernel, dim3(B * heads), dim3(256), attn_lds, s, e->qkv, attn_mask, L, H, heads, e->ctx);
+        VQA_HIP_CHECK(hipGetLastError());
+        if ((rc = launch_gemm<0>(e->ctx, Ly.wo, Ly.bo, e->tmp, T, H, H, s)) != VQA_OK) return rc;
+        hipLaunchKernelGGL(add_ln_kernel, dim3(row_blocks), dim3(256), 0, s, e->tmp, e->x, T, H, Ly.ln1_g, Ly.ln1_b, eps, e->x);
+        VQA_HIP_CHECK(hipGetLastError());
+        if ((rc = launch_gemm<1>(e->x, Ly.w1, Ly.b1, e->ffn, T, F, H, s)) != VQA_OK) return rc;
+        if ((rc = launch_gemm<0>(e->ffn, Ly.w2, Ly.b2, e->tmp, T, H, F, s)) != VQA_OK) return rc;
+        hipLaunchKernelGGL(add_ln_kernel, dim3(row_blocks), dim3(256), 0, s, e->tmp, e->x, T, H, Ly.ln2_g, Ly.ln2_b, eps, e->x);
+        VQA_HIP_CHECK(hipGetLastError());
+    }
+    hipLaunchKernelGGL(pool_normalize_kernel, dim3((B + 3) / 4), dim3(256), 0, s, e->x, attn_mask, B, L, H, pooling, normalize, out);
+    VQA_HIP_CHECK(hipGetLastError());
+    return VQA_OK;
 }

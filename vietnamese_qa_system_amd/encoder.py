@@ -1,0 +1,146 @@
+"""Host side of the question encoder: weight hand-off to ``vqa_encoder_create`` and the text-encoder hook of
+:class:`~vietnamese_qa_system_amd.embeddings.Embeddings`.
+
+Counterpart of the transformer forward txtai runs per query (reference: model chosen by ``path=`` at
+``inference_pipeline/db_utils/heavy_ranker.py:80,83``; DPR form ``q_model(input_ids).pooler_output`` at
+``src/test.py:84-86``).  Weights use HF ``RobertaModel`` state-dict names (no ``roberta.`` prefix), fp32; tokenisation
+stays on the host and is pluggable (PhoBERT needs word segmentation + BPE files that are not available offline).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+POOLING = {"cls": N.VQA_POOL_CLS, "mean": N.VQA_POOL_MEAN}
+
+PHOBERT_BASE = dict(vocab_size=64001, hidden=768, layers=12, heads=12, ffn=3072, max_pos=258, type_vocab=1, pad_id=1,
+                    ln_eps=1e-5)
+
+_LAYER_FIELDS = (
+    ("wq", "attention.self.query.weight"), ("bq", "attention.self.query.bias"),
+    ("wk", "attention.self.key.weight"), ("bk", "attention.self.key.bias"),
+    ("wv", "attention.self.value.weight"), ("bv", "attention.self.value.bias"),
+    ("wo", "attention.output.dense.weight"), ("bo", "attention.output.dense.bias"),
+    ("ln1_g", "attention.output.LayerNorm.weight"), ("ln1_b", "attention.output.LayerNorm.bias"),
+    ("w1", "intermediate.dense.weight"), ("b1", "intermediate.dense.bias"),
+    ("w2", "output.dense.weight"), ("b2", "output.dense.bias"),
+    ("ln2_g", "output.LayerNorm.weight"), ("ln2_b", "output.LayerNorm.bias"),
+)
+_TOP_FIELDS = (("word_emb", "embeddings.word_embeddings.weight"), ("pos_emb", "embeddings.position_embeddings.weight"),
+               ("type_emb", "embeddings.token_type_embeddings.weight"), ("emb_ln_g", "embeddings.LayerNorm.weight"),
+               ("emb_ln_b", "embeddings.LayerNorm.bias"))
+
+
+class QuestionEncoder:
+    """RoBERTa / PhoBERT-base-shaped encoder resident on one MI355X.
+
+    ``weights``: mapping HF state-dict name -> float32 array (numpy or torch, host or device).  ``config`` keys:
+    vocab_size, hidden, layers, heads, ffn, max_pos, type_vocab, pad_id, ln_eps.  ``max_tokens`` bounds B * L of one call.
+    """
+
+    def __init__(self, weights: Dict[str, object], config: dict, *, device: int = 0, max_tokens: int = 256 * 64):
+        if not torch.cuda.is_available():
+            raise RuntimeError("QuestionEncoder needs an MI355X (gfx950); there is no CPU fallback")
+        self._lib = N.load()
+        self._handle = ctypes.c_void_p()
+        self.device = int(device)
+        self.config = dict(config)
+        self.max_tokens = int(max_tokens)
+        keep = []  # host copies kept alive until vqa_encoder_create returns
+
+        def ptr(name: str, shape: Tuple[int, ...]) -> int:
+            if name not in weights:
+                raise KeyError(f"missing weight {name!r}")
+            w = weights[name]
+            if isinstance(w, torch.Tensor):
+                w = w.detach().to(torch.float32).contiguous()
+                if tuple(w.shape) != shape:
+                    raise ValueError(f"{name}: shape {tuple(w.shape)}, expected {shape}")
+                keep.append(w)
+                return w.data_ptr()
+            a = np.ascontiguousarray(w, dtype=np.float32)
+            if a.shape != shape:
+                raise ValueError(f"{name}: shape {a.shape}, expected {shape}")
+            keep.append(a)
+            return a.ctypes.data
+
+        c = self.config
+        h, f = int(c["hidden"]), int(c["ffn"])
+        cfg = N.EncoderConfig(int(c["vocab_size"]), h, int(c["layers"]), int(c["heads"]), f, int(c["max_pos"]),
+                              int(c["type_vocab"]), int(c["pad_id"]), float(c["ln_eps"]))
+        shapes = {"word_emb": (c["vocab_size"], h), "pos_emb": (c["max_pos"], h), "type_emb": (c["type_vocab"], h),
+                  "emb_ln_g": (h,), "emb_ln_b": (h,)}
+        lshapes = {"wq": (h, h), "wk": (h, h), "wv": (h, h), "wo": (h, h), "w1": (f, h), "w2": (h, f), "bq": (h,), "bk": (h,),
+                   "bv": (h,), "bo": (h,), "b1": (f,), "b2": (h,), "ln1_g": (h,), "ln1_b": (h,), "ln2_g": (h,), "ln2_b": (h,)}
+        layers = (N.EncoderLayerWeights * int(c["layers"]))()
+        for i in range(int(c["layers"])):
+            for field, name in _LAYER_FIELDS:
+                setattr(layers[i], field, ptr(f"encoder.layer.{i}.{name}", lshapes[field]))
+        top = N.EncoderWeights()
+        for field, name in _TOP_FIELDS:
+            setattr(top, field, ptr(name, shapes[field]))
+        top.layer = ctypes.cast(layers, ctypes.POINTER(N.EncoderLayerWeights))
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize()
+            N.check(self._lib.vqa_encoder_create(ctypes.byref(self._handle), self.device, ctypes.byref(cfg), ctypes.byref(top),
+                                                 self.max_tokens), "vqa_encoder_create")
+        del keep
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            self._lib.vqa_encoder_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward(self, input_ids, attention_mask, *, pooling: str = "cls", normalize: bool = True) -> torch.Tensor:
+        """``input_ids`` / ``attention_mask`` [B, L] integers -> [B, hidden] fp32 cuda tensor (pooled, L2-normalised)."""
+        if not self._handle.value:
+            raise RuntimeError("encoder is closed")
+        if pooling not in POOLING:
+            raise ValueError(f"pooling must be one of {sorted(POOLING)}")
+        dev = torch.device("cuda", self.device)
+        ids = torch.as_tensor(np.asarray(input_ids) if not isinstance(input_ids, torch.Tensor) else input_ids)
+        mask = torch.as_tensor(np.asarray(attention_mask) if not isinstance(attention_mask, torch.Tensor) else attention_mask)
+        if ids.dim() != 2 or mask.shape != ids.shape:
+            raise ValueError("input_ids and attention_mask must both be [B, L]")
+        ids = ids.to(dev, dtype=torch.int32).contiguous()
+        mask = mask.to(dev, dtype=torch.int32).contiguous()
+        b, l = int(ids.shape[0]), int(ids.shape[1])
+        with torch.cuda.device(dev):
+            out = torch.empty((b, int(self.config["hidden"])), dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            N.check(self._lib.vqa_encoder_forward(self._handle, ids.data_ptr(), mask.data_ptr(), b, l, POOLING[pooling],
+                                                  int(bool(normalize)), out.data_ptr(), stream), "vqa_encoder_forward")
+        return out
+
+    __call__ = forward
+
+
+class TextEncoder:
+    """``list[str] -> [B, hidden]`` hook for ``Embeddings(encoder=...)``: a host tokenizer + the HIP encoder.
+
+    ``tokenizer(texts) -> (input_ids [B, L], attention_mask [B, L])`` (lists, numpy or torch); any HF tokenizer wrapped
+    as ``lambda t: (lambda e: (e["input_ids"], e["attention_mask"]))(tok(t, padding=True, truncation=True,
+    max_length=128, return_tensors="np"))`` fits."""
+
+    def __init__(self, tokenizer: Callable[[List[str]], Tuple[Sequence, Sequence]], encoder: QuestionEncoder, *,
+                 pooling: str = "mean", normalize: bool = True, batch_size: int = 256):
+        self.tokenizer, self.encoder = tokenizer, encoder
+        self.pooling, self.normalize, self.batch_size = pooling, normalize, batch_size
+
+    def __call__(self, texts: List[str]) -> torch.Tensor:
+        outs = []
+        for c0 in range(0, len(texts), self.batch_size):
+            ids, mask = self.tokenizer(list(texts[c0:c0 + self.batch_size]))
+            outs.append(self.encoder.forward(ids, mask, pooling=self.pooling, normalize=self.normalize))
+        return torch.cat(outs) if len(outs) != 1 else outs[0]
