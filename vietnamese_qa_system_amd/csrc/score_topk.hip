@@ -299,11 +299,15 @@ __global__ __launch_bounds__(kThreads) void score_topk_f16_kernel(const _Float16
 #else
 #define VQA_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, ACC, 0, 0, 0)
 #endif
-#define VQA_MMA(A, B)                                                           \
+#define VQA_MMA_RANGE(A, B, M0, M1)                                             \
     do {                                                                        \
-        _Pragma("unroll") for (int mi_ = 0; mi_ < 8; ++mi_)                     \
+        _Pragma("unroll") for (int mi_ = (M0); mi_ < (M1); ++mi_)               \
             _Pragma("unroll") for (int ni_ = 0; ni_ < 4; ++ni_) VQA_MFMA(acc[mi_][ni_], A[mi_], B[ni_]); \
     } while (0)
+#define VQA_MMA(A, B) VQA_MMA_RANGE(A, B, 0, 8)
+#ifndef VQA_SPLIT
+#define VQA_SPLIT 4  // matrix-first group: row groups multiplied before its memory instructions are issued (of 8)
+#endif
 #if VQA_ABLATE & 1
 #define VQA_ISSUE() (void)0
 #elif VQA_ABLATE & 32
@@ -325,10 +329,12 @@ __global__ __launch_bounds__(kThreads) void score_topk_f16_kernel(const _Float16
 #define VQA_KSTEP(CA, CB, NA, NB, KAPPA, PREFETCH)                 \
     do {                                                           \
         if (!kMemFirst) {                                          \
-            VQA_MMA(CA, CB);                                       \
+            VQA_MMA_RANGE(CA, CB, 0, VQA_SPLIT);                   \
             VQA_SB();                                              \
             if (PREFETCH) VQA_READ_FRAGS(NA, NB);                  \
             VQA_ISSUE();                                           \
+            VQA_SB();                                              \
+            VQA_MMA_RANGE(CA, CB, VQA_SPLIT, 8);                   \
         } else {                                                   \
             if (PREFETCH) VQA_READ_FRAGS(NA, NB);                  \
             VQA_ISSUE();                                           \
@@ -429,8 +435,10 @@ __global__ __launch_bounds__(kThreads) void score_topk_f16_kernel(const _Float16
             const float th = L.thr[wn * 64 + ni * 16 + c];
             float m = -INFINITY;
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
-                m = fmaxf(m, fmaxf(fmaxf(acc[mi][ni][0], acc[mi][ni][1]), fmaxf(acc[mi][ni][2], acc[mi][ni][3])));
+            for (int mi = 0; mi < 8; ++mi) {  // two v_max3_f32 per accumulator vector
+                m = fmaxf(fmaxf(m, acc[mi][ni][0]), acc[mi][ni][1]);
+                m = fmaxf(fmaxf(m, acc[mi][ni][2]), acc[mi][ni][3]);
+            }
             uint32_t bits = 0;
             if (m >= th) {
 #pragma unroll
@@ -452,18 +460,20 @@ __global__ __launch_bounds__(kThreads) void score_topk_f16_kernel(const _Float16
         if (any && process_pending(L, acc, pend, wm, wn, c, g, row0)) atomicOr(&L.cnt[0], kOverBit);
         __syncthreads();
         for (;;) {
-            const int over = L.cnt[0] & kOverBit;
+            const int over = L.cnt[0] & kOverBit;  // stable here: set before the barrier above, cleared only behind the next
             // normal tiles: compact lists that are nearly full; after a refusal: compact everything above k
             compact_pass(L, wave, lane, k, over ? k + 1 : k + (kCap - k + 1) / 2, kCap + kExt);
-            __syncthreads();
+            // Fast path: no trailing barrier.  What compaction wrote (thr, cnt, cand) is next read in the next tile's
+            // epilogue, 24+ barriers away; the spill stage L.ext is refilled only behind the next tile's first barrier,
+            // which no wave passes before every wave has finished compacting.
             if (!over) break;
+            __syncthreads();
             if (tid == 0) L.cnt[0] &= ~kOverBit;
             __syncthreads();
             if (process_pending(L, acc, pend, wm, wn, c, g, row0)) atomicOr(&L.cnt[0], kOverBit);
             __syncthreads();
         }
     }
-
     };
     if (wm) tile_loop(std::false_type{});
     else tile_loop(std::true_type{});
