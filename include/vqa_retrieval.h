@@ -41,7 +41,7 @@ extern "C" {
 #define VQA_INDEX_HAS_IDS 1 /* reserve the id vector even though ids_or_null is NULL (filled later by vqa_index_set_rows) */
 
 /* limits of the fused scoring + top-k kernel */
-#define VQA_MAX_K 16       /* top-k per query handled in LDS candidate lists (BASELINE k = 10; reference k = 1) */
+#define VQA_MAX_K 12       /* top-k per query handled in LDS candidate lists (BASELINE k = 10; reference k = 1) */
 #define VQA_QUERY_TILE 256 /* queries scored per pass over the index (BASELINE batch = 256) */
 
 typedef struct vqa_index vqa_index;     /* opaque: one row shard of the corpus on one device */
@@ -51,11 +51,13 @@ int vqa_version(void);
 const char* vqa_last_error(void);
 
 /* ---- index: replaces txtai's ANN backend (faiss IndexFlatIP + IDMap) behind Embeddings.index/load -----------
- * heavy_ranker.py:86-94.  The index keeps its rows in HBM in a TILED fp16 layout (tiles of 256 rows x K-blocks of 32
- * elements, each a contiguous 16 KiB block in the exact bank-conflict-free LDS image of the scoring kernel), so a
- * search streams the shard as one sequential read.  vqa_index_create allocates a shard of n rows of length d and,
+ * heavy_ranker.py:86-94.  The index keeps its rows in HBM in a TILED layout (tiles of 256 rows x K-blocks of 64 bytes per
+ * row, each a contiguous 16 KiB block in the exact bank-conflict-free LDS image of the scoring kernel), so a search
+ * streams the shard as one sequential read.  Storage type `dtype`: VQA_F16 (fp16 MFMA), VQA_F32 (exact fp32 MFMA) or
+ * VQA_FP8_E4M3 (OCP e4m3 MFMA; rows AND queries are stored as e4m3(16 * x) so that unit-vector components leave the
+ * subnormal range, and returned scores are divided by 256 -- both factors are powers of two, hence exact).  vqa_index_create allocates a shard of n rows of length d and,
  * when `rows` is not NULL, fills it: rows [n, d] row-major, host or device pointer, element type rows_dtype
- * (VQA_F32 or VQA_F16; converted to the storage type with round-to-nearest-even), expected L2-normalised by the
+ * (VQA_F32 or VQA_F16; converted to the storage type with round-to-nearest-even, saturating for fp8), expected L2-normalised by the
  * caller (txtai normalises at index time).  ids: [n] int64 external ids (host or device) or NULL, in which case
  * id = id_base + row position (sqlite AUTOINCREMENT rowids start at 1, setup_db.py:14).
  * vqa_index_set_rows (faiss `add_with_ids` counterpart) fills rows [first, first + count) later, chunk by chunk, so
@@ -64,17 +66,18 @@ int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t d, int32_t 
                      const int64_t* ids_or_null, int64_t id_base, uint32_t flags);
 int vqa_index_set_rows(vqa_index* index, int64_t first, int64_t count, const void* rows, int32_t rows_dtype,
                        const int64_t* ids_or_null);
-/* export (Embeddings.save, heavy_ranker.py:87): rows [first, first + count) back as row-major fp16 [count, d] (host or
- * device pointer) and, optionally, their ids; synchronises before returning. */
-int vqa_index_get_rows(vqa_index* index, int64_t first, int64_t count, void* out_rows_f16, int64_t* out_ids_or_null);
+/* export (Embeddings.save, heavy_ranker.py:87): rows [first, first + count) back as row-major [count, d] in the STORAGE
+ * type (fp16 / fp32 values, or e4m3 codes of 16 * x) into a host or device buffer and, optionally, their ids;
+ * synchronises before returning. */
+int vqa_index_get_rows(vqa_index* index, int64_t first, int64_t count, void* out_rows, int64_t* out_ids_or_null);
 void vqa_index_destroy(vqa_index* index);
 int64_t vqa_index_size(const vqa_index* index);
 int32_t vqa_index_dim(const vqa_index* index);
 int32_t vqa_index_dtype(const vqa_index* index);
 
 /* ---- search: replaces the scoring + top-k inside Embeddings.search / batchsearch (heavy_ranker.py:98,100) ---
- * q: [B, d] DEVICE pointer, element type q_dtype (VQA_F32 or VQA_F16; converted to the index element type with
- * round-to-nearest-even inside the call).  Scores are fp32 inner products accumulated in fp32.
+ * q: [B, d] DEVICE pointer, element type q_dtype (VQA_F32 or VQA_F16; converted to the index storage type with
+ * round-to-nearest-even inside the call).  Scores are fp32 inner products of the stored values accumulated in fp32.
  * out_scores [B, k] float and out_ids [B, k] int64 (device): best first; ties by row position ascending; when
  * the shard holds fewer than k rows the tail is padded with (-inf, -1).  out_pos_or_null [B, k] int64 receives
  * the row positions inside this shard (or NULL).  1 <= k <= VQA_MAX_K; any B >= 1 (processed in tiles of

@@ -19,7 +19,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 OBJ_DIR = os.path.join(HERE, "lib", "obj")
 LIB_PATH = os.path.join(LIB_DIR, "libvqa_retrieval.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-function"]
+FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++20", "-I", INCLUDE, "-I", CSRC, "-Wall", "-Wno-unused-function"]
 
 
 def sources() -> list[str]:

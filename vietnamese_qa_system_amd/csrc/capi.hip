@@ -28,6 +28,8 @@ struct vqa_index {
     int device = 0;
     int64_t n = 0;
     int32_t d = 0, d_pad = 0, dtype = 0;
+    float scale = 1.0f;      // stored value = scale * given value (power of two; 16 for fp8 so unit-vector components leave
+                             // the e4m3 subnormal range); queries are scaled alike and scores are multiplied by 1/scale^2
     void* rows = nullptr;    // TILED layout: ceil(n/256) tiles x (d_pad/32) blocks of 16 KiB (convert.hip)
     size_t rows_bytes = 0;
     int64_t* ids = nullptr;  // [n] or null
@@ -89,7 +91,7 @@ extern "C" int vqa_index_set_rows(vqa_index* ix, int64_t first, int64_t count, c
     (void)hipGetLastError();  // an unregistered host pointer reports an error: not ours
     const int seb = src_dtype == VQA_F32 ? 4 : 2;
     if (on_device) {
-        int rc = vqa_launch_tile_rows(rows, src_dtype, first, count, count, ix->d, ix->d_pad, ix->rows, nullptr);
+        int rc = vqa_launch_tile_rows(rows, src_dtype, first, count, count, ix->d, ix->d_pad, ix->dtype, ix->scale, ix->rows, nullptr);
         if (rc != VQA_OK) return rc;
     } else {
         // host rows: stage through a device buffer, 64 Mi elements at a time
@@ -109,7 +111,8 @@ extern "C" int vqa_index_set_rows(vqa_index* ix, int64_t first, int64_t count, c
             const int64_t c = std::min(chunk_rows, count - c0);
             VQA_HIP_CHECK(hipMemcpy(ix->q_rows, reinterpret_cast<const char*>(rows) + (size_t)c0 * ix->d * seb,
                                     (size_t)c * ix->d * seb, hipMemcpyHostToDevice));
-            int rc = vqa_launch_tile_rows(ix->q_rows, src_dtype, first + c0, c, c, ix->d, ix->d_pad, ix->rows, nullptr);
+            int rc = vqa_launch_tile_rows(ix->q_rows, src_dtype, first + c0, c, c, ix->d, ix->d_pad, ix->dtype, ix->scale, ix->rows,
+                                          nullptr);
             if (rc != VQA_OK) return rc;
             VQA_HIP_CHECK(hipStreamSynchronize(nullptr));
         }
@@ -126,7 +129,6 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
     VQA_REQUIRE(n >= 0 && n < 0xFFFFFFFFll, "vqa_index_create: n=%lld outside [0, 2^32-1) rows per shard", (long long)n);
     VQA_REQUIRE(d >= 1 && d <= 65536, "vqa_index_create: d=%d", d);
     VQA_REQUIRE(dtype == VQA_F32 || dtype == VQA_F16 || dtype == VQA_FP8_E4M3, "vqa_index_create: dtype %d", dtype);
-    VQA_REQUIRE(dtype == VQA_F16, "vqa_index_create: only VQA_F16 storage is implemented in this build (dtype %d)", dtype);
     VQA_REQUIRE((flags & ~(uint32_t)VQA_INDEX_HAS_IDS) == 0, "vqa_index_create: unknown flags 0x%x", flags);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
@@ -149,8 +151,10 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
     ix->device = device;
     ix->n = n;
     ix->d = d;
-    ix->d_pad = (d + 63) / 64 * 64;
+    const int pad_to = 128 / elem_bytes(dtype);  // two K-steps of 64 bytes
+    ix->d_pad = (d + pad_to - 1) / pad_to * pad_to;
     ix->dtype = dtype;
+    ix->scale = dtype == VQA_FP8_E4M3 ? 16.0f : 1.0f;
     ix->id_base = id_base;
     ix->num_cu = prop.multiProcessorCount;
     ix->max_grid = ix->num_cu;
@@ -203,22 +207,23 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
     return VQA_OK;
 }
 
-extern "C" int vqa_index_get_rows(vqa_index* ix, int64_t first, int64_t count, void* out_rows_f16, int64_t* out_ids_or_null) {
+extern "C" int vqa_index_get_rows(vqa_index* ix, int64_t first, int64_t count, void* out_rows, int64_t* out_ids_or_null) {
     VQA_REQUIRE(ix, "vqa_index_get_rows: index is null");
     VQA_REQUIRE(first >= 0 && count >= 0 && first + count <= ix->n, "vqa_index_get_rows: rows [%lld, %lld) outside [0, %lld)",
                 (long long)first, (long long)(first + count), (long long)ix->n);
     if (count == 0) return VQA_OK;
-    VQA_REQUIRE(out_rows_f16, "vqa_index_get_rows: out is null");
+    VQA_REQUIRE(out_rows, "vqa_index_get_rows: out is null");
     DeviceGuard guard(ix->device);
     hipPointerAttribute_t attr;
-    const bool on_device = hipPointerGetAttributes(&attr, out_rows_f16) == hipSuccess && attr.type == hipMemoryTypeDevice;
+    const bool on_device = hipPointerGetAttributes(&attr, out_rows) == hipSuccess && attr.type == hipMemoryTypeDevice;
     (void)hipGetLastError();
     if (on_device) {
-        int rc = vqa_launch_untile_rows(ix->rows, first, count, ix->d, ix->d_pad, out_rows_f16, nullptr);
+        int rc = vqa_launch_untile_rows(ix->rows, first, count, ix->d, ix->d_pad, ix->dtype, out_rows, nullptr);
         if (rc != VQA_OK) return rc;
     } else {
         const int64_t chunk_rows = std::max<int64_t>(1, (64ll << 20) / ix->d);
-        const size_t need = (size_t)std::min(chunk_rows, count) * ix->d * 2;
+        const size_t eb = (size_t)elem_bytes(ix->dtype);
+        const size_t need = (size_t)std::min(chunk_rows, count) * ix->d * eb;
         if (ix->q_rows_bytes < need) {
             if (ix->q_rows) (void)hipFree(ix->q_rows);
             ix->q_rows = nullptr;
@@ -231,10 +236,10 @@ extern "C" int vqa_index_get_rows(vqa_index* ix, int64_t first, int64_t count, v
         }
         for (int64_t c0 = 0; c0 < count; c0 += chunk_rows) {
             const int64_t c = std::min(chunk_rows, count - c0);
-            int rc = vqa_launch_untile_rows(ix->rows, first + c0, c, ix->d, ix->d_pad, ix->q_rows, nullptr);
+            int rc = vqa_launch_untile_rows(ix->rows, first + c0, c, ix->d, ix->d_pad, ix->dtype, ix->q_rows, nullptr);
             if (rc != VQA_OK) return rc;
-            VQA_HIP_CHECK(hipMemcpy(reinterpret_cast<char*>(out_rows_f16) + (size_t)c0 * ix->d * 2, ix->q_rows,
-                                    (size_t)c * ix->d * 2, hipMemcpyDeviceToHost));
+            VQA_HIP_CHECK(hipMemcpy(reinterpret_cast<char*>(out_rows) + (size_t)c0 * ix->d * eb, ix->q_rows,
+                                    (size_t)c * ix->d * eb, hipMemcpyDeviceToHost));
         }
     }
     if (out_ids_or_null) {
@@ -336,12 +341,12 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
         if (ix->n == 0) {  // empty shard: every slot is padding
             // reuse the merge kernel on one all-empty partial list
             VQA_HIP_CHECK(hipMemsetAsync(ix->partial, 0, (size_t)VQA_QUERY_TILE * k * sizeof(vqa_key), stream));
-            int rc = vqa_launch_merge_partials(ix->partial, 1, k, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr, stream);
+            int rc = vqa_launch_merge_partials(ix->partial, 1, k, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr, 1.0f, stream);
             if (rc != VQA_OK) return rc;
             continue;
         }
         int rc = vqa_launch_tile_rows(reinterpret_cast<const char*>(q) + (size_t)q0 * ix->d * qeb, q_dtype, 0, VQA_QUERY_TILE, nq,
-                                      ix->d, ix->d_pad, ix->q_stage, stream);
+                                      ix->d, ix->d_pad, ix->dtype, ix->scale, ix->q_stage, stream);
         if (rc != VQA_OK) return rc;
         ScoreTopkArgs a;
         a.x = ix->rows;
@@ -360,7 +365,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             rc = vqa_launch_score_topk(ix->dtype, a, stream);
             if (rc != VQA_OK) return rc;
             rc = vqa_launch_merge_partials(ix->partial, p.grid0, vqa_score_topk_seeds_per_query(), nq, k, nullptr, 0, nullptr,
-                                           nullptr, nullptr, ix->thr0, stream);
+                                           nullptr, nullptr, ix->thr0, 1.0f, stream);
             if (rc != VQA_OK) return rc;
         }
         a.thr_init = p.grid0 > 0 ? ix->thr0 : nullptr;
@@ -373,7 +378,8 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
         rc = vqa_launch_score_topk(ix->dtype, a, stream);
         if (rc != VQA_OK) return rc;
         if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
-        rc = vqa_launch_merge_partials(ix->partial, p.grid1, k, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr, stream);
+        rc = vqa_launch_merge_partials(ix->partial, p.grid1, k, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr,
+                                       1.0f / (ix->scale * ix->scale), stream);
         if (rc != VQA_OK) return rc;
     }
     return VQA_OK;

@@ -1,6 +1,6 @@
 // Element-wise helpers around the index (HBM-bound, 16 B per lane where the shape allows), gfx950 only.
-//   * stage_queries : [nq, d] fp32|fp16 queries -> one zero padded 256-row tile in the index element type, TILED layout
-//   * tile_rows     : row-major [count, d] rows -> the TILED layout of the index (see vqa_common.h), zero padded
+//   * tile_rows / untile_rows : row-major [count, d] f32|f16 rows <-> the TILED layout of the index in its storage type
+//     (fp16 | fp8-e4m3 | fp32), zero padded; also stages the 256-query tile of a search
 //   * normalize_convert : fp32 rows -> L2-normalised (txtai normalises at index and at query time; cosine intent at
 //     /root/reference/src/test.py:104) -> fp32 | fp16 | fp8-e4m3 (OCP, saturating, round to nearest even)
 #include "vqa_common.h"
@@ -45,44 +45,62 @@ __device__ __forceinline__ uint8_t f32_to_e4m3(float f) {
     return (uint8_t)(sign | code);
 }
 
-// TILED layout (fp16): tile t (256 rows), K-step kappa (32 elements) is one contiguous 16 KiB block at unit index
-// (t * KT + kappa) * 1024 (unit = 16 B = 8 elements); inside the block the unit of (row r, 8-element slot s) sits at
-// r * 4 + (s ^ 3 * bit3(r)) -- exactly the bank-conflict-free LDS image K1 wants, so K1's LDS-DMA reads 1 KiB
-// contiguous per wave-instruction and a tile's K-steps stream from HBM as one sequential 256 * d_pad * 2 byte run.
+// TILED layout: tile t (256 rows), K-step kappa (64 bytes of every row = 32 fp16 / 64 fp8 / 16 fp32 elements) is one
+// contiguous 16 KiB block at unit index (t * KT + kappa) * 1024 (unit = 16 B); inside the block the unit of (row r,
+// 16-byte slot s) sits at r * 4 + (s ^ 3 * bit3(r)) -- exactly the bank-conflict-free LDS image K1 wants, so K1's LDS-DMA
+// reads 1 KiB contiguous per wave-instruction and a tile's K-steps stream from HBM as one sequential 256 * d_pad * esize
+// byte run.  Which k index lands in which byte of a unit is irrelevant as long as rows and queries agree (a dot product
+// is invariant under a common permutation of k), so elements are simply stored in their natural order.
 __device__ __forceinline__ size_t tiled_unit(long long row, int kappa, int slot, int KT) {
     const long long t = row >> 8;
     const int r = (int)(row & 255);
     return ((size_t)t * KT + kappa) * 1024 + (size_t)(r * 4 + (slot ^ (((r >> 3) & 1) * 3)));
 }
 
-typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+template <typename DST>
+__device__ __forceinline__ DST store_cast(float v);
+template <>
+__device__ __forceinline__ float store_cast<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ _Float16 store_cast<_Float16>(float v) { return (_Float16)v; }
+template <>
+__device__ __forceinline__ uint8_t store_cast<uint8_t>(float v) { return f32_to_e4m3(v); }
 
-// rows: [count, d] row-major, SRC element type; row i goes to index row first + i.  One thread per 16-byte output unit.
-template <typename SRC>
+// rows: [valid, d] row-major, SRC element type; row i goes to index row first + i; rows valid..count-1 become zeros.
+// One thread per 16-byte output unit (EPU = 16 / sizeof(DST) elements); values are multiplied by `scale` (a power of
+// two: 1 for fp16/fp32 storage, the fp8 range scale otherwise) before the round-to-nearest-even conversion.
+template <typename SRC, typename DST>
 __global__ void tile_rows_kernel(const SRC* __restrict__ rows, long long first, long long count, long long valid, int d,
-                                 int KT, _Float16* __restrict__ out) {
+                                 int KT, float scale, DST* __restrict__ out) {
+    constexpr int EPU = 16 / (int)sizeof(DST);
     const int units_per_row = KT * 4;
     const long long total = count * units_per_row;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long ri = i / units_per_row;
         const int u = (int)(i - ri * units_per_row);
         const int kappa = u >> 2, slot = u & 3;
-        const int j0 = u * 8;
-        half8_t v;
+        const int j0 = u * EPU;
+        DST v[EPU];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (ri < valid && j0 + e < d) ? (_Float16)rows[ri * d + j0 + e] : (_Float16)0;
-        *reinterpret_cast<half8_t*>(out + tiled_unit(first + ri, kappa, slot, KT) * 8) = v;
+        for (int e = 0; e < EPU; ++e)
+            v[e] = store_cast<DST>((ri < valid && j0 + e < d) ? (float)rows[ri * d + j0 + e] * scale : 0.0f);
+        DST* dst = out + tiled_unit(first + ri, kappa, slot, KT) * EPU;
+#pragma unroll
+        for (int e = 0; e < EPU; ++e) dst[e] = v[e];
     }
 }
 
-// inverse of tile_rows: TILED fp16 -> row-major [count, d] fp16 (index export for Embeddings.save)
-__global__ void untile_rows_kernel(const _Float16* __restrict__ tiled, long long first, long long count, int d, int KT,
-                                   _Float16* __restrict__ out) {
+// inverse of tile_rows: TILED -> row-major [count, d] in the storage type (index export for Embeddings.save)
+template <typename DST>
+__global__ void untile_rows_kernel(const DST* __restrict__ tiled, long long first, long long count, int d, int KT,
+                                   DST* __restrict__ out) {
+    constexpr int EPU = 16 / (int)sizeof(DST);
     const long long total = count * d;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const long long ri = i / d;
         const int j = (int)(i - ri * d);
-        out[i] = tiled[tiled_unit(first + ri, j >> 5, (j >> 3) & 3, KT) * 8 + (j & 7)];
+        const int u = j / EPU;
+        out[i] = tiled[tiled_unit(first + ri, u >> 2, u & 3, KT) * EPU + (j - u * EPU)];
     }
 }
 
@@ -115,34 +133,56 @@ __global__ __launch_bounds__(256) void normalize_convert_kernel(const float* __r
 
 }  // namespace
 
-int vqa_launch_tile_rows(const void* rows, int32_t src_dtype, int64_t first, int64_t count, int64_t valid, int32_t d,
-                         int32_t d_pad, void* out, hipStream_t stream) {
-    VQA_REQUIRE(src_dtype == VQA_F32 || src_dtype == VQA_F16, "tile_rows: source element type %d is not f32/f16", src_dtype);
-    if (count == 0) return VQA_OK;
-    const int KT = d_pad / 32;
+template <typename SRC>
+static int launch_tile_rows_src(const SRC* rows, int64_t first, int64_t count, int64_t valid, int32_t d, int32_t d_pad,
+                                int32_t dtype, float scale, void* out, hipStream_t stream) {
+    const int esize = dtype == VQA_F32 ? 4 : dtype == VQA_F16 ? 2 : 1;
+    const int KT = d_pad * esize / 64;
     const long long total = (long long)count * KT * 4;
     const int threads = 256;
     const int blocks = (int)((total + threads - 1) / threads < 65536 ? (total + threads - 1) / threads : 65536);
-    if (src_dtype == VQA_F32)
-        hipLaunchKernelGGL(tile_rows_kernel<float>, dim3(blocks), dim3(threads), 0, stream,
-                           reinterpret_cast<const float*>(rows), (long long)first, (long long)count, (long long)valid, d, KT,
-                           reinterpret_cast<_Float16*>(out));
+    if (dtype == VQA_F16)
+        hipLaunchKernelGGL((tile_rows_kernel<SRC, _Float16>), dim3(blocks), dim3(threads), 0, stream, rows, (long long)first,
+                           (long long)count, (long long)valid, d, KT, scale, reinterpret_cast<_Float16*>(out));
+    else if (dtype == VQA_F32)
+        hipLaunchKernelGGL((tile_rows_kernel<SRC, float>), dim3(blocks), dim3(threads), 0, stream, rows, (long long)first,
+                           (long long)count, (long long)valid, d, KT, scale, reinterpret_cast<float*>(out));
     else
-        hipLaunchKernelGGL(tile_rows_kernel<_Float16>, dim3(blocks), dim3(threads), 0, stream,
-                           reinterpret_cast<const _Float16*>(rows), (long long)first, (long long)count, (long long)valid, d, KT,
-                           reinterpret_cast<_Float16*>(out));
+        hipLaunchKernelGGL((tile_rows_kernel<SRC, uint8_t>), dim3(blocks), dim3(threads), 0, stream, rows, (long long)first,
+                           (long long)count, (long long)valid, d, KT, scale, reinterpret_cast<uint8_t*>(out));
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }
 
-int vqa_launch_untile_rows(const void* tiled, int64_t first, int64_t count, int32_t d, int32_t d_pad, void* out,
+int vqa_launch_tile_rows(const void* rows, int32_t src_dtype, int64_t first, int64_t count, int64_t valid, int32_t d,
+                         int32_t d_pad, int32_t dtype, float scale, void* out, hipStream_t stream) {
+    VQA_REQUIRE(src_dtype == VQA_F32 || src_dtype == VQA_F16, "tile_rows: source element type %d is not f32/f16", src_dtype);
+    if (count == 0) return VQA_OK;
+    if (src_dtype == VQA_F32)
+        return launch_tile_rows_src(reinterpret_cast<const float*>(rows), first, count, valid, d, d_pad, dtype, scale, out, stream);
+    return launch_tile_rows_src(reinterpret_cast<const _Float16*>(rows), first, count, valid, d, d_pad, dtype, scale, out, stream);
+}
+
+int vqa_launch_untile_rows(const void* tiled, int64_t first, int64_t count, int32_t d, int32_t d_pad, int32_t dtype, void* out,
                            hipStream_t stream) {
     if (count == 0) return VQA_OK;
+    const int esize = dtype == VQA_F32 ? 4 : dtype == VQA_F16 ? 2 : 1;
+    const int KT = d_pad * esize / 64;
     const long long total = (long long)count * d;
     const int threads = 256;
     const int blocks = (int)((total + threads - 1) / threads < 65536 ? (total + threads - 1) / threads : 65536);
-    hipLaunchKernelGGL(untile_rows_kernel, dim3(blocks), dim3(threads), 0, stream, reinterpret_cast<const _Float16*>(tiled),
-                       (long long)first, (long long)count, d, d_pad / 32, reinterpret_cast<_Float16*>(out));
+    if (dtype == VQA_F16)
+        hipLaunchKernelGGL(untile_rows_kernel<_Float16>, dim3(blocks), dim3(threads), 0, stream,
+                           reinterpret_cast<const _Float16*>(tiled), (long long)first, (long long)count, d, KT,
+                           reinterpret_cast<_Float16*>(out));
+    else if (dtype == VQA_F32)
+        hipLaunchKernelGGL(untile_rows_kernel<float>, dim3(blocks), dim3(threads), 0, stream,
+                           reinterpret_cast<const float*>(tiled), (long long)first, (long long)count, d, KT,
+                           reinterpret_cast<float*>(out));
+    else
+        hipLaunchKernelGGL(untile_rows_kernel<uint8_t>, dim3(blocks), dim3(threads), 0, stream,
+                           reinterpret_cast<const uint8_t*>(tiled), (long long)first, (long long)count, d, KT,
+                           reinterpret_cast<uint8_t*>(out));
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

@@ -23,6 +23,7 @@
 //                  each is the score of a distinct row); K2 turns their k-th largest into starting thresholds.
 //   MODE 1 "main": all tiles, thresholds seeded; flushes per-workgroup sorted top-k lists for K2 to merge.
 #include <type_traits>
+#include <utility>
 
 #include "vqa_common.h"
 
@@ -37,13 +38,68 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int frag_t __attribute__((ext_vector_type(4)));  // 16 bytes of one row: 8 fp16 | 16 fp8 | 4 fp32
+typedef long long i64x2 __attribute__((ext_vector_type(2)));
+
+// One K-step (64 bytes of every row) of one 16 x 16 accumulator tile.  Which k index sits in which byte is irrelevant as
+// long as rows and queries are read the same way, so a lane's 16-byte fragment feeds sub-step t of every MFMA chain:
+//   fp16: 1 x v_mfma_f32_16x16x32_f16 (8 halves);  fp8: 2 x v_mfma_f32_16x16x32_fp8_fp8 (8 bytes each);
+//   fp32: 4 x v_mfma_f32_16x16x4_f32 (1 float each).  T = sub-step.
+template <int DT>
+struct MfmaTraits;
+template <>
+struct MfmaTraits<VQA_F16> {
+    static constexpr int kSub = 1;
+    template <int T>
+    static __device__ __forceinline__ f32x4 mma(frag_t a, frag_t b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+    }
+};
+template <>
+struct MfmaTraits<VQA_FP8_E4M3> {
+    static constexpr int kSub = 2;
+    template <int T>
+    static __device__ __forceinline__ f32x4 mma(frag_t a, frag_t b, f32x4 c) {
+        const i64x2 a2 = __builtin_bit_cast(i64x2, a), b2 = __builtin_bit_cast(i64x2, b);
+        return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a2[T], b2[T], c, 0, 0, 0);
+    }
+};
+template <>
+struct MfmaTraits<VQA_F32> {
+    static constexpr int kSub = 4;
+    template <int T>
+    static __device__ __forceinline__ f32x4 mma(frag_t a, frag_t b, f32x4 c) {
+        // cast the whole fragment first: __builtin_bit_cast of a single vector ELEMENT (a[T]) reads element 0 for every T
+        const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(af[T], bf[T], c, 0, 0, 0);
+    }
+};
+
+// row groups [M0, M1) x all four query groups; sub-step outermost so consecutive MFMAs hit different accumulators
+// (v_mfma_f32_16x16x4_f32 has a 40-cycle dependent latency against a 32-cycle issue)
+template <int DT, int T, int M0, int M1>
+__device__ __forceinline__ void mma_sub(f32x4 (&acc)[8][4], const frag_t (&a)[8], const frag_t (&b)[4]) {
+#pragma unroll
+    for (int mi = M0; mi < M1; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = MfmaTraits<DT>::template mma<T>(a[mi], b[ni], acc[mi][ni]);
+}
+template <int DT, int M0, int M1>
+__device__ __forceinline__ void mma_block(f32x4 (&acc)[8][4], const frag_t (&a)[8], const frag_t (&b)[4]) {
+    mma_sub<DT, 0, M0, M1>(acc, a, b);
+    if constexpr (MfmaTraits<DT>::kSub > 1) mma_sub<DT, 1, M0, M1>(acc, a, b);
+    if constexpr (MfmaTraits<DT>::kSub > 2) {
+        mma_sub<DT, 2, M0, M1>(acc, a, b);
+        mma_sub<DT, 3, M0, M1>(acc, a, b);
+    }
+}
+
 typedef __attribute__((address_space(3))) char* lds_char_ptr;
 
 constexpr int kThreads = 512;           // 8 waves: 2 (row halves = ping-pong groups) x 4 (query quarters)
 constexpr int kTileRows = 256;          // corpus rows per tile
 constexpr int kQ = VQA_QUERY_TILE;      // 256 queries per tile
-constexpr int kBK = 32;                 // K-step in elements
-constexpr int kRowBytes = kBK * 2;      // 64 B of fp16 per row per K-step
+constexpr int kRowBytes = 64;           // bytes of every row per K-step (32 fp16 / 64 fp8 / 16 fp32 elements)
 constexpr int kOperandBytes = 256 * kRowBytes;  // 16 KiB: one operand slice (256 rows x one K-step)
 #ifndef VQA_RING_ALT
 constexpr int kSx = 6, kPx = 5;  // X ring: stages, K-steps issued ahead (HBM stream: deep); one stage idles per K-step
@@ -184,12 +240,11 @@ __device__ __forceinline__ void block_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(kThreads) void score_topk_f16_kernel(const _Float16* __restrict__ X,
-                                                                  const _Float16* __restrict__ Qs,
-                                                                  const float* __restrict__ thr_init,
-                                                                  vqa_key* __restrict__ out, long long N, int D, int nq,
-                                                                  int k, int tile_begin, int tile_end) {
+template <int MODE, int DT>
+__global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __restrict__ X, const void* __restrict__ Qs,
+                                                              const float* __restrict__ thr_init, vqa_key* __restrict__ out,
+                                                              long long N, int KT, int nq, int k, int tile_begin,
+                                                              int tile_end) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lists L;
     L.thr = reinterpret_cast<float*>(smem + kPipeBytes);
@@ -211,7 +266,6 @@ __global__ __launch_bounds__(kThreads) void score_topk_f16_kernel(const _Float16
         L.cnt[tid] = 0;
     }
 
-    const int KT = D / kBK;
     const int first_tile = tile_begin + blockIdx.x;
     const int ntile = first_tile < tile_end ? (tile_end - first_tile + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     const int total = ntile * KT;  // K-steps of this workgroup, numbered kappa = ti * KT + kt
@@ -276,8 +330,8 @@ __global__ __launch_bounds__(kThreads) void score_topk_f16_kernel(const _Float16
 #if VQA_ABLATE & 2
 #define VQA_READ_FRAGS(A, B)                                                                  \
     do {                                                                                      \
-        for (int i_ = 0; i_ < 8; ++i_) { A[i_] = half8{}; asm volatile("" : "+v"(A[i_])); }   \
-        for (int i_ = 0; i_ < 4; ++i_) { B[i_] = half8{}; asm volatile("" : "+v"(B[i_])); }   \
+        for (int i_ = 0; i_ < 8; ++i_) { A[i_] = frag_t{}; asm volatile("" : "+v"(A[i_])); }  \
+        for (int i_ = 0; i_ < 4; ++i_) { B[i_] = frag_t{}; asm volatile("" : "+v"(B[i_])); }  \
         if (++sx == kSx) sx = 0;                                                              \
         if (++sq == kSq) sq = 0;                                                              \
     } while (0)
@@ -287,23 +341,23 @@ __global__ __launch_bounds__(kThreads) void score_topk_f16_kernel(const _Float16
         const char* xbuf_ = smem + sx * kOperandBytes;                                                            \
         const char* qbuf_ = smem + sq * kOperandBytes;                                                            \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                          \
-            B[i_] = *reinterpret_cast<const half8*>(qbuf_ + b_base + i_ * 16 * kRowBytes);                        \
+            B[i_] = *reinterpret_cast<const frag_t*>(qbuf_ + b_base + i_ * 16 * kRowBytes);                       \
         _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                          \
-            A[i_] = *reinterpret_cast<const half8*>(xbuf_ + a_base + i_ * 16 * kRowBytes);                        \
+            A[i_] = *reinterpret_cast<const frag_t*>(xbuf_ + a_base + i_ * 16 * kRowBytes);                       \
         if (++sx == kSx) sx = 0;                                                                                  \
         if (++sq == kSq) sq = 0;                                                                                  \
     } while (0)
 #endif
 #if VQA_ABLATE & 4
-#define VQA_MFMA(ACC, A, B) asm volatile("" : "+v"(ACC) : "v"(A), "v"(B))
-#else
-#define VQA_MFMA(ACC, A, B) ACC = __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, ACC, 0, 0, 0)
-#endif
-#define VQA_MMA_RANGE(A, B, M0, M1)                                             \
-    do {                                                                        \
-        _Pragma("unroll") for (int mi_ = (M0); mi_ < (M1); ++mi_)               \
-            _Pragma("unroll") for (int ni_ = 0; ni_ < 4; ++ni_) VQA_MFMA(acc[mi_][ni_], A[mi_], B[ni_]); \
+#define VQA_MMA_RANGE(A, B, M0, M1)                                                                       \
+    do {                                                                                                  \
+        _Pragma("unroll") for (int mi_ = (M0); mi_ < (M1); ++mi_)                                         \
+            _Pragma("unroll") for (int ni_ = 0; ni_ < 4; ++ni_)                                           \
+                asm volatile("" : "+v"(acc[mi_][ni_]) : "v"(A[mi_]), "v"(B[ni_]));                        \
     } while (0)
+#else
+#define VQA_MMA_RANGE(A, B, M0, M1) mma_block<DT, (M0), (M1)>(acc, A, B)
+#endif
 #define VQA_MMA(A, B) VQA_MMA_RANGE(A, B, 0, 8)
 #ifndef VQA_SPLIT
 #define VQA_SPLIT 4  // matrix-first group: row groups multiplied before its memory instructions are issued (of 8)
@@ -371,14 +425,31 @@ __global__ __launch_bounds__(kThreads) void score_topk_f16_kernel(const _Float16
         // kappa + 1 may be refilled after the barrier), a counted vmcnt (this wave's pieces of kappa + 2 landed) and
         // the barrier.  Group 0 runs R, D, M and group 1 runs M, R, D, so on every SIMD one wave starts with the
         // matrix pipe while its partner starts with memory instructions.
-        half8 a0[8], b0[4], a1[8], b1[4];
+        frag_t a0[8], b0[4];
         VQA_READ_FRAGS(a0, b0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         block_barrier();  // every wave holds its first fragments before a piece of K-step + kS may overwrite the stage
-        for (int kt = 0; kt < KT; kt += 2) {  // KT is even (d_pad is a multiple of 64)
-            const int kappa = ti * KT + kt;
-            VQA_KSTEP(a0, b0, a1, b1, kappa, true);
-            VQA_KSTEP(a1, b1, a0, b0, kappa + 1, kt + 2 < KT);
+        if constexpr (DT == VQA_F16) {
+            frag_t a1[8], b1[4];  // second register set: the next K-step's fragments load under this K-step's MFMAs
+            for (int kt = 0; kt < KT; kt += 2) {  // KT is even (rows are padded to two K-steps)
+                const int kappa = ti * KT + kt;
+                VQA_KSTEP(a0, b0, a1, b1, kappa, true);
+                VQA_KSTEP(a1, b1, a0, b0, kappa + 1, kt + 2 < KT);
+            }
+        } else {
+            // fp8 / fp32: 2x / 4x the MFMAs per K-step and one register set (a second one spills): issue the DMA
+            // pieces, multiply, then refill the same registers; the reads' latency hides under the partner wave's MFMAs
+            for (int kt = 0; kt < KT; ++kt) {
+                const int kappa = ti * KT + kt;
+                VQA_ISSUE();
+                VQA_SB();
+                VQA_MMA(a0, b0);
+                VQA_SB();
+                if (kt + 1 < KT) VQA_READ_FRAGS(a0, b0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wait_pieces(kappa + 2);
+                VQA_LOOP_BARRIER();
+            }
         }
 
         // ---- epilogue; scores stay in registers ------------------------------------------------------------------
@@ -505,29 +576,38 @@ int vqa_score_topk_max_k(int dtype) {
 
 int vqa_score_topk_seeds_per_query() { return kSeedsPerQuery; }
 
-int vqa_launch_score_topk(int dtype, const ScoreTopkArgs& a, hipStream_t stream) {
-    VQA_REQUIRE(dtype == VQA_F16, "score_topk: only fp16 rows are implemented (dtype %d)", dtype);
-    VQA_REQUIRE(a.d_pad > 0 && a.d_pad % 64 == 0, "score_topk: padded row length %d is not a multiple of 64", a.d_pad);
-    VQA_REQUIRE(a.k >= 1 && a.k <= kMaxK, "score_topk: k=%d outside [1, %d]", a.k, kMaxK);
-    VQA_REQUIRE(a.nq >= 1 && a.nq <= kQ, "score_topk: nq=%d outside [1, %d]", a.nq, kQ);
-    VQA_REQUIRE(a.grid >= 1 && a.tile_end > a.tile_begin, "score_topk: empty launch");
-    VQA_REQUIRE(!a.seed_only || a.tile_end - a.tile_begin <= a.grid, "score_topk: the seed pass takes one tile per workgroup");
-    const int lds = vqa_score_topk_lds_bytes(dtype, a.k);
+template <int DT>
+static int launch_dt(const ScoreTopkArgs& a, int KT, int lds, hipStream_t stream) {
     static bool attr_set_dev[64] = {};
     int dev = 0;
     VQA_HIP_CHECK(hipGetDevice(&dev));
     bool& attr_set = attr_set_dev[dev & 63];
     if (!attr_set) {
-        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_f16_kernel<0>),
+        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<0, DT>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_f16_kernel<1>),
+        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<1, DT>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    auto kern = a.seed_only ? score_topk_f16_kernel<0> : score_topk_f16_kernel<1>;
-    hipLaunchKernelGGL(kern, dim3(a.grid), dim3(kThreads), lds, stream, reinterpret_cast<const _Float16*>(a.x),
-                       reinterpret_cast<const _Float16*>(a.q), a.thr_init, a.partial, (long long)a.n, a.d_pad, a.nq, a.k,
-                       a.tile_begin, a.tile_end);
+    auto kern = a.seed_only ? score_topk_kernel<0, DT> : score_topk_kernel<1, DT>;
+    hipLaunchKernelGGL(kern, dim3(a.grid), dim3(kThreads), lds, stream, a.x, a.q, a.thr_init, a.partial, (long long)a.n, KT, a.nq,
+                       a.k, a.tile_begin, a.tile_end);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
+}
+
+int vqa_launch_score_topk(int dtype, const ScoreTopkArgs& a, hipStream_t stream) {
+    VQA_REQUIRE(dtype == VQA_F16 || dtype == VQA_FP8_E4M3 || dtype == VQA_F32, "score_topk: storage type %d", dtype);
+    const int esize = dtype == VQA_F32 ? 4 : dtype == VQA_F16 ? 2 : 1;
+    VQA_REQUIRE(a.d_pad > 0 && (a.d_pad * esize) % (2 * kRowBytes) == 0,
+                "score_topk: padded row of %d elements x %d B is not a multiple of %d B", a.d_pad, esize, 2 * kRowBytes);
+    VQA_REQUIRE(a.k >= 1 && a.k <= kMaxK, "score_topk: k=%d outside [1, %d]", a.k, kMaxK);
+    VQA_REQUIRE(a.nq >= 1 && a.nq <= kQ, "score_topk: nq=%d outside [1, %d]", a.nq, kQ);
+    VQA_REQUIRE(a.grid >= 1 && a.tile_end > a.tile_begin, "score_topk: empty launch");
+    VQA_REQUIRE(!a.seed_only || a.tile_end - a.tile_begin <= a.grid, "score_topk: the seed pass takes one tile per workgroup");
+    const int lds = vqa_score_topk_lds_bytes(dtype, a.k);
+    const int KT = a.d_pad * esize / kRowBytes;  // even
+    if (dtype == VQA_F16) return launch_dt<VQA_F16>(a, KT, lds, stream);
+    if (dtype == VQA_FP8_E4M3) return launch_dt<VQA_FP8_E4M3>(a, KT, lds, stream);
+    return launch_dt<VQA_F32>(a, KT, lds, stream);
 }

@@ -69,12 +69,14 @@ int vqa_score_topk_seeds_per_query();
 // final [nq, k] (scores, external ids, positions) and/or the k-th best score per query (-inf when fewer exist)
 int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t list_len, int32_t nq, int32_t k,
                               const int64_t* ids, int64_t id_base, float* out_scores, int64_t* out_ids, int64_t* out_pos,
-                              float* out_thr, hipStream_t stream);
+                              float* out_thr, float score_scale /* applied to out_scores only (power of two) */,
+                              hipStream_t stream);
 
-// row-major [valid, d] f32|f16 rows (device) -> TILED fp16 layout of the index at rows [first, first + count);
-// rows valid..count-1 are written as zeros (query tile: first = 0, count = 256, valid = nq)
+// row-major [valid, d] f32|f16 rows (device) -> TILED layout, storage type `dtype`, at rows [first, first + count);
+// rows valid..count-1 are written as zeros (query tile: first = 0, count = 256, valid = nq); values are multiplied by
+// `scale` before conversion
 int vqa_launch_tile_rows(const void* rows, int32_t src_dtype, int64_t first, int64_t count, int64_t valid, int32_t d,
-                         int32_t d_pad, void* out, hipStream_t stream);
-// TILED fp16 rows [first, first + count) -> row-major [count, d] fp16 (device)
-int vqa_launch_untile_rows(const void* tiled, int64_t first, int64_t count, int32_t d, int32_t d_pad, void* out,
+                         int32_t d_pad, int32_t dtype, float scale, void* out, hipStream_t stream);
+// TILED rows [first, first + count) -> row-major [count, d] in the storage type (device)
+int vqa_launch_untile_rows(const void* tiled, int64_t first, int64_t count, int32_t d, int32_t d_pad, int32_t dtype, void* out,
                            hipStream_t stream);

@@ -32,7 +32,20 @@ from . import docstore
 from .index import DeviceIndex, resolve_dtype
 from .sharded import ShardedSearcher, shard_bounds
 
-META_FILE, VECTORS_FILE, IDS_FILE, DOCS_FILE = "meta.json", "vectors.f16", "ids.i64", "documents.db"
+META_FILE, IDS_FILE, DOCS_FILE = "meta.json", "ids.i64", "documents.db"
+VECTOR_FILES = {"float16": "vectors.f16", "float32": "vectors.f32"}
+
+
+def _e4m3_decode_table() -> np.ndarray:
+    """OCP e4m3fn code -> value (the 256 code points); used to export an fp8 index as exactly representable fp16."""
+    c = np.arange(256, dtype=np.int64)
+    e, m = (c >> 3) & 0xF, c & 7
+    v = np.where(e == 0, m / 8.0 * 2.0 ** -6, (1 + m / 8.0) * 2.0 ** (e.astype(np.float64) - 7))
+    v = np.where(c & 0x80, -v, v)
+    v[(c & 0x7F) == 0x7F] = np.nan
+    return v
+
+
 FORMAT_VERSION = 1
 
 Query = Union[str, np.ndarray, torch.Tensor, Sequence[float]]
@@ -218,7 +231,7 @@ class Embeddings:
 
     # ---- persistence -----------------------------------------------------------------------
     def save(self, path: str) -> None:
-        """``heavy_ranker.py:87``: ``<path>/meta.json`` + ``vectors.f16`` (row-major, mmap-able, shardable by byte range)
+        """``heavy_ranker.py:87``: ``<path>/meta.json`` + ``vectors.f16`` / ``vectors.f32`` (row-major, mmap-able, shardable by byte range)
         + ``ids.i64`` (+ ``documents.db`` with the reference's table schema when ``content=True``)."""
         if self._index is None:
             raise RuntimeError("nothing to save: the index is empty")
@@ -226,12 +239,19 @@ class Embeddings:
             raise NotImplementedError("save() from a sharded Embeddings: gather on one rank first")
         os.makedirs(path, exist_ok=True)
         rows, ids = self._index.get_rows()
-        rows.tofile(os.path.join(path, VECTORS_FILE))
+        if rows.dtype == np.uint8:
+            # fp8 index: codes of 16 * x -> x as fp16 (3 mantissa bits, exponents down to 2^-13: exact), so that
+            # load() re-encodes to the very same codes
+            from .index import FP8_SCALE
+            rows = (_e4m3_decode_table()[rows] / FP8_SCALE).astype(np.float16)
+        vec_dtype = "float32" if rows.dtype == np.float32 else "float16"
+        rows.tofile(os.path.join(path, VECTOR_FILES[vec_dtype]))
         if ids is not None:
             ids.tofile(os.path.join(path, IDS_FILE))
         meta = {"format": FORMAT_VERSION, "n": self.n, "d": self.d, "dtype": self.dtype, "normalize": self.normalize,
                 "pooling": self.pooling, "path": self.path, "content": self.content, "hybrid": self.hybrid,
-                "id_base": self._index.id_base, "has_ids": ids is not None, "host_ids": self._host_ids}
+                "id_base": self._index.id_base, "has_ids": ids is not None, "host_ids": self._host_ids,
+                "vector_dtype": vec_dtype}
         with open(os.path.join(path, META_FILE), "w") as f:
             json.dump(meta, f)
         if self.content and self._docs_mem is not None:
@@ -258,11 +278,13 @@ class Embeddings:
         self.path, self.content, self.hybrid = meta["path"], meta["content"], meta["hybrid"]
         self._host_ids = meta.get("host_ids")
         lo, hi = shard_bounds(n, self.world, self.rank)
-        vec_path = os.path.join(path, VECTORS_FILE)
-        expected = n * d * 2
+        vec_dtype = meta.get("vector_dtype", "float16")
+        np_dtype = np.dtype(vec_dtype)
+        vec_path = os.path.join(path, VECTOR_FILES[vec_dtype])
+        expected = n * d * np_dtype.itemsize
         if os.path.getsize(vec_path) != expected:
             raise ValueError(f"{vec_path}: {os.path.getsize(vec_path)} bytes, expected {expected}")
-        rows = np.memmap(vec_path, dtype=np.float16, mode="r", shape=(n, d)) if n else np.zeros((0, d), np.float16)
+        rows = np.memmap(vec_path, dtype=np_dtype, mode="r", shape=(n, d)) if n else np.zeros((0, d), np_dtype)
         ids = None
         if meta["has_ids"]:
             ids = np.fromfile(os.path.join(path, IDS_FILE), dtype=np.int64)[lo:hi]

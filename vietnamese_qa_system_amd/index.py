@@ -15,6 +15,8 @@ import torch
 from . import _native as N
 
 _SRC_DTYPE = {torch.float32: N.VQA_F32, torch.float16: N.VQA_F16}
+_STORE_NP = {N.VQA_F32: np.float32, N.VQA_F16: np.float16, N.VQA_FP8_E4M3: np.uint8}
+FP8_SCALE = 16.0  # an fp8 index stores e4m3(16 * x) (and scores 16 * q the same way); scores come back divided by 256
 
 
 def _require_gpu(device: int) -> None:
@@ -44,7 +46,8 @@ def _as_tensor(a, what: str) -> torch.Tensor:
 
 
 class DeviceIndex:
-    """One row shard of the corpus in HBM (tiled fp16 layout), searched by the fused MFMA scoring + top-k kernel.
+    """One row shard of the corpus in HBM (tiled layout; fp16, fp8-e4m3 or fp32 storage), searched by the fused MFMA
+    scoring + top-k kernel.
 
     ``DeviceIndex(vectors, ids)`` builds a shard from ``vectors`` [n, d] (torch tensor on any device or numpy array,
     ``float32`` or ``float16``); ``normalize=True`` L2-normalises float32 rows on the device first (txtai's behaviour
@@ -123,12 +126,13 @@ class DeviceIndex:
                         "vqa_index_set_rows")
 
     def get_rows(self, first: int = 0, count: Optional[int] = None) -> Tuple[np.ndarray, Optional[np.ndarray]]:
-        """Stored rows [first, first + count) as a host ``float16`` array [count, d] (and their ids, if the index has an
-        id vector) -- the export used by ``Embeddings.save``."""
+        """Stored rows [first, first + count) as a host array [count, d] in the storage type (``float16``, ``float32`` or
+        ``uint8`` e4m3 codes of ``16 * x``) and their ids, if the index has an id vector -- the export used by
+        ``Embeddings.save``."""
         if not self._handle.value:
             raise RuntimeError("index is closed")
         count = self.n - first if count is None else int(count)
-        rows = np.empty((count, self.d), dtype=np.float16)
+        rows = np.empty((count, self.d), dtype=_STORE_NP[self.dtype])
         ids = np.empty((count,), dtype=np.int64) if self.has_ids else None
         N.check(self._lib.vqa_index_get_rows(self._handle, int(first), count, rows.ctypes.data if count else None,
                                              ids.ctypes.data if ids is not None and count else None), "vqa_index_get_rows")
