@@ -31,30 +31,40 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy rate)
 
 
-def build_shard(n, d, seed, device, chunk=1 << 18):
-    """Synthetic corpus shard generated ON the device: i.i.d. standard normal rows, L2-normalised in fp32, stored
-    fp16."""
+def build_shard(n, d, seed, device, dtype, chunk=1 << 18):
+    """Synthetic corpus shard generated ON the device: i.i.d. standard normal rows, L2-normalised in fp32
+    (SURVEY.md section 8d); kept as fp16 for an fp16 index (= the stored values), as fp32 for fp32 / fp8 indexes."""
     gen = torch.Generator(device=device)
     gen.manual_seed(seed)
-    buf = torch.empty((n, d), dtype=torch.float16, device=device)
+    buf = torch.empty((n, d), dtype=torch.float16 if dtype == "fp16" else torch.float32, device=device)
     for c0 in range(0, n, chunk):
         c1 = min(n, c0 + chunk)
         x = torch.randn((c1 - c0, d), generator=gen, device=device, dtype=torch.float32)
         x /= x.norm(dim=1, keepdim=True)
-        buf[c0:c1] = x.to(torch.float16)
+        buf[c0:c1] = x.to(buf.dtype)
     return buf
 
 
-def cpu_oracle_topk(shard, q16, k, rows=None, chunk_rows=1 << 19):
-    """Exact top-k of the oracle over the first ``rows`` rows of the device shard, streamed to the host in chunks."""
+FP8_SCALE = 16.0
+
+
+def cpu_oracle_topk(shard, q, k, dtype, rows=None, chunk_rows=1 << 19):
+    """Exact top-k of the oracle over the first ``rows`` rows of the device shard, streamed to the host in chunks.
+    ``dtype``: 'fp16' / 'fp32' score the stored values as they are; 'fp8' scores the e4m3 codes of 16 * x (rows and
+    queries, exactly what the index stores) and divides by 256; 'ref32' scores the un-quantised fp32 rows."""
     from oracle import retrieval as R
     n = shard.shape[0] if rows is None else min(rows, shard.shape[0])
-    q = q16.astype(np.float32)
+    q = q.astype(np.float32)
+    if dtype == "fp8":
+        q = R.e4m3_decode(R.e4m3_encode(q * FP8_SCALE)) / FP8_SCALE ** 2
     best_s = best_p = None
     for c0 in range(0, n, chunk_rows):
         c1 = min(n, c0 + chunk_rows)
         xc = shard[c0:c1].cpu().numpy()
-        s, _, p = R.search(q, xc, k, dtype=R.DTYPE_F16)
+        if dtype == "fp8":
+            s, _, p = R.search(q, R.e4m3_encode(xc * FP8_SCALE), k, dtype=R.DTYPE_FP8_E4M3)
+        else:
+            s, _, p = R.search(q, xc, k, dtype=R.DTYPE_F16 if xc.dtype == np.float16 else R.DTYPE_F32)
         p = p + c0
         if best_s is None:
             best_s, best_p = s, p
@@ -76,6 +86,7 @@ def main():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--dtype", choices=["fp16", "fp8", "fp32"], default="fp16", help="index storage type (headline: fp16)")
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--verify-queries", type=int, default=16, help="queries checked against the CPU oracle over the FULL shard")
     ap.add_argument("--no-cpu", action="store_true", help="skip cpu_baseline and the recall check (profiling runs)")
@@ -94,17 +105,20 @@ def main():
         dist.init_process_group("nccl", device_id=device)
 
     from vietnamese_qa_system_amd import build
-    build.build()
+    if local_rank == 0:
+        build.build()  # no-op when the in-tree .so is newer than the sources
+    if world > 1:
+        dist.barrier()  # the other ranks load the library only after rank 0 has (re)built it
     from vietnamese_qa_system_amd.index import DeviceIndex
     from vietnamese_qa_system_amd.sharded import sharded_index_searcher
 
     n, d, b, k = args.docs_per_gpu, args.dim, args.batch, args.k
-    shard = build_shard(n, d, 1234 + rank, device)
-    index = DeviceIndex(shard, id_base=1 + rank * n, dtype="fp16", device=local_rank)
+    shard = build_shard(n, d, 1234 + rank, device, args.dtype)
+    index = DeviceIndex(shard, id_base=1 + rank * n, dtype=args.dtype, device=local_rank)
     gq = torch.Generator(device=device)
     gq.manual_seed(99)
     q = torch.randn((b, d), generator=gq, device=device, dtype=torch.float32)
-    q = (q / q.norm(dim=1, keepdim=True)).to(torch.float16)
+    q = (q / q.norm(dim=1, keepdim=True)).to(shard.dtype)
     searcher = sharded_index_searcher(index)
 
     def sync():
@@ -138,18 +152,20 @@ def main():
         achieved = info.bytes_per_launch / (kern_ms * 1e-3) / 1e9 if launches else None
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        dt = {"fp16": "f16", "fp8": "fp8_e4m3", "fp32": "f32"}[args.dtype]
         if os.path.exists(tpath):
             with open(tpath) as f:
-                traffic = json.load(f).get(f"{n}x{d}_f16_b{b}_k{k}")
+                traffic = json.load(f).get(f"{n}x{d}_{dt}_b{b}_k{k}")
+        mode = {"fp16": 1, "fp8": 2, "fp32": 0}[args.dtype]
         result = {
             "metric": "queries_per_sec", "value": round(qps, 1), "unit": "queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"{world}x{n}x{d} fp16 index row-sharded, batch={b} queries, top-{k}, fused MFMA scoring + top-k"
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dt, "data": "synthetic",
+            "config": {"workload": f"{world}x{n}x{d} {args.dtype} index row-sharded, batch={b} queries, top-{k}, fused MFMA scoring + top-k"
                                    + (", RCCL all-gather + merge" if world > 1 else ""),
                        "docs_total": world * n, "docs_per_gpu": n, "dim": d, "batch": b, "k": k,
                        "parallelism": f"row-shard x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "score_topk_f16_kernel<1>", "achieved": round(achieved, 1) if achieved else None,
+            "roofline": {"bound": "hbm", "kernel": f"score_topk_kernel<1, {mode}>", "achieved": round(achieved, 1) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "traffic": traffic, "kernel_ms": round(kern_ms, 4), "launches": launches,
                          "bytes_per_launch": info.bytes_per_launch, "flops_per_launch": info.flops_per_launch,
@@ -165,17 +181,28 @@ def main():
         q16 = q.cpu().numpy()
         nv = min(args.verify_queries, b)
         t1 = time.perf_counter()
-        ref_s, ref_p = cpu_oracle_topk(shard, q16[:nv], k)
+        # the fp8 oracle encodes every row on the CPU (slow): it checks a 2M-row prefix through a second, prefix-only index
+        vrows = n if args.dtype != "fp8" else min(n, 2_000_000)
+        if vrows < n:
+            pre = DeviceIndex(shard[:vrows], id_base=1, dtype=args.dtype, device=local_rank)
+            s_gpu, i_gpu, p_gpu = pre.search(q, k, return_positions=True)
+            torch.cuda.synchronize(device)
+            pre.close()
+        ref_s, ref_p = cpu_oracle_topk(shard, q16[:nv], k, args.dtype, rows=vrows)
         verify_s = time.perf_counter() - t1
         recall = R.recall_at_k(p_gpu[:nv].cpu().numpy(), ref_p)
         score_err = float(np.abs(s_gpu[:nv].cpu().numpy() - ref_s).max())
         result["recall_at_10"] = recall
-        result["recall_check"] = {"queries": nv, "rows": n, "max_abs_score_err": score_err, "oracle_seconds": round(verify_s, 1)}
+        result["recall_check"] = {"queries": nv, "rows": vrows, "max_abs_score_err": score_err, "oracle_seconds": round(verify_s, 1),
+                                  "oracle": "same stored values"}
+        if args.dtype == "fp8":  # configs[4]: recall of the fp8 index against the un-quantised fp32 rows
+            _, ref32_p = cpu_oracle_topk(shard, q16[:nv], k, "ref32", rows=vrows)
+            result["recall_at_10_vs_fp32"] = R.recall_at_k(p_gpu[:nv].cpu().numpy(), ref32_p)
         if world == 1:
-            rows = min(args.cpu_sample_rows, n)
+            rows = min(args.cpu_sample_rows if args.dtype != "fp8" else args.cpu_sample_rows // 4, n)
             torch.set_num_threads(os.cpu_count())
             t1 = time.perf_counter()
-            cpu_oracle_topk(shard, q16, k, rows=rows)
+            cpu_oracle_topk(shard, q16, k, args.dtype, rows=rows)
             cpu_s = time.perf_counter() - t1
             cpu_qps = b / (cpu_s * (n / rows))
             result["cpu_baseline"] = {"value": round(cpu_qps, 3), "unit": "queries/s", "cores": os.cpu_count(), "kind": "port",
