@@ -113,7 +113,7 @@ def test_argument_errors(native_lib):
     x, q = _mk(100, 64, 2, seed=0)
     ix = DeviceIndex(x, dtype="fp16")
     with pytest.raises(ValueError):
-        ix.search(torch.from_numpy(q).cuda(), 1000)
+        ix.search(torch.from_numpy(q).cuda(), 5000)
     with pytest.raises(ValueError):
         ix.search(torch.zeros(2, 32, dtype=torch.float16).cuda(), 5)
     with pytest.raises(ValueError):
@@ -136,3 +136,26 @@ def test_merge_topk_matches_oracle(native_lib):
     gs, gi = merge_topk(torch.from_numpy(sc).cuda(), torch.from_numpy(ids).cuda(), k)
     assert np.array_equal(gs.cpu().numpy(), es)
     assert np.array_equal(gi.cpu().numpy(), ei)
+
+
+@pytest.mark.parametrize("n,d,b,k", [(5000, 128, 9, 30), (2000, 64, 3, 100), (40, 64, 2, 50), (70001, 64, 257, 13)])
+def test_large_k_runs_continuation_passes(native_lib, n, d, b, k):
+    """k > 12: ceil(k / 12) passes, each strictly below the last key of the previous one; exact, incl. exhaustion."""
+    x, q = _mk(n, d, b, seed=k)
+    s, i, p = _search(x, q, k, id_base=1)
+    kk = min(k, n)
+    R.check_topk(s[:, :kk], p[:, :kk], R.full_scores(q.astype(np.float32), x, R.DTYPE_F16), k, score_tol=SCORE_TOL,
+                 tie_tol=TIE_TOL)
+    assert np.array_equal(i[:, :kk], p[:, :kk] + 1)
+    if kk < k:
+        assert np.all(np.isneginf(s[:, kk:])) and np.all(i[:, kk:] == -1)
+
+
+def test_large_k_ties_across_pass_boundaries(native_lib, golden_dir):
+    g = np.load(f"{golden_dir}/retr_ties.npz")
+    x, q = g["x"].astype(np.float16), g["q"].astype(np.float16)
+    s, i, p = _search(x, q, 40)
+    full = R.full_scores(q.astype(np.float32), x, R.DTYPE_F16)
+    order = np.argsort(-full, axis=1, kind="stable")[:, :40]  # score desc, position asc: exact integers, many duplicates
+    assert np.array_equal(p, order)
+    assert np.array_equal(s, np.take_along_axis(full, order, axis=1).astype(np.float32))

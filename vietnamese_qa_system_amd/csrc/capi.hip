@@ -43,6 +43,7 @@ struct vqa_index {
     size_t q_rows_bytes = 0;
     vqa_key* partial = nullptr;  // [max_grid, 256, max(max_k, seeds per query)]: seed pass output, then main pass lists
     float* thr0 = nullptr;       // [256]
+    vqa_key* upper = nullptr;    // [256] last key returned per query (continuation passes of a search with k > 12)
     // opt-in kernel timing (bench.py): event pairs around the main scoring kernel
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -70,6 +71,7 @@ extern "C" void vqa_index_destroy(vqa_index* ix) {
     if (ix->q_rows) (void)hipFree(ix->q_rows);
     if (ix->partial) (void)hipFree(ix->partial);
     if (ix->thr0) (void)hipFree(ix->thr0);
+    if (ix->upper) (void)hipFree(ix->upper);
     for (hipEvent_t e : ix->ev) (void)hipEventDestroy(e);
     delete ix;
 }
@@ -192,7 +194,8 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
         const int list_len = max_k > vqa_score_topk_seeds_per_query() ? max_k : vqa_score_topk_seeds_per_query();
         if (hipMalloc(&ix->q_stage, (size_t)VQA_QUERY_TILE * ix->d_pad * eb) != hipSuccess ||
             hipMalloc((void**)&ix->partial, (size_t)ix->max_grid * VQA_QUERY_TILE * list_len * sizeof(vqa_key)) != hipSuccess ||
-            hipMalloc((void**)&ix->thr0, VQA_QUERY_TILE * sizeof(float)) != hipSuccess) {
+            hipMalloc((void**)&ix->thr0, VQA_QUERY_TILE * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&ix->upper, VQA_QUERY_TILE * sizeof(vqa_key)) != hipSuccess) {
             vqa_set_error("vqa_index_create: workspace allocation failed");
             rc = VQA_ENOMEM;
             break;
@@ -326,8 +329,8 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
     VQA_REQUIRE(ix, "vqa_index_search: index is null");
     VQA_REQUIRE(q && out_scores && out_ids, "vqa_index_search: null pointer");
     VQA_REQUIRE(B >= 1, "vqa_index_search: B=%d", B);
-    const int max_k = vqa_score_topk_max_k(ix->dtype);
-    VQA_REQUIRE(k >= 1 && k <= max_k, "vqa_index_search: k=%d outside [1, %d]", k, max_k);
+    const int max_k = vqa_score_topk_max_k(ix->dtype);  // per pass over the index
+    VQA_REQUIRE(k >= 1 && k <= VQA_MAX_K_TOTAL, "vqa_index_search: k=%d outside [1, %d]", k, VQA_MAX_K_TOTAL);
     VQA_REQUIRE(q_dtype == VQA_F32 || q_dtype == VQA_F16, "vqa_index_search: q_dtype %d is not f32/f16", q_dtype);
     hipStream_t stream = (hipStream_t)hip_stream;
     DeviceGuard guard(ix->device);
@@ -339,48 +342,59 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
         int64_t* oi = out_ids + (size_t)q0 * k;
         int64_t* op = out_pos_or_null ? out_pos_or_null + (size_t)q0 * k : nullptr;
         if (ix->n == 0) {  // empty shard: every slot is padding
-            // reuse the merge kernel on one all-empty partial list
-            VQA_HIP_CHECK(hipMemsetAsync(ix->partial, 0, (size_t)VQA_QUERY_TILE * k * sizeof(vqa_key), stream));
-            int rc = vqa_launch_merge_partials(ix->partial, 1, k, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr, 1.0f, stream);
-            if (rc != VQA_OK) return rc;
+            // reuse the merge kernel on one all-empty partial list, max_k columns at a time
+            VQA_HIP_CHECK(hipMemsetAsync(ix->partial, 0, (size_t)VQA_QUERY_TILE * max_k * sizeof(vqa_key), stream));
+            for (int done = 0; done < k; done += max_k) {
+                const int kk = k - done < max_k ? k - done : max_k;
+                int rc = vqa_launch_merge_partials(ix->partial, 1, max_k, nq, kk, ix->ids, ix->id_base, os, oi, op, nullptr, 1.0f, k,
+                                                   done, nullptr, stream);
+                if (rc != VQA_OK) return rc;
+            }
             continue;
         }
         int rc = vqa_launch_tile_rows(reinterpret_cast<const char*>(q) + (size_t)q0 * ix->d * qeb, q_dtype, 0, VQA_QUERY_TILE, nq,
                                       ix->d, ix->d_pad, ix->dtype, ix->scale, ix->q_stage, stream);
         if (rc != VQA_OK) return rc;
-        ScoreTopkArgs a;
-        a.x = ix->rows;
-        a.q = ix->q_stage;
-        a.n = ix->n;
-        a.d_pad = ix->d_pad;
-        a.nq = nq;
-        a.k = k;
-        if (p.grid0 > 0) {
-            a.thr_init = nullptr;
+        // k <= 12: one pass.  Larger k: further passes, each admitting only keys strictly below the last key already
+        // returned (keys are distinct, so the continuation is exact); every pass is a full scan of the shard.
+        for (int done = 0; done < k; done += max_k) {
+            const int kk = k - done < max_k ? k - done : max_k;
+            const vqa_key* upper = done > 0 ? ix->upper : nullptr;
+            ScoreTopkArgs a;
+            a.x = ix->rows;
+            a.q = ix->q_stage;
+            a.n = ix->n;
+            a.d_pad = ix->d_pad;
+            a.nq = nq;
+            a.k = kk;
+            a.upper = upper;
+            if (p.grid0 > 0) {
+                a.thr_init = nullptr;
+                a.partial = ix->partial;
+                a.tile_begin = 0;
+                a.tile_end = p.grid0;
+                a.grid = p.grid0;
+                a.seed_only = true;
+                rc = vqa_launch_score_topk(ix->dtype, a, stream);
+                if (rc != VQA_OK) return rc;
+                rc = vqa_launch_merge_partials(ix->partial, p.grid0, vqa_score_topk_seeds_per_query(), nq, kk, nullptr, 0, nullptr,
+                                               nullptr, nullptr, ix->thr0, 1.0f, kk, 0, nullptr, stream);
+                if (rc != VQA_OK) return rc;
+            }
+            a.thr_init = p.grid0 > 0 ? ix->thr0 : nullptr;
             a.partial = ix->partial;
             a.tile_begin = 0;
-            a.tile_end = p.grid0;
-            a.grid = p.grid0;
-            a.seed_only = true;
+            a.tile_end = p.tiles;
+            a.grid = p.grid1;
+            a.seed_only = false;
+            if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
             rc = vqa_launch_score_topk(ix->dtype, a, stream);
             if (rc != VQA_OK) return rc;
-            rc = vqa_launch_merge_partials(ix->partial, p.grid0, vqa_score_topk_seeds_per_query(), nq, k, nullptr, 0, nullptr,
-                                           nullptr, nullptr, ix->thr0, 1.0f, stream);
+            if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
+            rc = vqa_launch_merge_partials(ix->partial, p.grid1, kk, nq, kk, ix->ids, ix->id_base, os, oi, op, nullptr,
+                                           1.0f / (ix->scale * ix->scale), k, done, done + kk < k ? ix->upper : nullptr, stream);
             if (rc != VQA_OK) return rc;
         }
-        a.thr_init = p.grid0 > 0 ? ix->thr0 : nullptr;
-        a.partial = ix->partial;
-        a.tile_begin = 0;
-        a.tile_end = p.tiles;
-        a.grid = p.grid1;
-        a.seed_only = false;
-        if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
-        rc = vqa_launch_score_topk(ix->dtype, a, stream);
-        if (rc != VQA_OK) return rc;
-        if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
-        rc = vqa_launch_merge_partials(ix->partial, p.grid1, k, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr,
-                                       1.0f / (ix->scale * ix->scale), stream);
-        if (rc != VQA_OK) return rc;
     }
     return VQA_OK;
 }

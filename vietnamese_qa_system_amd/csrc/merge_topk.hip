@@ -42,7 +42,9 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
                                                                        long long id_base, float* __restrict__ out_scores,
                                                                        long long* __restrict__ out_ids,
                                                                        long long* __restrict__ out_pos,
-                                                                       float* __restrict__ out_thr, float score_scale) {
+                                                                       float* __restrict__ out_thr, float score_scale,
+                                                                       int out_stride, int out_offset,
+                                                                       vqa_key* __restrict__ out_last_key) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     vqa_key* keys = reinterpret_cast<vqa_key*>(smem);    // [parts * list_len]
     vqa_key* red = keys + (size_t)parts * list_len;      // [4]
@@ -64,10 +66,12 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
         if (threadIdx.x == 0) {
             const bool empty = best == 0ull;
             const long long pos = empty ? -1 : (long long)vqa_key_pos(best);
-            if (out_scores) out_scores[(size_t)q * k + r] = empty ? -INFINITY : vqa_key_score(best) * score_scale;
-            if (out_ids) out_ids[(size_t)q * k + r] = empty ? -1 : (ids ? ids[pos] : id_base + pos);
-            if (out_pos) out_pos[(size_t)q * k + r] = pos;
+            const size_t o = (size_t)q * out_stride + out_offset + r;
+            if (out_scores) out_scores[o] = empty ? -INFINITY : vqa_key_score(best) * score_scale;
+            if (out_ids) out_ids[o] = empty ? -1 : (ids ? ids[pos] : id_base + pos);
+            if (out_pos) out_pos[o] = pos;
             if (out_thr && r == k - 1) out_thr[q] = empty ? -INFINITY : vqa_key_score(best);
+            if (out_last_key && r == k - 1) out_last_key[q] = best;
         }
         prev = best;  // 0 once the candidates are exhausted: later rounds stay empty
         if (best == 0ull) prev = 0ull;
@@ -117,14 +121,16 @@ __global__ __launch_bounds__(kMergeThreads) void merge_shards_kernel(const float
 
 int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t list_len, int32_t nq, int32_t k,
                               const int64_t* ids, int64_t id_base, float* out_scores, int64_t* out_ids, int64_t* out_pos,
-                              float* out_thr, float score_scale, hipStream_t stream) {
+                              float* out_thr, float score_scale, int32_t out_stride, int32_t out_offset,
+                              vqa_key* out_last_key, hipStream_t stream) {
     VQA_REQUIRE(parts >= 1 && list_len >= 1 && nq >= 1 && nq <= VQA_QUERY_TILE && k >= 1,
                 "merge_partials: bad shape parts=%d list_len=%d nq=%d k=%d", parts, list_len, nq, k);
     const size_t lds = ((size_t)parts * list_len + 4) * sizeof(vqa_key);
     VQA_REQUIRE(lds <= 64 * 1024, "merge_partials: %d lists x %d keys do not fit in LDS", parts, list_len);
     hipLaunchKernelGGL(merge_partials_kernel, dim3(nq), dim3(kMergeThreads), lds, stream, partial, parts, list_len, k,
                        reinterpret_cast<const long long*>(ids), (long long)id_base, out_scores,
-                       reinterpret_cast<long long*>(out_ids), reinterpret_cast<long long*>(out_pos), out_thr, score_scale);
+                       reinterpret_cast<long long*>(out_ids), reinterpret_cast<long long*>(out_pos), out_thr, score_scale,
+                       out_stride, out_offset, out_last_key);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

@@ -183,8 +183,10 @@ __device__ __forceinline__ float select_acc(const f32x4 (&acc)[8][4], int ni, in
 
 // Append this lane's pending accumulators (bit mi*4+j of pend[ni]) that still beat their query's threshold.
 // Returns true when some append was refused (list full): the bit stays set for the next round.
+// `upper` (or null): exclusive upper bound key per query -- the continuation of a search beyond kMaxK results only admits
+// candidates strictly below the last key already returned.
 __device__ __forceinline__ bool process_pending(const Lists& L, const f32x4 (&acc)[8][4], uint32_t (&pend)[4], int wm,
-                                                int wn, int c, int g, uint32_t row0) {
+                                                int wn, int c, int g, uint32_t row0, const vqa_key* __restrict__ upper) {
     bool refused = false;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -192,14 +194,15 @@ __device__ __forceinline__ bool process_pending(const Lists& L, const f32x4 (&ac
         if (bits) {
             const int q = wn * 64 + ni * 16 + c;
             const float th = L.thr[q];
+            const vqa_key up = upper ? upper[q] : ~0ull;
             uint32_t keep = 0;
             while (bits) {
                 const int b = __builtin_ctz(bits);
                 bits &= bits - 1;
                 const float v = select_acc(acc, ni, b);
                 if (v >= th) {
-                    const int r = wm * 128 + (b >> 2) * 16 + g * 4 + (b & 3);
-                    if (!append_candidate(L, q, v, row0 + (uint32_t)r)) keep |= 1u << b;
+                    const uint32_t pos = row0 + (uint32_t)(wm * 128 + (b >> 2) * 16 + g * 4 + (b & 3));
+                    if (vqa_make_key(v, pos) < up && !append_candidate(L, q, v, pos)) keep |= 1u << b;
                 }
             }
             pend[ni] = keep;
@@ -242,9 +245,10 @@ __device__ __forceinline__ void block_barrier() {
 
 template <int MODE, int DT>
 __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __restrict__ X, const void* __restrict__ Qs,
-                                                              const float* __restrict__ thr_init, vqa_key* __restrict__ out,
-                                                              long long N, int KT, int nq, int k, int tile_begin,
-                                                              int tile_end) {
+                                                              const float* __restrict__ thr_init,
+                                                              const vqa_key* __restrict__ upper,
+                                                              vqa_key* __restrict__ out, long long N, int KT, int nq, int k,
+                                                              int tile_begin, int tile_end) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lists L;
     L.thr = reinterpret_cast<float*>(smem + kPipeBytes);
@@ -474,6 +478,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 const int q = wn * 64 + ni * 16 + c;
+                const vqa_key up = upper ? upper[q] : ~0ull;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     float m = -INFINITY;
@@ -484,7 +489,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
                         for (int j = 0; j < 4; ++j) {
                             const int r = wm * 128 + mi * 16 + g * 4 + j;
                             const float v = acc[mi][ni][j];
-                            if (v > m) {
+                            if (v > m && (!upper || vqa_make_key(v, row0 + (uint32_t)r) < up)) {
                                 m = v;
                                 arg = r;
                             }
@@ -528,7 +533,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         // every wave passed the re-align barrier after its last fragment reads completed, so the idle stage (L.ext)
         // is free: a list holds up to kCap + kExt keys inside this epilogue and is back below kCap when it ends
         // (water <= kCap: every list that spilled into L.ext is compacted).
-        if (any && process_pending(L, acc, pend, wm, wn, c, g, row0)) atomicOr(&L.cnt[0], kOverBit);
+        if (any && process_pending(L, acc, pend, wm, wn, c, g, row0, upper)) atomicOr(&L.cnt[0], kOverBit);
         __syncthreads();
         for (;;) {
             const int over = L.cnt[0] & kOverBit;  // stable here: set before the barrier above, cleared only behind the next
@@ -541,7 +546,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
             __syncthreads();
             if (tid == 0) L.cnt[0] &= ~kOverBit;
             __syncthreads();
-            if (process_pending(L, acc, pend, wm, wn, c, g, row0)) atomicOr(&L.cnt[0], kOverBit);
+            if (process_pending(L, acc, pend, wm, wn, c, g, row0, upper)) atomicOr(&L.cnt[0], kOverBit);
             __syncthreads();
         }
     }
@@ -590,8 +595,8 @@ static int launch_dt(const ScoreTopkArgs& a, int KT, int lds, hipStream_t stream
         attr_set = true;
     }
     auto kern = a.seed_only ? score_topk_kernel<0, DT> : score_topk_kernel<1, DT>;
-    hipLaunchKernelGGL(kern, dim3(a.grid), dim3(kThreads), lds, stream, a.x, a.q, a.thr_init, a.partial, (long long)a.n, KT, a.nq,
-                       a.k, a.tile_begin, a.tile_end);
+    hipLaunchKernelGGL(kern, dim3(a.grid), dim3(kThreads), lds, stream, a.x, a.q, a.thr_init, a.upper, a.partial, (long long)a.n,
+                       KT, a.nq, a.k, a.tile_begin, a.tile_end);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

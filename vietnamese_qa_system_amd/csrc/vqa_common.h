@@ -50,6 +50,7 @@ struct ScoreTopkArgs {
     const void* x;        // index rows in TILED layout (convert.hip): ceil(n/256) tiles x (d_pad/32) blocks of 16 KiB
     const void* q;        // staged query tile, same layout (one tile), zero padded
     const float* thr_init; // [VQA_QUERY_TILE] starting thresholds or nullptr (-inf)
+    const vqa_key* upper = nullptr;  // [VQA_QUERY_TILE] exclusive upper bound keys (continuation passes) or nullptr
     vqa_key* partial;     // [grid, VQA_QUERY_TILE, k] per-workgroup sorted partial lists (output)
     int64_t n;            // rows in the shard
     int32_t d_pad;        // padded row length in elements (multiple of 64)
@@ -70,6 +71,8 @@ int vqa_score_topk_seeds_per_query();
 int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t list_len, int32_t nq, int32_t k,
                               const int64_t* ids, int64_t id_base, float* out_scores, int64_t* out_ids, int64_t* out_pos,
                               float* out_thr, float score_scale /* applied to out_scores only (power of two) */,
+                              int32_t out_stride /* row stride of the out arrays */, int32_t out_offset /* first column */,
+                              vqa_key* out_last_key /* [nq] k-th key per query (0 when fewer exist) or nullptr */,
                               hipStream_t stream);
 
 // row-major [valid, d] f32|f16 rows (device) -> TILED layout, storage type `dtype`, at rows [first, first + count);
