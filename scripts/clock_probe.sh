@@ -13,7 +13,7 @@ d, v = sys.argv[1], sys.argv[2]
 f = glob.glob(d + '/*/*counter_collection.csv')[0]
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    if 'score_topk_f16_kernelILi1E' in r['Kernel_Name']:
+    if 'score_topk_kernel<1,' in r['Kernel_Name'] or 'score_topk_kernelILi1E' in r['Kernel_Name']:
         agg[r['Counter_Name']].append((float(r['Counter_Value']), (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3))
 g = agg['GRBM_GUI_ACTIVE'][2:]
 clk = sum(x[0] / 8 / x[1] for x in g) / len(g) / 1e3

@@ -10,18 +10,19 @@ ap.add_argument("--d", type=int, default=768)
 ap.add_argument("--b", type=int, default=256)
 ap.add_argument("--k", type=int, default=10)
 ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--dtype", default="fp16")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 gen = torch.Generator(device=dev); gen.manual_seed(1234)
-buf = torch.empty((args.n, args.d), dtype=torch.float16, device=dev)
+buf = torch.empty((args.n, args.d), dtype=torch.float16 if args.dtype == "fp16" else torch.float32, device=dev)
 for c0 in range(0, args.n, 1 << 18):
     c1 = min(args.n, c0 + (1 << 18))
     x = torch.randn((c1 - c0, args.d), generator=gen, device=dev)
     x /= x.norm(dim=1, keepdim=True)
-    buf[c0:c1] = x.half()
-ix = DeviceIndex(buf, dtype="fp16")
+    buf[c0:c1] = x.to(buf.dtype)
+ix = DeviceIndex(buf, dtype=args.dtype)
 q = torch.randn((args.b, args.d), generator=gen, device=dev)
-q = (q / q.norm(dim=1, keepdim=True)).half()
+q = (q / q.norm(dim=1, keepdim=True)).to(buf.dtype)
 for _ in range(3):
     ix.search(q, args.k)
 ix.set_timing(True)
@@ -33,4 +34,4 @@ torch.cuda.synchronize()
 el = (time.perf_counter() - t0) / args.steps * 1e3
 ms, n = ix.get_timing()
 print(f"{os.environ.get('VQA_LIB', 'default'):60s} step {el:.3f} ms  main kernel {ms / max(n, 1):.3f} ms  "
-      f"-> {args.n * args.d * 2 / (ms / max(n, 1) * 1e-3) / 1e9:.0f} GB/s, {2 * 256 * args.n * args.d / (ms / max(n, 1) * 1e-3) / 1e12:.0f} TF", flush=True)
+      f"-> {args.n * args.d * {'fp16': 2, 'fp8': 1, 'fp32': 4}[args.dtype] / (ms / max(n, 1) * 1e-3) / 1e9:.0f} GB/s, {2 * 256 * args.n * args.d / (ms / max(n, 1) * 1e-3) / 1e12:.0f} TF", flush=True)

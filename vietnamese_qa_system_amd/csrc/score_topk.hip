@@ -433,7 +433,10 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         VQA_READ_FRAGS(a0, b0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         block_barrier();  // every wave holds its first fragments before a piece of K-step + kS may overwrite the stage
-        if constexpr (DT == VQA_F16) {
+#ifndef VQA_SINGLE_SET
+#define VQA_SINGLE_SET 0
+#endif
+        if constexpr (DT == VQA_F16 && !VQA_SINGLE_SET) {
             frag_t a1[8], b1[4];  // second register set: the next K-step's fragments load under this K-step's MFMAs
             for (int kt = 0; kt < KT; kt += 2) {  // KT is even (rows are padded to two K-steps)
                 const int kappa = ti * KT + kt;
