@@ -56,7 +56,7 @@ struct MfmaTraits<VQA_F16> {
     }
 };
 template <>
-struct MfmaTraits<VQA_FP8_E4M3> {
+struct MfmaTraits<VQA_FP8_E4M3> {  // plain fp8 MFMA (fp16 rate); the kernel uses the block-scaled form below instead
     static constexpr int kSub = 2;
     template <int T>
     static __device__ __forceinline__ f32x4 mma(frag_t a, frag_t b, f32x4 c) {
@@ -64,6 +64,7 @@ struct MfmaTraits<VQA_FP8_E4M3> {
         return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a2[T], b2[T], c, 0, 0, 0);
     }
 };
+
 template <>
 struct MfmaTraits<VQA_F32> {
     static constexpr int kSub = 4;
@@ -74,6 +75,29 @@ struct MfmaTraits<VQA_F32> {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(af[T], bf[T], c, 0, 0, 0);
     }
 };
+
+// fp8 at twice the fp16 MFMA rate: v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (E8M0 127 = 2^0, byte 0 of
+// the scale register, op_sel 0).  One instruction consumes 32 bytes per lane and operand = the lane's fragments of TWO
+// consecutive K-steps; rows and queries are paired byte for byte (scripts/probes/mx_fp8_probe.hip: exact on integer
+// data, 2.18x the plain fp8 MFMA rate).
+typedef int v8i __attribute__((ext_vector_type(8)));
+template <int HALF>  // write a 16-byte fragment into the low / high half of a 32-byte MFMA operand (no copy: sub-registers)
+__device__ __forceinline__ void set_half(v8i& v, frag_t f) {
+    v[4 * HALF + 0] = (int)f[0];
+    v[4 * HALF + 1] = (int)f[1];
+    v[4 * HALF + 2] = (int)f[2];
+    v[4 * HALF + 3] = (int)f[3];
+}
+template <int M0, int M1>
+__device__ __forceinline__ void mma_block_mx(f32x4 (&acc)[8][4], const v8i (&a)[8], const v8i (&b)[4]) {
+    constexpr int kUnitScale = 0x7F7F7F7F;
+#pragma unroll
+    for (int mi = M0; mi < M1; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a[mi], b[ni], acc[mi][ni], 0, 0, 0, kUnitScale, 0,
+                                                                           kUnitScale);
+}
 
 // row groups [M0, M1) x all four query groups; sub-step outermost so consecutive MFMAs hit different accumulators
 // (v_mfma_f32_16x16x4_f32 has a 40-cycle dependent latency against a 32-cycle issue)
@@ -95,6 +119,10 @@ __device__ __forceinline__ void mma_block(f32x4 (&acc)[8][4], const frag_t (&a)[
 }
 
 typedef __attribute__((address_space(3))) char* lds_char_ptr;
+
+#ifndef VQA_SINGLE_SET
+#define VQA_SINGLE_SET 0  // dev A/B: 1 = the fp16 loop without the second fragment register set
+#endif
 
 constexpr int kThreads = 512;           // 8 waves: 2 (row halves = ping-pong groups) x 4 (query quarters)
 constexpr int kTileRows = 256;          // corpus rows per tile
@@ -160,13 +188,13 @@ __device__ __forceinline__ void compact_pass(const Lists& L, int wave, int lane,
     }
 }
 
-__device__ __forceinline__ bool append_candidate(const Lists& L, int q, float v, uint32_t pos) {
+__device__ __forceinline__ bool append_candidate(const Lists& L, int q, float v, uint32_t pos, int spill) {
     const int slot = atomicAdd(&L.cnt[q], 1) & kCntMask;  // ds_add_rtn_u32
     if (slot < kCap) {
         L.cand[q * kCap + slot] = vqa_make_key(v, pos);
         return true;
     }
-    if (slot < kCap + kExt) {
+    if (slot < kCap + spill) {
         L.ext[q * kExt + (slot - kCap)] = vqa_make_key(v, pos);
         return true;
     }
@@ -186,7 +214,7 @@ __device__ __forceinline__ float select_acc(const f32x4 (&acc)[8][4], int ni, in
 // `upper` (or null): exclusive upper bound key per query -- the continuation of a search beyond kMaxK results only admits
 // candidates strictly below the last key already returned.
 __device__ __forceinline__ bool process_pending(const Lists& L, const f32x4 (&acc)[8][4], uint32_t (&pend)[4], int wm,
-                                                int wn, int c, int g, uint32_t row0, const vqa_key* __restrict__ upper) {
+                                                int wn, int c, int g, uint32_t row0, const vqa_key* __restrict__ upper, int spill) {
     bool refused = false;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -202,7 +230,7 @@ __device__ __forceinline__ bool process_pending(const Lists& L, const f32x4 (&ac
                 const float v = select_acc(acc, ni, b);
                 if (v >= th) {
                     const uint32_t pos = row0 + (uint32_t)(wm * 128 + (b >> 2) * 16 + g * 4 + (b & 3));
-                    if (vqa_make_key(v, pos) < up && !append_candidate(L, q, v, pos)) keep |= 1u << b;
+                    if (vqa_make_key(v, pos) < up && !append_candidate(L, q, v, pos, spill)) keep |= 1u << b;
                 }
             }
             pend[ni] = keep;
@@ -352,6 +380,18 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         if (++sq == kSq) sq = 0;                                                                                  \
     } while (0)
 #endif
+// fp8: fragments of an even / odd K-step into the low / high halves of the 32-byte MFMA operands
+#define VQA_READ_HALVES(A, B, HALF)                                                                               \
+    do {                                                                                                          \
+        const char* xbuf_ = smem + sx * kOperandBytes;                                                            \
+        const char* qbuf_ = smem + sq * kOperandBytes;                                                            \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                          \
+            set_half<HALF>(B[i_], *reinterpret_cast<const frag_t*>(qbuf_ + b_base + i_ * 16 * kRowBytes));        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                          \
+            set_half<HALF>(A[i_], *reinterpret_cast<const frag_t*>(xbuf_ + a_base + i_ * 16 * kRowBytes));        \
+        if (++sx == kSx) sx = 0;                                                                                  \
+        if (++sq == kSq) sq = 0;                                                                                  \
+    } while (0)
 #if VQA_ABLATE & 4
 #define VQA_MMA_RANGE(A, B, M0, M1)                                                                       \
     do {                                                                                                  \
@@ -404,14 +444,17 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         VQA_LOOP_BARRIER();                                        \
     } while (0)
 
-    // prologue: the first kP K-steps of this wave's stream; K-steps 0 and 1 landed
+    // prologue: the first K-steps of this wave's stream (fp8 works on K-step PAIRS: three X pairs, one Q pair);
+    // fp16 / fp32: K-steps 0 and 1 landed
     if (wm) {
-        for (int i = 0; i < kPx; ++i) issue_x();
+        for (int i = 0; i < (DT == VQA_FP8_E4M3 ? 6 : kPx); ++i) issue_x();
     } else {
         for (int i = 0; i < kPq; ++i) issue_q();
     }
-    wait_pieces(1);
-    block_barrier();
+    if constexpr (DT != VQA_FP8_E4M3) {
+        wait_pieces(1);
+        block_barrier();
+    }
 
     // The whole tile loop exists twice (group 0: memory instructions first, group 1: matrix instructions first) and
     // the wave-uniform branch sits OUTSIDE it: a diamond around each K-step makes hipcc spill the accumulators.
@@ -429,13 +472,45 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         // kappa + 1 may be refilled after the barrier), a counted vmcnt (this wave's pieces of kappa + 2 landed) and
         // the barrier.  Group 0 runs R, D, M and group 1 runs M, R, D, so on every SIMD one wave starts with the
         // matrix pipe while its partner starts with memory instructions.
+        if constexpr (DT == VQA_FP8_E4M3) {
+            // fp8: the block-scaled MFMA consumes two K-steps at once, so the loop works on K-step PAIRS.  Pair j:
+            // (A) this wave's pieces of pair j have landed (counted vmcnt), barrier; (B) read all 24 fragments of the pair
+            // (both halves of every 32-byte operand in one place, so they form register tuples without copies),
+            // lgkmcnt(0), barrier; (C) issue the DMA pieces of X pair j + 3 (into the stages just read; the 6-stage X ring
+            // holds three pairs) / Q pair j + 1 (the 2-stage Q ring holds one pair); (D) 32 scaled MFMAs.
+            static_assert(kSx == 6 && kSq == 2, "the fp8 pair loop assumes three X pairs and one Q pair of ring stages");
+            v8i a2[8], b2[4];
+            for (int kt = 0; kt < KT; kt += 2) {  // KT is even: pairs never straddle tiles
+                const int kappa = ti * KT + kt;
+                if (wm) {
+                    if (kappa + 5 < total) wait_vmcnt<16>();  // issued through pair j + 2: two pairs may stay in flight
+                    else wait_vmcnt<0>();
+                } else {
+                    wait_vmcnt<0>();
+                }
+                block_barrier();
+                VQA_READ_HALVES(a2, b2, 0);
+                VQA_READ_HALVES(a2, b2, 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                VQA_LOOP_BARRIER();
+#if !(VQA_ABLATE & 1)
+                if (wm) {
+                    issue_x();
+                    issue_x();
+                } else {
+                    issue_q();
+                    issue_q();
+                }
+#endif
+                VQA_SB();
+                mma_block_mx<0, 8>(acc, a2, b2);
+            }
+            block_barrier();  // every wave is done with the MFMAs before the epilogue's barriers interleave with (A)
+        } else {
         frag_t a0[8], b0[4];
         VQA_READ_FRAGS(a0, b0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         block_barrier();  // every wave holds its first fragments before a piece of K-step + kS may overwrite the stage
-#ifndef VQA_SINGLE_SET
-#define VQA_SINGLE_SET 0
-#endif
         if constexpr (DT == VQA_F16 && !VQA_SINGLE_SET) {
             frag_t a1[8], b1[4];  // second register set: the next K-step's fragments load under this K-step's MFMAs
             for (int kt = 0; kt < KT; kt += 2) {  // KT is even (rows are padded to two K-steps)
@@ -444,8 +519,8 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
                 VQA_KSTEP(a1, b1, a0, b0, kappa + 1, kt + 2 < KT);
             }
         } else {
-            // fp8 / fp32: 2x / 4x the MFMAs per K-step and one register set (a second one spills): issue the DMA
-            // pieces, multiply, then refill the same registers; the reads' latency hides under the partner wave's MFMAs
+            // fp32: 4x the MFMAs per K-step and one register set (a second one spills): issue the DMA pieces, multiply,
+            // then refill the same registers; the reads' latency hides under the partner wave's MFMAs
             for (int kt = 0; kt < KT; ++kt) {
                 const int kappa = ti * KT + kt;
                 VQA_ISSUE();
@@ -458,6 +533,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
                 VQA_LOOP_BARRIER();
             }
         }
+        }  // storage types other than fp8
 
         // ---- epilogue; scores stay in registers ------------------------------------------------------------------
         // acc[mi][ni][j] = score(row = row0 + 128 wm + 16 mi + 4 g + j, query = 64 wn + 16 ni + c)
@@ -505,7 +581,9 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         }
         // X stage of the tile's last K-step: every read of it completed before the re-align barrier and its next
         // refill (K-step + kSx) is issued in the next tile's first L segment
+        // (fp8: every X stage holds a pair in flight, so there is no spill area and a list holds kCap keys)
         L.ext = reinterpret_cast<vqa_key*>(smem + (sx == 0 ? kSx - 1 : sx - 1) * kOperandBytes);
+        constexpr int kSpill = DT == VQA_FP8_E4M3 ? 0 : kExt;
         static_assert(kPx < kSx, "the X stage of the K-step just computed must idle until the next K-step's pieces are issued");
         uint32_t pend[4];
         bool any = false;
@@ -536,12 +614,12 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         // every wave passed the re-align barrier after its last fragment reads completed, so the idle stage (L.ext)
         // is free: a list holds up to kCap + kExt keys inside this epilogue and is back below kCap when it ends
         // (water <= kCap: every list that spilled into L.ext is compacted).
-        if (any && process_pending(L, acc, pend, wm, wn, c, g, row0, upper)) atomicOr(&L.cnt[0], kOverBit);
+        if (any && process_pending(L, acc, pend, wm, wn, c, g, row0, upper, kSpill)) atomicOr(&L.cnt[0], kOverBit);
         __syncthreads();
         for (;;) {
             const int over = L.cnt[0] & kOverBit;  // stable here: set before the barrier above, cleared only behind the next
             // normal tiles: compact lists that are nearly full; after a refusal: compact everything above k
-            compact_pass(L, wave, lane, k, over ? k + 1 : k + (kCap - k + 1) / 2, kCap + kExt);
+            compact_pass(L, wave, lane, k, over ? k + 1 : k + (kCap - k + 1) / 2, kCap + kSpill);
             // Fast path: no trailing barrier.  What compaction wrote (thr, cnt, cand) is next read in the next tile's
             // epilogue, 24+ barriers away; the spill stage L.ext is refilled only behind the next tile's first barrier,
             // which no wave passes before every wave has finished compacting.
@@ -549,7 +627,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
             __syncthreads();
             if (tid == 0) L.cnt[0] &= ~kOverBit;
             __syncthreads();
-            if (process_pending(L, acc, pend, wm, wn, c, g, row0, upper)) atomicOr(&L.cnt[0], kOverBit);
+            if (process_pending(L, acc, pend, wm, wn, c, g, row0, upper, kSpill)) atomicOr(&L.cnt[0], kOverBit);
             __syncthreads();
         }
     }
