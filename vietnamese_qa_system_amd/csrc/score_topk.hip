@@ -460,6 +460,14 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     // the wave-uniform branch sits OUTSIDE it: a diamond around each K-step makes hipcc spill the accumulators.
     auto tile_loop = [&](auto mem_first_tag) __attribute__((always_inline)) {
     constexpr bool kMemFirst = decltype(mem_first_tag)::value;
+    frag_t a0[8], b0[4];  // fp16 / fp32: fragments of the K-step about to be multiplied (carried across tiles)
+    if constexpr (DT != VQA_FP8_E4M3) {
+        if (ntile > 0) {
+            VQA_READ_FRAGS(a0, b0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        block_barrier();  // every wave holds its first fragments before a piece of K-step + kS may overwrite the stage
+    }
     for (int ti = 0; ti < ntile; ++ti) {
         f32x4 acc[8][4];
 #pragma unroll
@@ -507,16 +515,14 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
             }
             block_barrier();  // every wave is done with the MFMAs before the epilogue's barriers interleave with (A)
         } else {
-        frag_t a0[8], b0[4];
-        VQA_READ_FRAGS(a0, b0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        block_barrier();  // every wave holds its first fragments before a piece of K-step + kS may overwrite the stage
+        // (the first fragments of this tile were read before the loop / under the previous tile's last K-step, so their
+        // LDS latency and the pipeline refill hide under the previous tile's epilogue)
         if constexpr (DT == VQA_F16 && !VQA_SINGLE_SET) {
             frag_t a1[8], b1[4];  // second register set: the next K-step's fragments load under this K-step's MFMAs
             for (int kt = 0; kt < KT; kt += 2) {  // KT is even (rows are padded to two K-steps)
                 const int kappa = ti * KT + kt;
                 VQA_KSTEP(a0, b0, a1, b1, kappa, true);
-                VQA_KSTEP(a1, b1, a0, b0, kappa + 1, kt + 2 < KT);
+                VQA_KSTEP(a1, b1, a0, b0, kappa + 1, kt + 2 < KT || ti + 1 < ntile);
             }
         } else {
             // fp32: 4x the MFMAs per K-step and one register set (a second one spills): issue the DMA pieces, multiply,
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
                 VQA_SB();
                 VQA_MMA(a0, b0);
                 VQA_SB();
-                if (kt + 1 < KT) VQA_READ_FRAGS(a0, b0);
+                if (kt + 1 < KT || ti + 1 < ntile) VQA_READ_FRAGS(a0, b0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 wait_pieces(kappa + 2);
                 VQA_LOOP_BARRIER();
