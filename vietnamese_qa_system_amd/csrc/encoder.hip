@@ -33,27 +33,46 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// ---- LayerNorm of one row held as kMaxPer values per lane (element j = lane + 64 i; slots with j >= H hold 0).
-// All loops are fully unrolled over kMaxPer with j < H predicates so x[] stays in registers.
-constexpr int kMaxPer = 32;  // hidden <= 2048
+// ---- LayerNorm of one row held as kChunks x 8 values per lane: chunk i of a lane covers elements
+// (lane + 64 i) * 8 .. + 7 (16-byte fp16 / 32-byte fp32 accesses; H % 8 == 0).  Slots past H hold 0.  All loops are fully
+// unrolled so x[][] stays in registers.
+constexpr int kChunks = 4;  // hidden <= 2048
 
-__device__ __forceinline__ void row_layer_norm(float (&x)[kMaxPer], int H, int lane, const float* __restrict__ g,
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void row_layer_norm(float (&x)[kChunks][8], int H, int lane, const float* __restrict__ g,
                                                const float* __restrict__ b, float eps, _Float16* __restrict__ out) {
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxPer; ++i) s += x[i];
+    for (int i = 0; i < kChunks; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += x[i][e];
     const float mu = wave_sum(s) / H;
     float v = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxPer; ++i) {
-        const float dlt = (lane + 64 * i < H) ? x[i] - mu : 0.f;
-        v += dlt * dlt;
+    for (int i = 0; i < kChunks; ++i) {
+        const bool live = (lane + 64 * i) * 8 < H;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float dlt = live ? x[i][e] - mu : 0.f;
+            v += dlt * dlt;
+        }
     }
     const float rstd = rsqrtf(wave_sum(v) / H + eps);
 #pragma unroll
-    for (int i = 0; i < kMaxPer; ++i) {
-        const int j = lane + 64 * i;
-        if (j < H) out[j] = (_Float16)((x[i] - mu) * rstd * g[j] + b[j]);
+    for (int i = 0; i < kChunks; ++i) {
+        const int j0 = (lane + 64 * i) * 8;
+        if (j0 < H) {
+            const f32x4v g0 = *reinterpret_cast<const f32x4v*>(g + j0), g1 = *reinterpret_cast<const f32x4v*>(g + j0 + 4);
+            const f32x4v b0 = *reinterpret_cast<const f32x4v*>(b + j0), b1 = *reinterpret_cast<const f32x4v*>(b + j0 + 4);
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (_Float16)((x[i][e] - mu) * rstd * g0[e] + b0[e]);
+                o[4 + e] = (_Float16)((x[i][4 + e] - mu) * rstd * g1[e] + b1[e]);
+            }
+            *reinterpret_cast<half8*>(out + j0) = o;
+        }
     }
 }
 
@@ -72,11 +91,20 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ i
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
     const int pid = id != pad_id ? cnt + pad_id : pad_id;
-    float x[kMaxPer];
+    float x[kChunks][8];
 #pragma unroll
-    for (int i = 0; i < kMaxPer; ++i) {
-        const int j = lane + 64 * i;
-        x[i] = j < H ? word[(size_t)id * H + j] + pos[(size_t)pid * H + j] + type0[j] : 0.f;
+    for (int i = 0; i < kChunks; ++i) {
+        const int j0 = (lane + 64 * i) * 8;
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            f32x4v v = {0.f, 0.f, 0.f, 0.f};
+            if (j0 < H)
+                v = *reinterpret_cast<const f32x4v*>(word + (size_t)id * H + j0 + 4 * hlf) +
+                    *reinterpret_cast<const f32x4v*>(pos + (size_t)pid * H + j0 + 4 * hlf) +
+                    *reinterpret_cast<const f32x4v*>(type0 + j0 + 4 * hlf);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[i][4 * hlf + e] = v[e];
+        }
     }
     row_layer_norm(x, H, lane, g, b, eps, out + (size_t)t * H);
 }
@@ -87,89 +115,105 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const _Float16* __restrict_
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
-    float x[kMaxPer];
+    float x[kChunks][8];
 #pragma unroll
-    for (int i = 0; i < kMaxPer; ++i) {
-        const int j = lane + 64 * i;
-        x[i] = j < H ? (float)a[(size_t)t * H + j] + (float)res[(size_t)t * H + j] : 0.f;
+    for (int i = 0; i < kChunks; ++i) {
+        const int j0 = (lane + 64 * i) * 8;
+        half8 va = half8{0, 0, 0, 0, 0, 0, 0, 0}, vr = va;
+        if (j0 < H) {
+            va = *reinterpret_cast<const half8*>(a + (size_t)t * H + j0);
+            vr = *reinterpret_cast<const half8*>(res + (size_t)t * H + j0);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[i][e] = (float)va[e] + (float)vr[e];
     }
     row_layer_norm(x, H, lane, g, b, eps, out + (size_t)t * H);
 }
 
-// ---- GEMM: C[M, N] = A[M, K] . W[N, K]^T + bias[N]; EPI 0: identity, 1: erf GELU.  K % 32 == 0. ---------------------
-constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 32;
-constexpr int kGemmTileBytes = kGemmBM * kGemmBK * 2;  // 8 KiB per operand per stage
+// ---- GEMM: C[M, N] = A[M, K] . W[N, K]^T + bias[N]; EPI 0: identity, 1: erf GELU.  K % 64 == 0 (BK = 64) or K % 32 == 0
+// (BK = 32 instantiation for small hidden sizes). -----------------------------------------------------------------------
+constexpr int kGemmBM = 128, kGemmBN = 128;
 
-__device__ __forceinline__ int swz_off(int row, int slot) { return row * 64 + ((slot ^ (((row >> 3) & 1) * 3)) << 4); }
+// LDS image of a [128][BK] fp16 tile: 16-byte slot s of row r at r * (2 BK) + ((s ^ f(r)) << 4); conflict-free ds_read_b128
+// (BK = 32: 64-B rows, f = 3 * bit3(r); BK = 64: 128-B rows, f = r & 7)
+template <int BK>
+__device__ __forceinline__ int swz_off(int row, int slot) {
+    if (BK == 32) return row * 64 + ((slot ^ (((row >> 3) & 1) * 3)) << 4);
+    return row * 128 + ((slot ^ (row & 7)) << 4);
+}
 
-template <int EPI>
+template <int EPI, int BK>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                                                       const float* __restrict__ bias, _Float16* __restrict__ C, int M, int N,
                                                       int K) {
-    __shared__ __attribute__((aligned(16))) char lds[4 * kGemmTileBytes];  // [stage][A | W]
+    constexpr int kTileBytes = kGemmBM * BK * 2;   // per operand per stage
+    constexpr int kSlots = BK / 8;                 // 16-byte slots per row
+    constexpr int kLoads = 128 * kSlots / 256;     // staging loads per thread per operand (2 or 4)
+    __shared__ __attribute__((aligned(16))) char lds[4 * kTileBytes];  // [stage][A | W]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     const int c = lane & 15, g = lane >> 4;
     const int bm = blockIdx.y * kGemmBM, bn = blockIdx.x * kGemmBN;
-    // staging: unit u = tid + 256 i -> row u >> 2, 16-byte slot u & 3
-    int st_row[2], st_slot[2];
-    const _Float16* a_src[2];
-    const _Float16* w_src[2];
+    int st_off[kLoads];
+    const _Float16* a_src[kLoads];
+    const _Float16* w_src[kLoads];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kLoads; ++i) {
         const int u = tid + 256 * i;
-        st_row[i] = u >> 2;
-        st_slot[i] = u & 3;
-        const int ar = bm + st_row[i] < M ? bm + st_row[i] : M - 1;  // clamped rows are computed and discarded
-        const int wrow = bn + st_row[i] < N ? bn + st_row[i] : N - 1;
-        a_src[i] = A + (size_t)ar * K + st_slot[i] * 8;
-        w_src[i] = W + (size_t)wrow * K + st_slot[i] * 8;
+        const int row = u / kSlots, slot = u % kSlots;
+        st_off[i] = swz_off<BK>(row, slot);
+        const int ar = bm + row < M ? bm + row : M - 1;  // clamped rows are computed and discarded
+        const int wrow = bn + row < N ? bn + row : N - 1;
+        a_src[i] = A + (size_t)ar * K + slot * 8;
+        w_src[i] = W + (size_t)wrow * K + slot * 8;
     }
     f32x4 acc[4][4];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int KT = K / kGemmBK;
-    half8 ra[2], rw[2];
+    const int KT = K / BK;
+    half8 ra[kLoads], rw[kLoads];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kLoads; ++i) {
         ra[i] = *reinterpret_cast<const half8*>(a_src[i]);
         rw[i] = *reinterpret_cast<const half8*>(w_src[i]);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        *reinterpret_cast<half8*>(lds + swz_off(st_row[i], st_slot[i])) = ra[i];
-        *reinterpret_cast<half8*>(lds + kGemmTileBytes + swz_off(st_row[i], st_slot[i])) = rw[i];
+    for (int i = 0; i < kLoads; ++i) {
+        *reinterpret_cast<half8*>(lds + st_off[i]) = ra[i];
+        *reinterpret_cast<half8*>(lds + kTileBytes + st_off[i]) = rw[i];
     }
     __syncthreads();
-    const int frag = swz_off(c, g);  // row base multiple of 16 keeps bit3(row) = bit3(c)
     for (int kt = 0; kt < KT; ++kt) {
-        const char* cur = lds + (kt & 1) * 2 * kGemmTileBytes;
-        char* nxt = lds + ((kt + 1) & 1) * 2 * kGemmTileBytes;
+        const char* cur = lds + (kt & 1) * 2 * kTileBytes;
+        char* nxt = lds + ((kt + 1) & 1) * 2 * kTileBytes;
         if (kt + 1 < KT) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ra[i] = *reinterpret_cast<const half8*>(a_src[i] + (size_t)(kt + 1) * kGemmBK);
-                rw[i] = *reinterpret_cast<const half8*>(w_src[i] + (size_t)(kt + 1) * kGemmBK);
+            for (int i = 0; i < kLoads; ++i) {
+                ra[i] = *reinterpret_cast<const half8*>(a_src[i] + (size_t)(kt + 1) * BK);
+                rw[i] = *reinterpret_cast<const half8*>(w_src[i] + (size_t)(kt + 1) * BK);
             }
         }
-        half8 a[4], b[4];
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) a[mi] = *reinterpret_cast<const half8*>(cur + (wr * 64 + mi * 16) * 64 + frag);
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            half8 a[4], b[4];
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-            b[ni] = *reinterpret_cast<const half8*>(cur + kGemmTileBytes + (wc * 64 + ni * 16) * 64 + frag);
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 4; ++mi) a[mi] = *reinterpret_cast<const half8*>(cur + swz_off<BK>(wr * 64 + mi * 16 + c, kk * 4 + g));
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                b[ni] = *reinterpret_cast<const half8*>(cur + kTileBytes + swz_off<BK>(wc * 64 + ni * 16 + c, kk * 4 + g));
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
         if (kt + 1 < KT) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                *reinterpret_cast<half8*>(nxt + swz_off(st_row[i], st_slot[i])) = ra[i];
-                *reinterpret_cast<half8*>(nxt + kGemmTileBytes + swz_off(st_row[i], st_slot[i])) = rw[i];
+            for (int i = 0; i < kLoads; ++i) {
+                *reinterpret_cast<half8*>(nxt + st_off[i]) = ra[i];
+                *reinterpret_cast<half8*>(nxt + kTileBytes + st_off[i]) = rw[i];
             }
         }
         __syncthreads();
@@ -244,6 +288,110 @@ __global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restri
         __builtin_amdgcn_wave_barrier();
     }
 }
+
+// ---- attention on the matrix cores (head size 64, L <= 256): one workgroup per (sequence, head), one wave per block of
+// 32 queries.  S^T = K . Q^T with v_mfma_f32_32x32x16_f16 (A = keys, B = queries: a lane then holds ONE query's scores
+// for 16 keys per 32-key block in registers, so the softmax is register-local plus one cross-half shuffle); the
+// normalised probabilities, converted to fp16, are used straight from the accumulator registers as the A operand of
+// P . V (X^T . B form: no lane movement), with V read from a transposed LDS image in the matching permuted key order.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kAttDh = 64;
+constexpr int kAttMaxBlocks = 8;  // L <= 256
+
+template <int NQB>
+__global__ __launch_bounds__(64 * NQB) void attention_mfma_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ mask,
+                                                                   int L, int H, int heads, _Float16* __restrict__ ctx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int Lp = NQB * 32;
+    constexpr int kVtStride = Lp + 8;  // halves per dim row (+16 B so that consecutive dims start on different banks)
+    _Float16* vt = reinterpret_cast<_Float16*>(smem);  // [64][kVtStride]
+    const int seq = blockIdx.x / heads, head = blockIdx.x - seq * heads;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const size_t row_stride = (size_t)3 * H;
+    const _Float16* base = qkv + (size_t)seq * L * row_stride + head * kAttDh;
+    // V -> LDS, transposed (keys beyond L are zero)
+    for (int i = tid; i < Lp * 8; i += 64 * NQB) {
+        const int key = i >> 3, ch = i & 7;
+        half8 v = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (key < L) v = *reinterpret_cast<const half8*>(base + (size_t)key * row_stride + 2 * H + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vt[(ch * 8 + e) * kVtStride + key] = v[e];
+    }
+    const int qb = wave;
+    const int qrow = qb * 32 + li < L ? qb * 32 + li : L - 1;  // padded query rows recompute the last row, never stored
+    half8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const half8*>(base + (size_t)qrow * row_stride + kk * 16 + h * 8);
+    f32x16 st[NQB];
+    const float scale = rsqrtf((float)kAttDh);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < NQB; ++kb) {
+        const int key = kb * 32 + li;
+        const int krow = key < L ? key : L - 1;
+        f32x16 acc = {};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const half8 kf = *reinterpret_cast<const half8*>(base + (size_t)krow * row_stride + H + kk * 16 + h * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], acc, 0, 0, 0);
+        }
+        // key validity of this block as a wave-uniform bit mask (bit = key index inside the block)
+        const int valid = key < L && mask[seq * L + (key < L ? key : 0)] != 0;
+        const unsigned long long bal = __ballot(valid);
+        const unsigned int kmask = (unsigned int)(bal & 0xFFFFFFFFull);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int kidx = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float sv = ((kmask >> kidx) & 1u) ? acc[r] * scale : -INFINITY;  // HF adds finfo.min: weight exactly 0
+            acc[r] = sv;
+            mx = fmaxf(mx, sv);
+        }
+        st[kb] = acc;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < NQB; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __expf(st[kb][r] - mx);
+            st[kb][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    __syncthreads();  // V^T image complete
+    f32x16 o[2] = {};
+#pragma unroll
+    for (int kb = 0; kb < NQB; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            half8 pf;  // accumulator registers 8 s2 .. 8 s2 + 7 -> k-step s2 of the A operand (X^T . B form)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (_Float16)(st[kb][8 * s2 + j] * inv);
+            // element j of lane half h is key kb*32 + 16 s2 + 8 (j >> 2) + 4 h + (j & 3): V must use the same order
+            const int k0 = kb * 32 + 16 * s2 + 4 * h;
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const _Float16* vrow = vt + (db * 32 + li) * kVtStride + k0;
+                typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+                const half4 lo = *reinterpret_cast<const half4*>(vrow);
+                const half4 hi = *reinterpret_cast<const half4*>(vrow + 8);
+                const half8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, vf, o[db], 0, 0, 0);
+            }
+        }
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (q < L) ctx[((size_t)seq * L + q) * H + head * kAttDh + db * 32 + li] = (_Float16)o[db][r];
+        }
+}
+
+constexpr int kMaxPer = 32;  // hidden <= 2048 (pooling keeps element j = lane + 64 i per lane)
 
 __global__ __launch_bounds__(256) void pool_normalize_kernel(const _Float16* __restrict__ hidden, const int* __restrict__ mask,
                                                              int B, int L, int H, int pooling, int normalize,
@@ -370,7 +518,10 @@ int upload_f16(vqa_encoder* e, const float* src, size_t n, _Float16* dst) {
 template <int EPI>
 int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, _Float16* C, int M, int N, int K, hipStream_t s) {
     dim3 grid((N + kGemmBN - 1) / kGemmBN, (M + kGemmBM - 1) / kGemmBM);
-    hipLaunchKernelGGL(gemm_nt_kernel<EPI>, grid, dim3(256), 0, s, A, W, bias, C, M, N, K);
+    if (K % 64 == 0)
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI, 64>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K);
+    else
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI, 32>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }
@@ -389,8 +540,8 @@ extern "C" int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encod
     VQA_REQUIRE(out, "vqa_encoder_create: out is null");
     *out = nullptr;
     VQA_REQUIRE(cfg && w && w->layer, "vqa_encoder_create: null config / weights");
-    VQA_REQUIRE(cfg->hidden >= 32 && cfg->hidden <= 64 * kMaxPer && cfg->hidden % 32 == 0, "vqa_encoder_create: hidden=%d must be a multiple of 32 in [32, %d]",
-                cfg->hidden, 64 * kMaxPer);
+    VQA_REQUIRE(cfg->hidden >= 32 && cfg->hidden <= 2048 && cfg->hidden % 32 == 0,
+                "vqa_encoder_create: hidden=%d must be a multiple of 32 in [32, 2048]", cfg->hidden);
     VQA_REQUIRE(cfg->ffn >= 32 && cfg->ffn % 32 == 0, "vqa_encoder_create: ffn=%d must be a multiple of 32", cfg->ffn);
     VQA_REQUIRE(cfg->heads >= 1 && cfg->hidden % cfg->heads == 0 && cfg->hidden / cfg->heads <= 128,
                 "vqa_encoder_create: heads=%d does not divide hidden=%d into head sizes <= 128", cfg->heads, cfg->hidden);
@@ -493,7 +644,21 @@ extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, con
     for (const vqa_encoder::Layer& Ly : e->layers) {
         int rc = launch_gemm<0>(e->x, Ly.wqkv, Ly.bqkv, e->qkv, T, 3 * H, H, s);
         if (rc != VQA_OK) return rc;
-        hipLaunchKernelGGL(attention_kernel, dim3(B * heads), dim3(256), attn_lds, s, e->qkv, attn_mask, L, H, heads, e->ctx);
+        if (dh == kAttDh && L <= 32 * kAttMaxBlocks) {
+            const int nqb = (L + 31) / 32;
+            const size_t lds = (size_t)kAttDh * (nqb * 32 + 8) * sizeof(_Float16);
+#define VQA_ATT(NQB)                                                                                                   \
+    case NQB:                                                                                                          \
+        hipLaunchKernelGGL(attention_mfma_kernel<NQB>, dim3(B * heads), dim3(64 * NQB), lds, s, e->qkv, attn_mask, L, H, heads, \
+                           e->ctx);                                                                                   \
+        break;
+            switch (nqb) {
+                VQA_ATT(1) VQA_ATT(2) VQA_ATT(3) VQA_ATT(4) VQA_ATT(5) VQA_ATT(6) VQA_ATT(7) VQA_ATT(8)
+            }
+#undef VQA_ATT
+        } else {
+            hipLaunchKernelGGL(attention_kernel, dim3(B * heads), dim3(256), attn_lds, s, e->qkv, attn_mask, L, H, heads, e->ctx);
+        }
         VQA_HIP_CHECK(hipGetLastError());
         if ((rc = launch_gemm<0>(e->ctx, Ly.wo, Ly.bo, e->tmp, T, H, H, s)) != VQA_OK) return rc;
         hipLaunchKernelGGL(add_ln_kernel, dim3(row_blocks), dim3(256), 0, s, e->tmp, e->x, T, H, Ly.ln1_g, Ly.ln1_b, eps, e->x);

@@ -43,8 +43,8 @@ typedef long long i64x2 __attribute__((ext_vector_type(2)));
 
 // One K-step (64 bytes of every row) of one 16 x 16 accumulator tile.  Which k index sits in which byte is irrelevant as
 // long as rows and queries are read the same way, so a lane's 16-byte fragment feeds sub-step t of every MFMA chain:
-//   fp16: 1 x v_mfma_f32_16x16x32_f16 (8 halves);  fp8: 2 x v_mfma_f32_16x16x32_fp8_fp8 (8 bytes each);
-//   fp32: 4 x v_mfma_f32_16x16x4_f32 (1 float each).  T = sub-step.
+//   fp16: 1 x v_mfma_f32_16x16x32_f16 (8 halves);  fp32: 4 x v_mfma_f32_16x16x4_f32 (1 float each);  T = sub-step.
+//   (fp8 pairs the fragments of two K-steps for the block-scaled MFMA, see mma_block_mx.)
 template <int DT>
 struct MfmaTraits;
 template <>
@@ -55,16 +55,6 @@ struct MfmaTraits<VQA_F16> {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
     }
 };
-template <>
-struct MfmaTraits<VQA_FP8_E4M3> {  // plain fp8 MFMA (fp16 rate); the kernel uses the block-scaled form below instead
-    static constexpr int kSub = 2;
-    template <int T>
-    static __device__ __forceinline__ f32x4 mma(frag_t a, frag_t b, f32x4 c) {
-        const i64x2 a2 = __builtin_bit_cast(i64x2, a), b2 = __builtin_bit_cast(i64x2, b);
-        return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(a2[T], b2[T], c, 0, 0, 0);
-    }
-};
-
 template <>
 struct MfmaTraits<VQA_F32> {
     static constexpr int kSub = 4;
