@@ -99,10 +99,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the measured path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one process per GPU; VQA_BENCH_SHARE_GPU=1 (dev only) lets several ranks share a device to exercise the N > 1 path
+    # on a 1-GPU box (then over gloo, since RCCL refuses two ranks on one device)
+    share = os.environ.get("VQA_BENCH_SHARE_GPU") == "1"
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
+    local_rank_dev = dev_index
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     from vietnamese_qa_system_amd import build
     if local_rank == 0:
@@ -114,7 +122,7 @@ def main():
 
     n, d, b, k = args.docs_per_gpu, args.dim, args.batch, args.k
     shard = build_shard(n, d, 1234 + rank, device, args.dtype)
-    index = DeviceIndex(shard, id_base=1 + rank * n, dtype=args.dtype, device=local_rank)
+    index = DeviceIndex(shard, id_base=1 + rank * n, dtype=args.dtype, device=local_rank_dev)
     gq = torch.Generator(device=device)
     gq.manual_seed(99)
     q = torch.randn((b, d), generator=gq, device=device, dtype=torch.float32)
@@ -184,7 +192,7 @@ def main():
         # the fp8 oracle encodes every row on the CPU (slow): it checks a 2M-row prefix through a second, prefix-only index
         vrows = n if args.dtype != "fp8" else min(n, 2_000_000)
         if vrows < n:
-            pre = DeviceIndex(shard[:vrows], id_base=1, dtype=args.dtype, device=local_rank)
+            pre = DeviceIndex(shard[:vrows], id_base=1, dtype=args.dtype, device=local_rank_dev)
             s_gpu, i_gpu, p_gpu = pre.search(q, k, return_positions=True)
             torch.cuda.synchronize(device)
             pre.close()

@@ -110,22 +110,13 @@ __device__ __forceinline__ void mma_block(f32x4 (&acc)[8][4], const frag_t (&a)[
 
 typedef __attribute__((address_space(3))) char* lds_char_ptr;
 
-#ifndef VQA_SINGLE_SET
-#define VQA_SINGLE_SET 0  // dev A/B: 1 = the fp16 loop without the second fragment register set
-#endif
-
 constexpr int kThreads = 512;           // 8 waves: 2 (row halves = ping-pong groups) x 4 (query quarters)
 constexpr int kTileRows = 256;          // corpus rows per tile
 constexpr int kQ = VQA_QUERY_TILE;      // 256 queries per tile
 constexpr int kRowBytes = 64;           // bytes of every row per K-step (32 fp16 / 64 fp8 / 16 fp32 elements)
 constexpr int kOperandBytes = 256 * kRowBytes;  // 16 KiB: one operand slice (256 rows x one K-step)
-#ifndef VQA_RING_ALT
 constexpr int kSx = 6, kPx = 5;  // X ring: stages, K-steps issued ahead (HBM stream: deep); one stage idles per K-step
 constexpr int kSq = 2, kPq = 2;  // Q ring: stages, K-steps issued ahead (L2 resident: shallow)
-#else
-constexpr int kSx = 5, kPx = 4;
-constexpr int kSq = 3, kPq = 2;
-#endif
 constexpr int kXRingBytes = kSx * kOperandBytes;
 constexpr int kQRingBytes = kSq * kOperandBytes;
 constexpr int kPipeBytes = kXRingBytes + kQRingBytes;  // 128 KiB
@@ -394,8 +385,8 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
 #endif
 #define VQA_MMA(A, B) VQA_MMA_RANGE(A, B, 0, 8)
 #ifndef VQA_SPLIT
-#define VQA_SPLIT 4  // matrix-first group: row groups multiplied before its memory instructions are issued (of 8)
-#endif
+#define VQA_SPLIT 4  // matrix-first group: row groups multiplied before its memory instructions are issued (of 8); 3 / 5 / 8
+#endif               // measured 0.6 / 1.3 / 7 % slower on one device
 #if VQA_ABLATE & 1
 #define VQA_ISSUE() (void)0
 #elif VQA_ABLATE & 32
@@ -507,7 +498,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         } else {
         // (the first fragments of this tile were read before the loop / under the previous tile's last K-step, so their
         // LDS latency and the pipeline refill hide under the previous tile's epilogue)
-        if constexpr (DT == VQA_F16 && !VQA_SINGLE_SET) {
+        if constexpr (DT == VQA_F16) {
             frag_t a1[8], b1[4];  // second register set: the next K-step's fragments load under this K-step's MFMAs
             for (int kt = 0; kt < KT; kt += 2) {  // KT is even (rows are padded to two K-steps)
                 const int kappa = ti * KT + kt;
