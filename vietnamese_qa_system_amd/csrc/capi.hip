@@ -37,6 +37,7 @@ struct vqa_index {
     int num_cu = 0;
     int max_grid = 0;
     bool two_pass = true;
+    int seed_mult = 2;  // seed pass covers seed_mult * CUs tiles (VQA_SEED_MULT = 1..4)
     // workspace (allocated once; search never allocates)
     void* q_stage = nullptr;     // one 256-row tile in TILED layout
     void* q_rows = nullptr;      // staging for host -> device row chunks in set_rows (lazy)
@@ -162,6 +163,8 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
     ix->max_grid = ix->num_cu;
     const char* tp = getenv("VQA_TWO_PASS");
     ix->two_pass = !(tp && tp[0] == '0');
+    const char* sm = getenv("VQA_SEED_MULT");
+    if (sm && sm[0] >= '1' && sm[0] <= '4') ix->seed_mult = sm[0] - '0';
     const int eb = elem_bytes(dtype);
     int rc = VQA_OK;
     do {
@@ -193,7 +196,7 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
         const int max_k = vqa_score_topk_max_k(dtype);
         const int list_len = max_k > vqa_score_topk_seeds_per_query() ? max_k : vqa_score_topk_seeds_per_query();
         if (hipMalloc(&ix->q_stage, (size_t)VQA_QUERY_TILE * ix->d_pad * eb) != hipSuccess ||
-            hipMalloc((void**)&ix->partial, (size_t)ix->max_grid * VQA_QUERY_TILE * list_len * sizeof(vqa_key)) != hipSuccess ||
+            hipMalloc((void**)&ix->partial, (size_t)4 * ix->max_grid * VQA_QUERY_TILE * list_len * sizeof(vqa_key)) != hipSuccess ||
             hipMalloc((void**)&ix->thr0, VQA_QUERY_TILE * sizeof(float)) != hipSuccess ||
             hipMalloc((void**)&ix->upper, VQA_QUERY_TILE * sizeof(vqa_key)) != hipSuccess) {
             vqa_set_error("vqa_index_create: workspace allocation failed");
@@ -267,11 +270,15 @@ static LaunchPlan plan_launch(const vqa_index* ix) {
     LaunchPlan p;
     p.tiles = (int)((ix->n + 255) / 256);
     p.grid1 = p.tiles < ix->max_grid ? p.tiles : ix->max_grid;
-    // Seed pass: the first min(tiles, CUs) tiles are scored once more by the MODE 0 kernel, which only keeps 16
+    // Seed pass: the first min(tiles, seed_mult * CUs) tiles are scored once more by the MODE 0 kernel, which only keeps 16
     // sub-maxima per query and tile; their k-th largest is a valid lower bound of the k-th best score and seeds every
     // workgroup's thresholds, so the main pass appends ~k / (256 * grid) of the scores instead of flooding its
-    // candidate lists on each workgroup's first tiles.  Costs <= 256 tiles of extra scoring (0.65 % at 10M rows).
-    if (ix->two_pass) p.grid0 = p.grid1;
+    // candidate lists on each workgroup's first tiles.  Costs <= 512 tiles of extra scoring (1.3 % at 10M rows) and halves
+    // the appends of the main pass against 256 seed tiles (measured: net gain).
+    if (ix->two_pass) {
+        const int want = ix->seed_mult * ix->max_grid;  // more seed tiles = tighter starting thresholds = fewer appends
+        p.grid0 = p.tiles < want ? p.tiles : want;
+    }
     return p;
 }
 

@@ -126,7 +126,17 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
     VQA_REQUIRE(parts >= 1 && list_len >= 1 && nq >= 1 && nq <= VQA_QUERY_TILE && k >= 1,
                 "merge_partials: bad shape parts=%d list_len=%d nq=%d k=%d", parts, list_len, nq, k);
     const size_t lds = ((size_t)parts * list_len + 4) * sizeof(vqa_key);
-    VQA_REQUIRE(lds <= 64 * 1024, "merge_partials: %d lists x %d keys do not fit in LDS", parts, list_len);
+    VQA_REQUIRE(lds <= 160 * 1024, "merge_partials: %d lists x %d keys do not fit in LDS", parts, list_len);
+    if (lds > 64 * 1024) {
+        static bool attr_set_dev[64] = {};
+        int dev = 0;
+        VQA_HIP_CHECK(hipGetDevice(&dev));
+        if (!attr_set_dev[dev & 63]) {
+            VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(merge_partials_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr_set_dev[dev & 63] = true;
+        }
+    }
     hipLaunchKernelGGL(merge_partials_kernel, dim3(nq), dim3(kMergeThreads), lds, stream, partial, parts, list_len, k,
                        reinterpret_cast<const long long*>(ids), (long long)id_base, out_scores,
                        reinterpret_cast<long long*>(out_ids), reinterpret_cast<long long*>(out_pos), out_thr, score_scale,
