@@ -1,0 +1,13 @@
+"""Dev helper: build several -D variants of the library in parallel.  usage: build_variants.py tag:DEF=1,DEF2=3 ..."""
+import os, sys
+from concurrent.futures import ThreadPoolExecutor
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from vietnamese_qa_system_amd import build as b
+
+def one(spec):
+    tag, _, defs = spec.partition(":")
+    return b.build_variant(tag, [d for d in defs.split(",") if d])
+
+with ThreadPoolExecutor(max_workers=3) as ex:
+    for out in ex.map(one, sys.argv[1:]):
+        print(out)

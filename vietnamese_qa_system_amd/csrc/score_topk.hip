@@ -33,6 +33,9 @@
 // 32 no Q pieces, 64 no loop barrier
 #define VQA_ABLATE 0
 #endif
+#ifndef VQA_XNT
+#define VQA_XNT 1  // the index stream (read once per search) is loaded with the nt policy: measured 1.7 % faster at 10M rows
+#endif
 
 namespace {
 
@@ -225,20 +228,36 @@ __device__ __forceinline__ bool process_pending(const Lists& L, const f32x4 (&ac
 // LDS address = lds_dst + i * 1024 + lane * 16 (M0 base + instruction offset + lane * 16, added by hardware): the
 // instruction offset moves both sides, so one M0 write serves the four.  Inline asm so that hipcc keeps no scoreboard
 // entry for the loads: all ordering is by the counted vmcnt waits below.  sbase / lds_dst are SALU-computed.
+template <bool NT>
 __device__ __forceinline__ void glds16x4(const void* sbase, uint32_t voff, uint32_t lds_dst) {
     uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
-        "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(sbase), "s"(lds_dst)
-        : "memory");
+    if constexpr (NT) {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2 nt\n\t"
+            "global_load_lds_dwordx4 %1, %2 offset:1024 nt\n\t"
+            "global_load_lds_dwordx4 %1, %2 offset:2048 nt\n\t"
+            "global_load_lds_dwordx4 %1, %2 offset:3072 nt\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(sbase), "s"(lds_dst)
+            : "memory");
+    } else {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2\n\t"
+            "global_load_lds_dwordx4 %1, %2 offset:1024\n\t"
+            "global_load_lds_dwordx4 %1, %2 offset:2048\n\t"
+            "global_load_lds_dwordx4 %1, %2 offset:3072\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(sbase), "s"(lds_dst)
+            : "memory");
+    }
 }
 
 template <int N>
@@ -299,7 +318,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     uint32_t i_dst = (wm ? xring_lds : qring_lds) + lw * 4096;
     auto issue_x = [&]() {
         if (ik >= total) return;
-        glds16x4(x_src, voff, i_dst);
+        glds16x4<VQA_XNT != 0>(x_src, voff, i_dst);
         ++ik;
         x_src += kOperandBytes;
         if (++i_kt == KT) {
@@ -311,7 +330,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     };
     auto issue_q = [&]() {
         if (ik >= total) return;
-        glds16x4(q_src, voff, i_dst);
+        glds16x4<false>(q_src, voff, i_dst);
         ++ik;
         q_src += kOperandBytes;
         if (++i_kt == KT) {
