@@ -106,7 +106,7 @@ typedef struct vqa_launch_info {
     int64_t rows_per_launch;  /* corpus rows the MAIN scoring kernel covers (n minus the rows of the seeding pass) */
     int64_t bytes_per_launch; /* algorithmic bytes of that launch: rows_per_launch * d * sizeof(element) */
     int64_t flops_per_launch; /* 2 * VQA_QUERY_TILE * rows_per_launch * d */
-    int32_t seed_grid;        /* workgroups (= tiles) of the seeding pass, 0 when the search is single pass */
+    int32_t seed_grid;        /* workgroups of the seeding pass (a few tiles each), 0 when the search is single pass */
     int32_t reserved;
 } vqa_launch_info;
 int vqa_index_launch_info(const vqa_index* index, int32_t B, int32_t k, vqa_launch_info* out);

@@ -194,7 +194,7 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
             }
         }
         const int max_k = vqa_score_topk_max_k(dtype);
-        const int list_len = max_k > vqa_score_topk_seeds_per_query() ? max_k : vqa_score_topk_seeds_per_query();
+        const int list_len = max_k;  // main pass lists [max_grid][256][k <= max_k]; the seed pass needs 4 * max_grid * 256 * 2 keys at most
         if (hipMalloc(&ix->q_stage, (size_t)VQA_QUERY_TILE * ix->d_pad * eb) != hipSuccess ||
             hipMalloc((void**)&ix->partial, (size_t)4 * ix->max_grid * VQA_QUERY_TILE * list_len * sizeof(vqa_key)) != hipSuccess ||
             hipMalloc((void**)&ix->thr0, VQA_QUERY_TILE * sizeof(float)) != hipSuccess ||
@@ -262,7 +262,8 @@ extern "C" int32_t vqa_index_dtype(const vqa_index* ix) { return ix ? ix->dtype 
 
 struct LaunchPlan {
     int tiles = 0;  // corpus tiles of 256 rows
-    int grid0 = 0;  // workgroups (= tiles) of the seed pass, 0 = no seeding
+    int seed_tiles = 0;  // tiles of the seed pass, 0 = no seeding
+    int grid0 = 0;  // its workgroups (a few tiles each)
     int grid1 = 0;  // workgroups of the main pass
 };
 
@@ -270,14 +271,15 @@ static LaunchPlan plan_launch(const vqa_index* ix) {
     LaunchPlan p;
     p.tiles = (int)((ix->n + 255) / 256);
     p.grid1 = p.tiles < ix->max_grid ? p.tiles : ix->max_grid;
-    // Seed pass: the first min(tiles, seed_mult * CUs) tiles are scored once more by the MODE 0 kernel, which only keeps 16
+    // Seed pass: the first min(tiles, seed_mult * CUs) tiles are scored once more by the MODE 0 kernel, which only keeps 2
     // sub-maxima per query and tile; their k-th largest is a valid lower bound of the k-th best score and seeds every
     // workgroup's thresholds, so the main pass appends ~k / (256 * grid) of the scores instead of flooding its
     // candidate lists on each workgroup's first tiles.  Costs <= 512 tiles of extra scoring (1.3 % at 10M rows) and halves
     // the appends of the main pass against 256 seed tiles (measured: net gain).
     if (ix->two_pass) {
         const int want = ix->seed_mult * ix->max_grid;  // more seed tiles = tighter starting thresholds = fewer appends
-        p.grid0 = p.tiles < want ? p.tiles : want;
+        p.seed_tiles = p.tiles < want ? p.tiles : want;
+        p.grid0 = p.seed_tiles < ix->max_grid ? p.seed_tiles : ix->max_grid;
     }
     return p;
 }
@@ -354,7 +356,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             for (int done = 0; done < k; done += max_k) {
                 const int kk = k - done < max_k ? k - done : max_k;
                 int rc = vqa_launch_merge_partials(ix->partial, 1, max_k, nq, kk, ix->ids, ix->id_base, os, oi, op, nullptr, 1.0f, k,
-                                                   done, nullptr, stream);
+                                                   done, nullptr, false, stream);
                 if (rc != VQA_OK) return rc;
             }
             continue;
@@ -379,13 +381,13 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
                 a.thr_init = nullptr;
                 a.partial = ix->partial;
                 a.tile_begin = 0;
-                a.tile_end = p.grid0;
+                a.tile_end = p.seed_tiles;
                 a.grid = p.grid0;
                 a.seed_only = true;
                 rc = vqa_launch_score_topk(ix->dtype, a, stream);
                 if (rc != VQA_OK) return rc;
-                rc = vqa_launch_merge_partials(ix->partial, p.grid0, vqa_score_topk_seeds_per_query(), nq, kk, nullptr, 0, nullptr,
-                                               nullptr, nullptr, ix->thr0, 1.0f, kk, 0, nullptr, stream);
+                rc = vqa_launch_merge_partials(ix->partial, p.seed_tiles, vqa_score_topk_seeds_per_tile(), nq, kk, nullptr, 0, nullptr,
+                                               nullptr, nullptr, ix->thr0, 1.0f, kk, 0, nullptr, true, stream);
                 if (rc != VQA_OK) return rc;
             }
             a.thr_init = p.grid0 > 0 ? ix->thr0 : nullptr;
@@ -399,7 +401,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             if (rc != VQA_OK) return rc;
             if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
             rc = vqa_launch_merge_partials(ix->partial, p.grid1, kk, nq, kk, ix->ids, ix->id_base, os, oi, op, nullptr,
-                                           1.0f / (ix->scale * ix->scale), k, done, done + kk < k ? ix->upper : nullptr, stream);
+                                           1.0f / (ix->scale * ix->scale), k, done, done + kk < k ? ix->upper : nullptr, false, stream);
             if (rc != VQA_OK) return rc;
         }
     }

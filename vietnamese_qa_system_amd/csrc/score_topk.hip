@@ -19,8 +19,8 @@
 // atomic; lists are compacted (rank-by-counting inside one wave) when they fill.  No B x N score matrix exists.
 //
 // Two instantiations:
-//   MODE 0 "seed": one tile per workgroup; writes, per query, the 16 sub-maxima of the tile (valid lower bounds:
-//                  each is the score of a distinct row); K2 turns their k-th largest into starting thresholds.
+//   MODE 0 "seed": a few tiles per workgroup; writes, per query and tile, two sub-maxima (valid lower bounds: each is
+//                  the score of a distinct row); K2 turns their k-th largest into starting thresholds.
 //   MODE 1 "main": all tiles, thresholds seeded; flushes per-workgroup sorted top-k lists for K2 to merge.
 #include <type_traits>
 #include <utility>
@@ -127,7 +127,7 @@ constexpr int kLdsTotal = 160 * 1024;
 constexpr int kCap = (kLdsTotal - kPipeBytes - 2 * kQ * 4) / (kQ * 8);  // 15 candidate slots per query
 constexpr int kExt = kOperandBytes / (kQ * 8);                           // 8 more in the idle X stage during an epilogue
 constexpr int kMaxK = kCap - 3;                                         // 12
-constexpr int kSeedsPerQuery = 16;
+constexpr int kSeedsPerTile = 2;  // seed pass: sub-maxima kept per query and tile (one per row half)
 static_assert(kPipeBytes == 128 * 1024, "ring sizes");
 
 constexpr int kOverBit = 1 << 30;  // "an append was refused" flag, kept in bit 30 of cnt[0] (LDS is fully used)
@@ -558,30 +558,34 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
                 }
         }
         if (MODE == 0) {
-            // 16 sub-maxima per query and tile: (row half wm, lane group g, mi half) -> seeds [tile][query][16]
-            vqa_key* seeds = out + (size_t)blockIdx.x * kQ * kSeedsPerQuery;
+            // two sub-maxima per query and tile (one per row half wm) -> seeds [query][seed tile][2].  Each is the score of
+            // a distinct row, so the k-th largest of any k of them bounds the k-th best score from below.
+            const int seed_tiles = tile_end - tile_begin;
+            const int tile_local = first_tile - tile_begin + ti * (int)gridDim.x;
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 const int q = wn * 64 + ni * 16 + c;
                 const vqa_key up = upper ? upper[q] : ~0ull;
+                float m = -INFINITY;
+                int arg = 0;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    float m = -INFINITY;
-                    int arg = 0;
+                for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-                    for (int mi = 4 * h; mi < 4 * h + 4; ++mi)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int r = wm * 128 + mi * 16 + g * 4 + j;
-                            const float v = acc[mi][ni][j];
-                            if (v > m && (!upper || vqa_make_key(v, row0 + (uint32_t)r) < up)) {
-                                m = v;
-                                arg = r;
-                            }
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = wm * 128 + mi * 16 + g * 4 + j;
+                        const float v = acc[mi][ni][j];
+                        if (v > m && (!upper || vqa_make_key(v, row0 + (uint32_t)r) < up)) {
+                            m = v;
+                            arg = r;
                         }
-                    const bool valid = m > -INFINITY && q < nq;
-                    seeds[q * kSeedsPerQuery + wm * 8 + g * 2 + h] = valid ? vqa_make_key(m, row0 + (uint32_t)arg) : 0ull;
-                }
+                    }
+                vqa_key key = (m > -INFINITY && q < nq) ? vqa_make_key(m, row0 + (uint32_t)arg) : 0ull;
+                // max over the four lane groups g that hold the other rows of this query (lanes c, c + 16, c + 32, c + 48)
+                vqa_key o = __shfl_xor(key, 16, 64);
+                key = o > key ? o : key;
+                o = __shfl_xor(key, 32, 64);
+                key = o > key ? o : key;
+                if (g == 0) out[((size_t)q * seed_tiles + tile_local) * kSeedsPerTile + wm] = key;
             }
             continue;
         }
@@ -679,7 +683,7 @@ int vqa_score_topk_max_k(int dtype) {
     return kMaxK;
 }
 
-int vqa_score_topk_seeds_per_query() { return kSeedsPerQuery; }
+int vqa_score_topk_seeds_per_tile() { return kSeedsPerTile; }
 
 template <int DT>
 static int launch_dt(const ScoreTopkArgs& a, int KT, int lds, hipStream_t stream) {
@@ -709,7 +713,6 @@ int vqa_launch_score_topk(int dtype, const ScoreTopkArgs& a, hipStream_t stream)
     VQA_REQUIRE(a.k >= 1 && a.k <= kMaxK, "score_topk: k=%d outside [1, %d]", a.k, kMaxK);
     VQA_REQUIRE(a.nq >= 1 && a.nq <= kQ, "score_topk: nq=%d outside [1, %d]", a.nq, kQ);
     VQA_REQUIRE(a.grid >= 1 && a.tile_end > a.tile_begin, "score_topk: empty launch");
-    VQA_REQUIRE(!a.seed_only || a.tile_end - a.tile_begin <= a.grid, "score_topk: the seed pass takes one tile per workgroup");
     const int lds = vqa_score_topk_lds_bytes(dtype, a.k);
     const int KT = a.d_pad * esize / kRowBytes;  // even
     if (dtype == VQA_F16) return launch_dt<VQA_F16>(a, KT, lds, stream);

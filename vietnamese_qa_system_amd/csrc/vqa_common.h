@@ -59,20 +59,21 @@ struct ScoreTopkArgs {
     int32_t tile_begin;   // first corpus tile (of 256 rows) this launch covers
     int32_t tile_end;     // one past the last
     int32_t grid;         // workgroups
-    bool seed_only = false;  // MODE 0: one tile per workgroup, writes 16 sub-maxima per query and tile to `partial`
+    bool seed_only = false;  // MODE 0: writes 2 sub-maxima per query and tile to `partial` as [query][tile - tile_begin][2]
 };
 int vqa_launch_score_topk(int dtype, const ScoreTopkArgs& a, hipStream_t stream);
 int vqa_score_topk_lds_bytes(int dtype, int k);
 int vqa_score_topk_max_k(int dtype);
-int vqa_score_topk_seeds_per_query();
+int vqa_score_topk_seeds_per_tile();
 
-// `parts` key lists of `list_len` keys per query ([parts][256][list_len]) -> the k best per query:
+// `parts` key lists of `list_len` keys per query ([parts][256][list_len], or query-major) -> the k best per query:
 // final [nq, k] (scores, external ids, positions) and/or the k-th best score per query (-inf when fewer exist)
 int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t list_len, int32_t nq, int32_t k,
                               const int64_t* ids, int64_t id_base, float* out_scores, int64_t* out_ids, int64_t* out_pos,
                               float* out_thr, float score_scale /* applied to out_scores only (power of two) */,
                               int32_t out_stride /* row stride of the out arrays */, int32_t out_offset /* first column */,
                               vqa_key* out_last_key /* [nq] k-th key per query (0 when fewer exist) or nullptr */,
+                              bool query_major /* lists are [query][parts][list_len] instead of [parts][256][list_len] */,
                               hipStream_t stream);
 
 // row-major [valid, d] f32|f16 rows (device) -> TILED layout, storage type `dtype`, at rows [first, first + count);
