@@ -87,11 +87,13 @@ int vqa_index_search(vqa_index* index, const void* q, int32_t q_dtype, int32_t B
                      int64_t* out_ids, int64_t* out_pos_or_null, void* hip_stream);
 
 /* ---- merge: final step after the RCCL all-gather of per-shard candidates (new in this build; the reference is
- * single-process).  scores/ids: [R, B, k] device, each [k] list best first, padded with (-inf, -1); shards are
- * contiguous row ranges in rank order, so ties resolve by (rank asc, slot asc) = global row position asc.
- * out: [B, k_out] with k_out <= min(R*k, VQA_MAX_K * 8). */
-int vqa_merge_topk(const float* scores, const int64_t* ids, int32_t R, int32_t B, int32_t k, int32_t k_out,
-                   float* out_scores, int64_t* out_ids, void* hip_stream);
+ * single-process).  scores/ids: R blocks of [B, k] on the device, each [k] list best first, padded with (-inf, -1);
+ * block r starts at scores + r * score_rank_stride / ids + r * id_rank_stride (strides in ELEMENTS; 0 = B * k,
+ * i.e. plain [R, B, k] arrays) -- the strides let both arrays live in ONE all-gathered buffer (one collective per
+ * batch).  Shards are contiguous row ranges in rank order, so ties resolve by (rank asc, slot asc) = global row
+ * position asc.  out: [B, k_out] with k_out <= R * k <= 8192. */
+int vqa_merge_topk(const float* scores, const int64_t* ids, int64_t score_rank_stride, int64_t id_rank_stride, int32_t R,
+                   int32_t B, int32_t k, int32_t k_out, float* out_scores, int64_t* out_ids, void* hip_stream);
 
 /* ---- measurement hooks used by bench.py (roofline of the dominant kernel).  vqa_index_launch_info reports the
  * geometry of the main scoring kernel so the algorithmic bytes/flops per launch can be stated.  With timing

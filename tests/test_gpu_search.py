@@ -138,6 +138,37 @@ def test_merge_topk_matches_oracle(native_lib):
     assert np.array_equal(gi.cpu().numpy(), ei)
 
 
+def test_sharded_searcher_packs_one_gather_buffer(native_lib):
+    """The searcher's send/receive buffer layout ([ids int64 | scores f32] per rank) through the strided merge: fill the
+    receive buffer as an all-gather over 3 ranks would and compare with the oracle's shard merge; world = 1 end to end."""
+    from vietnamese_qa_system_amd.index import DeviceIndex, merge_topk
+    from vietnamese_qa_system_amd.sharded import ShardedSearcher, sharded_index_searcher
+    rng = np.random.default_rng(5)
+    world, b, k = 3, 7, 5  # b * k odd: the per-rank block is padded to 8 bytes
+    sc = np.sort(rng.standard_normal((world, b, k)).astype(np.float32), axis=2)[:, :, ::-1].copy()
+    ids = rng.integers(0, 1 << 40, size=(world, b, k)).astype(np.int64)
+    s = ShardedSearcher(lambda *a: None, merge_topk)
+    s.world = world
+    send_s, send_i, recv_s, recv_i = s._buffers(b, k, torch.device("cuda", 0))
+    assert s._send.numel() % 8 == 0 and s._recv.shape == (world, s._send.numel())
+    assert not recv_s.is_contiguous() and recv_s.shape == (world, b, k) and recv_i.shape == (world, b, k)
+    for r in range(world):  # what all_gather_into_tensor delivers: rank r's send buffer in row r
+        send_s.copy_(torch.from_numpy(sc[r]))
+        send_i.copy_(torch.from_numpy(ids[r]))
+        s._recv[r].copy_(s._send)
+    gs, gi = merge_topk(recv_s, recv_i, k)
+    es, ei = R.merge_shards(sc, ids, k)
+    assert np.array_equal(gs.cpu().numpy(), es) and np.array_equal(gi.cpu().numpy(), ei)
+    # world = 1 through a real index: results land in the send buffer and come back as copies
+    x, q = _mk(3000, 64, 9, seed=21)
+    ix = DeviceIndex(x, id_base=1, dtype="fp16", device=0)
+    one = sharded_index_searcher(ix)
+    s1, i1 = one.search(torch.from_numpy(q).cuda(), 10)
+    s2, i2, _ = ix.search(torch.from_numpy(q).cuda(), 10)
+    assert torch.equal(s1, s2) and torch.equal(i1, i2)
+    ix.close()
+
+
 @pytest.mark.parametrize("n,d,b,k", [(5000, 128, 9, 30), (2000, 64, 3, 100), (40, 64, 2, 50), (70001, 64, 257, 13)])
 def test_large_k_runs_continuation_passes(native_lib, n, d, b, k):
     """k > 12: ceil(k / 12) passes, each strictly below the last key of the previous one; exact, incl. exhaustion."""

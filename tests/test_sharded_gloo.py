@@ -32,13 +32,14 @@ def _worker(rank, world, port, out_dir):
     q = R.l2_normalize(rng.standard_normal((b, d)).astype(np.float32)).astype(np.float16)
     lo, hi = shard_bounds(n, world, rank)
 
-    def local_search(queries, kk):
+    def local_search(queries, kk, out_s, out_i):
         s, i, _ = R.search(queries.numpy().astype(np.float32), x[lo:hi], kk, dtype=R.DTYPE_F16, id_base=1 + lo)
         pad = kk - s.shape[1]
         if pad:
             s = np.pad(s, ((0, 0), (0, pad)), constant_values=-np.inf)
             i = np.pad(i, ((0, 0), (0, pad)), constant_values=-1)
-        return torch.from_numpy(s), torch.from_numpy(i)
+        out_s.copy_(torch.from_numpy(s))
+        out_i.copy_(torch.from_numpy(i))
 
     def merge(gs, gi, kk):
         ms, mi = R.merge_shards(gs.numpy(), gi.numpy(), kk)

@@ -89,8 +89,8 @@ def load() -> ctypes.CDLL:
     lib.vqa_index_dtype.restype = c.c_int32
     lib.vqa_index_search.argtypes = [c.c_void_p, c.c_void_p, c.c_int32, c.c_int32, c.c_int32, c.c_void_p, c.c_void_p,
                                      c.c_void_p, c.c_void_p]
-    lib.vqa_merge_topk.argtypes = [c.c_void_p, c.c_void_p, c.c_int32, c.c_int32, c.c_int32, c.c_int32, c.c_void_p,
-                                   c.c_void_p, c.c_void_p]
+    lib.vqa_merge_topk.argtypes = [c.c_void_p, c.c_void_p, c.c_int64, c.c_int64, c.c_int32, c.c_int32, c.c_int32, c.c_int32,
+                                   c.c_void_p, c.c_void_p, c.c_void_p]
     lib.vqa_index_launch_info.argtypes = [c.c_void_p, c.c_int32, c.c_int32, c.POINTER(LaunchInfo)]
     lib.vqa_index_set_timing.argtypes = [c.c_void_p, c.c_int32]
     lib.vqa_index_get_timing.argtypes = [c.c_void_p, c.POINTER(c.c_double), c.POINTER(c.c_int64)]

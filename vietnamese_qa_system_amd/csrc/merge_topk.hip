@@ -83,8 +83,10 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
 }
 
 __global__ __launch_bounds__(kMergeThreads) void merge_shards_kernel(const float* __restrict__ scores,
-                                                                     const long long* __restrict__ ids, int R, int B,
-                                                                     int k, int k_out, float* __restrict__ out_scores,
+                                                                     const long long* __restrict__ ids,
+                                                                     long long score_rank_stride, long long id_rank_stride,
+                                                                     int R, int B, int k, int k_out,
+                                                                     float* __restrict__ out_scores,
                                                                      long long* __restrict__ out_ids) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     vqa_key* keys = reinterpret_cast<vqa_key*>(smem);  // [R * k]
@@ -93,9 +95,10 @@ __global__ __launch_bounds__(kMergeThreads) void merge_shards_kernel(const float
     const int m = R * k;
     for (int i = threadIdx.x; i < m; i += kMergeThreads) {
         const int r = i / k, j = i - r * k;
-        const size_t src = ((size_t)r * B + q) * k + j;
+        const size_t src = (size_t)q * k + j;  // inside rank r's [B, k] block
         // padded slots carry id -1: they must lose against every real candidate, including score -inf
-        keys[i] = ids[src] < 0 ? 0ull : vqa_make_key(scores[src], (uint32_t)i);
+        keys[i] = ids[(size_t)r * id_rank_stride + src] < 0 ? 0ull
+                                                             : vqa_make_key(scores[(size_t)r * score_rank_stride + src], (uint32_t)i);
     }
     __syncthreads();
     vqa_key prev = ~0ull;
@@ -108,14 +111,14 @@ __global__ __launch_bounds__(kMergeThreads) void merge_shards_kernel(const float
         best = block_max_key(best, red);
         if (threadIdx.x == 0) {
             const bool empty = best == 0ull;
-            size_t src = 0;
+            size_t src = 0, rr = 0;
             if (!empty) {
                 const int i = (int)vqa_key_pos(best);
-                const int rr = i / k, j = i - rr * k;
-                src = ((size_t)rr * B + q) * k + j;
+                rr = (size_t)(i / k);
+                src = (size_t)q * k + (size_t)(i - (int)rr * k);
             }
-            out_scores[(size_t)q * k_out + r] = empty ? -INFINITY : scores[src];
-            out_ids[(size_t)q * k_out + r] = empty ? -1 : ids[src];
+            out_scores[(size_t)q * k_out + r] = empty ? -INFINITY : scores[rr * score_rank_stride + src];
+            out_ids[(size_t)q * k_out + r] = empty ? -1 : ids[rr * id_rank_stride + src];
         }
         prev = best;
     }
@@ -149,17 +152,24 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
     return VQA_OK;
 }
 
-extern "C" int vqa_merge_topk(const float* scores, const int64_t* ids, int32_t R, int32_t B, int32_t k, int32_t k_out,
-                              float* out_scores, int64_t* out_ids, void* hip_stream) {
+extern "C" int vqa_merge_topk(const float* scores, const int64_t* ids, int64_t score_rank_stride, int64_t id_rank_stride,
+                              int32_t R, int32_t B, int32_t k, int32_t k_out, float* out_scores, int64_t* out_ids,
+                              void* hip_stream) {
     VQA_REQUIRE(scores && ids && out_scores && out_ids, "vqa_merge_topk: null pointer");
     VQA_REQUIRE(R >= 1 && B >= 1 && k >= 1 && k_out >= 1, "vqa_merge_topk: bad shape R=%d B=%d k=%d k_out=%d", R, B, k,
                 k_out);
     VQA_REQUIRE((long long)R * k <= 8 * 1024, "vqa_merge_topk: R*k=%lld candidates per query exceed 8192",
                 (long long)R * k);
     VQA_REQUIRE(k_out <= R * k, "vqa_merge_topk: k_out=%d exceeds the R*k=%d candidates", k_out, R * k);
+    if (score_rank_stride == 0) score_rank_stride = (int64_t)B * k;
+    if (id_rank_stride == 0) id_rank_stride = (int64_t)B * k;
+    VQA_REQUIRE(score_rank_stride >= (int64_t)B * k && id_rank_stride >= (int64_t)B * k,
+                "vqa_merge_topk: rank strides %lld / %lld are smaller than one [B, k] block", (long long)score_rank_stride,
+                (long long)id_rank_stride);
     const size_t lds = ((size_t)R * k + 4) * sizeof(vqa_key);
     hipLaunchKernelGGL(merge_shards_kernel, dim3(B), dim3(kMergeThreads), lds, (hipStream_t)hip_stream, scores,
-                       reinterpret_cast<const long long*>(ids), R, B, k, k_out, out_scores,
+                       reinterpret_cast<const long long*>(ids), (long long)score_rank_stride, (long long)id_rank_stride, R, B, k,
+                       k_out, out_scores,
                        reinterpret_cast<long long*>(out_ids));
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;

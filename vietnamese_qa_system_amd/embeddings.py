@@ -155,9 +155,8 @@ class Embeddings:
         self._docs_db = None
         self._docs_mem = {d_["id"]: d_ for d_ in documents} if documents is not None else None
 
-    def _local_search(self, q: torch.Tensor, k: int):
-        s, i, _ = self._index.search(q, k)
-        return s, i
+    def _local_search(self, q: torch.Tensor, k: int, out_s: torch.Tensor, out_i: torch.Tensor) -> None:
+        self._index.search(q, k, out=(out_s, out_i))
 
     def count(self) -> int:
         return self.n

@@ -154,10 +154,13 @@ class DeviceIndex:
         return self.n
 
     # -- search --------------------------------------------------------------------------------------------------
-    def search(self, queries: torch.Tensor, k: int, *, return_positions: bool = False
+    def search(self, queries: torch.Tensor, k: int, *, return_positions: bool = False,
+               out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
                ) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
         """``queries`` [B, d] fp32/fp16 cuda tensor -> (scores [B, k] fp32, ids [B, k] int64[, positions]), best first,
-        ties by row position; slots beyond the shard's row count hold (-inf, -1).  Asynchronous on the current stream."""
+        ties by row position; slots beyond the shard's row count hold (-inf, -1).  Asynchronous on the current stream.
+        ``out`` = (scores, ids): contiguous [B, k] float32 / int64 tensors on this device to write into (the sharded
+        searcher passes views of its all-gather send buffer)."""
         if not self._handle.value:
             raise RuntimeError("index is closed")
         dev = torch.device("cuda", self.device)
@@ -169,9 +172,15 @@ class DeviceIndex:
         b = int(q.shape[0])
         if b == 0:
             raise ValueError("empty query batch")
+        if out is not None:
+            scores, ids = out
+            for t, dt in ((scores, torch.float32), (ids, torch.int64)):
+                if t.dtype != dt or tuple(t.shape) != (b, k) or t.device != dev or not t.is_contiguous():
+                    raise ValueError(f"out tensors must be contiguous [{b}, {k}] float32 / int64 on {dev}")
         with torch.cuda.device(dev):
-            scores = torch.empty((b, k), dtype=torch.float32, device=dev)
-            ids = torch.empty((b, k), dtype=torch.int64, device=dev)
+            if out is None:
+                scores = torch.empty((b, k), dtype=torch.float32, device=dev)
+                ids = torch.empty((b, k), dtype=torch.int64, device=dev)
             pos = torch.empty((b, k), dtype=torch.int64, device=dev) if return_positions else None
             stream = torch.cuda.current_stream(dev).cuda_stream
             N.check(self._lib.vqa_index_search(self._handle, q.data_ptr(), _SRC_DTYPE[q.dtype], b, int(k), scores.data_ptr(),
@@ -195,7 +204,8 @@ class DeviceIndex:
 
 
 def merge_topk(scores: torch.Tensor, ids: torch.Tensor, k_out: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Final merge of per-shard candidates ``[R, B, k]`` (after the RCCL all-gather) -> ``[B, k_out]``."""
+    """Final merge of per-shard candidates ``[R, B, k]`` (after the RCCL all-gather) -> ``[B, k_out]``.  The rank
+    dimension may be strided (views into one gathered buffer); each ``[B, k]`` block must be contiguous."""
     if scores.dim() != 3 or ids.shape != scores.shape:
         raise ValueError("scores/ids must both be [R, B, k]")
     if not scores.is_cuda:
@@ -203,12 +213,18 @@ def merge_topk(scores: torch.Tensor, ids: torch.Tensor, k_out: int) -> Tuple[tor
     lib = N.load()
     r, b, k = (int(x) for x in scores.shape)
     dev = scores.device
-    scores = scores.contiguous().to(torch.float32)
-    ids = ids.contiguous().to(torch.int64)
+
+    def blocks(t, dt):  # keep a rank-strided view as it is; anything else becomes a plain [R, B, k] array
+        if t.dtype == dt and t.stride(2) == 1 and t.stride(1) == k and (r == 1 or t.stride(0) >= b * k):
+            return t
+        return t.to(dt).contiguous()
+    scores = blocks(scores, torch.float32)
+    ids = blocks(ids, torch.int64)
     with torch.cuda.device(dev):
         out_s = torch.empty((b, k_out), dtype=torch.float32, device=dev)
         out_i = torch.empty((b, k_out), dtype=torch.int64, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        N.check(lib.vqa_merge_topk(scores.data_ptr(), ids.data_ptr(), r, b, k, int(k_out), out_s.data_ptr(), out_i.data_ptr(),
-                                   stream), "vqa_merge_topk")
+        N.check(lib.vqa_merge_topk(scores.data_ptr(), ids.data_ptr(), int(scores.stride(0)) if r > 1 else 0,
+                                   int(ids.stride(0)) if r > 1 else 0, r, b, k, int(k_out), out_s.data_ptr(),
+                                   out_i.data_ptr(), stream), "vqa_merge_topk")
     return out_s, out_i

@@ -28,9 +28,14 @@ def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
 
 
 class ShardedSearcher:
-    """All-gather + merge around a per-rank shard search."""
+    """All-gather + merge around a per-rank shard search.
 
-    def __init__(self, local_search: Callable[[torch.Tensor, int], Tuple[torch.Tensor, torch.Tensor]],
+    ``local_search(queries, k, out_scores, out_ids)`` writes the shard's ``[B, k]`` candidates into the two given
+    tensors -- views of ONE send buffer ``[ids int64 | scores float32]`` (12 * B * k bytes, padded to 8), so a batch
+    costs a single collective; ``merge(scores [R, B, k], ids [R, B, k], k)`` gets rank-strided views of the gathered
+    buffer."""
+
+    def __init__(self, local_search: Callable[[torch.Tensor, int, torch.Tensor, torch.Tensor], None],
                  merge: Optional[Callable[[torch.Tensor, torch.Tensor, int], Tuple[torch.Tensor, torch.Tensor]]] = None,
                  group=None):
         self.local_search = local_search
@@ -40,26 +45,46 @@ class ShardedSearcher:
         self.merge = merge
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self._gs = None
-        self._gi = None
+        self._key = None
+        self._send = self._recv = None
+        self._views = None
+
+    def _buffers(self, b: int, k: int, device: torch.device):
+        key = (b, k, device)
+        if self._key != key:
+            row = (12 * b * k + 7) // 8 * 8  # bytes per rank: ids [B, k] int64, scores [B, k] float32, pad to 8
+            self._send = torch.zeros((row,), dtype=torch.uint8, device=device)
+            self._recv = torch.zeros((self.world, row), dtype=torch.uint8, device=device)
+            n = b * k
+            send_i = self._send[:8 * n].view(torch.int64).view(b, k)
+            send_s = self._send[8 * n:12 * n].view(torch.float32).view(b, k)
+            recv_i = self._recv[:, :8 * n].view(torch.int64).unflatten(1, (b, k))
+            recv_s = self._recv[:, 8 * n:12 * n].view(torch.float32).unflatten(1, (b, k))
+            self._views = (send_s, send_i, recv_s, recv_i)
+            self._key = key
+        return self._views
 
     def search(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
-        s, i = self.local_search(queries, k)
+        b = int(queries.shape[0])
+        send_s, send_i, recv_s, recv_i = self._buffers(b, k, self._device(queries))
+        self.local_search(queries, k, send_s, send_i)
         if self.world == 1:
-            return s, i
-        b = s.shape[0]
-        if self._gs is None or self._gs.shape[1:] != (b, k) or self._gs.device != s.device:
-            self._gs = torch.empty((self.world, b, k), dtype=torch.float32, device=s.device)
-            self._gi = torch.empty((self.world, b, k), dtype=torch.int64, device=s.device)
-        # output viewed as the concatenation along dim 0 ([R * B, k]): same memory as [R, B, k], accepted by RCCL and gloo
-        dist.all_gather_into_tensor(self._gs.view(self.world * b, k), s.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(self._gi.view(self.world * b, k), i.contiguous(), group=self.group)
-        return self.merge(self._gs, self._gi, k)
+            return send_s.clone(), send_i.clone()
+        dist.all_gather_into_tensor(self._recv.view(-1), self._send, group=self.group)  # the one exchange step
+        return self.merge(recv_s, recv_i, k)
+
+    def _device(self, queries: torch.Tensor) -> torch.device:
+        return queries.device
 
 
 def sharded_index_searcher(index, group=None) -> ShardedSearcher:
-    """:class:`ShardedSearcher` over a :class:`~vietnamese_qa_system_amd.index.DeviceIndex` shard."""
-    def local(q, k):
-        s, i, _ = index.search(q, k)
-        return s, i
-    return ShardedSearcher(local, None, group)
+    """:class:`ShardedSearcher` over a :class:`~vietnamese_qa_system_amd.index.DeviceIndex` shard: the fused kernel
+    writes its results straight into the all-gather send buffer."""
+    dev = torch.device("cuda", index.device)
+
+    def local(q, k, out_s, out_i):
+        index.search(q, k, out=(out_s, out_i))
+
+    searcher = ShardedSearcher(local, None, group)
+    searcher._device = lambda queries: dev
+    return searcher
