@@ -6,7 +6,7 @@ mkdir -p $O
 for v in "$@"; do
   lib=$GRAFT_REPO_ROOT/vietnamese_qa_system_amd/lib/libvqa_retrieval_$v.so
   [ "$v" = default ] && lib=$GRAFT_REPO_ROOT/vietnamese_qa_system_amd/lib/libvqa_retrieval.so
-  VQA_LIB=$lib rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/$v -- python scripts/kbench.py --steps 4 > $O/$v.log 2>&1
+  VQA_LIB=$lib rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O/$v -- python scripts/kbench.py --steps 4 $KB_ARGS > $O/$v.log 2>&1
   python3 - $O/$v $v <<'PY'
 import csv, glob, sys, collections
 d, v = sys.argv[1], sys.argv[2]

@@ -288,8 +288,12 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2;  // corpus-row half = ping-pong group
-    const int wn = wave & 3;   // query quarter
+    // fp16 / fp32: group = corpus-row half (the two groups run the K-step memory-first / matrix-first).
+    // fp8: group = QUERY half (the two groups run one slot apart and own disjoint candidate lists, see stagger_loop).
+    constexpr bool kStagger = DT == VQA_FP8_E4M3;
+    const int grp = wave >> 2;                              // waves w and w + 4 share a SIMD: one of each group
+    const int wm = kStagger ? (wave >> 1) & 1 : grp;        // corpus-row half
+    const int wn = kStagger ? 2 * grp + (wave & 1) : wave & 3;  // query quarter
     const int c = lane & 15;
     const int g = lane >> 4;
 
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     const size_t tile_jump = ((size_t)gridDim.x - 1) * KT * kOperandBytes;  // from a tile's last block to the next tile's
     const char* x_src = reinterpret_cast<const char*>(X) + (size_t)first_tile * KT * kOperandBytes;
     const char* q_src = reinterpret_cast<const char*>(Qs);
-    uint32_t i_dst = (wm ? xring_lds : qring_lds) + lw * 4096;
+    uint32_t i_dst = (grp ? xring_lds : qring_lds) + lw * 4096;
     auto issue_x = [&]() {
         if (ik >= total) return;
         glds16x4<VQA_XNT != 0>(x_src, voff, i_dst);
@@ -343,7 +347,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     // wait until this wave's pieces of K-step kappa_needed have landed; it has then issued through
     // kappa_needed + extra (4 instructions per K-step), fewer near the end of the stream
     auto wait_pieces = [&](int kappa_needed) {
-        if (wm) {
+        if (grp) {
             if (kappa_needed + (kPx - 2) < total) wait_vmcnt<4 * (kPx - 2)>();
             else wait_vmcnt<0>();
         } else {
@@ -409,9 +413,9 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
 #if VQA_ABLATE & 1
 #define VQA_ISSUE() (void)0
 #elif VQA_ABLATE & 32
-#define VQA_ISSUE() do { if (wm) issue_x(); } while (0)
+#define VQA_ISSUE() do { if (grp) issue_x(); } while (0)
 #else
-#define VQA_ISSUE() do { if (wm) issue_x(); else issue_q(); } while (0)
+#define VQA_ISSUE() do { if (grp) issue_x(); else issue_q(); } while (0)
 #endif
 #if VQA_ABLATE & 64
 #define VQA_LOOP_BARRIER() (void)0
@@ -444,106 +448,9 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         VQA_LOOP_BARRIER();                                        \
     } while (0)
 
-    // prologue: the first K-steps of this wave's stream (fp8 works on K-step PAIRS: three X pairs, one Q pair);
-    // fp16 / fp32: K-steps 0 and 1 landed
-    if (wm) {
-        for (int i = 0; i < (DT == VQA_FP8_E4M3 ? 6 : kPx); ++i) issue_x();
-    } else {
-        for (int i = 0; i < kPq; ++i) issue_q();
-    }
-    if constexpr (DT != VQA_FP8_E4M3) {
-        wait_pieces(1);
-        block_barrier();
-    }
-
-    // The whole tile loop exists twice (group 0: memory instructions first, group 1: matrix instructions first) and
-    // the wave-uniform branch sits OUTSIDE it: a diamond around each K-step makes hipcc spill the accumulators.
-    auto tile_loop = [&](auto mem_first_tag) __attribute__((always_inline)) {
-    constexpr bool kMemFirst = decltype(mem_first_tag)::value;
-    frag_t a0[8], b0[4];  // fp16 / fp32: fragments of the K-step about to be multiplied (carried across tiles)
-    if constexpr (DT != VQA_FP8_E4M3) {
-        if (ntile > 0) {
-            VQA_READ_FRAGS(a0, b0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        }
-        block_barrier();  // every wave holds its first fragments before a piece of K-step + kS may overwrite the stage
-    }
-    for (int ti = 0; ti < ntile; ++ti) {
-        f32x4 acc[8][4];
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        // One barrier per K-step.  Iteration kappa: (R) read the fragments of kappa + 1 into the other register set,
-        // (D) issue this wave's LDS-DMA pieces of kappa + kP, (M) 32 MFMAs of kappa; then lgkmcnt(0) (the stage of
-        // kappa + 1 may be refilled after the barrier), a counted vmcnt (this wave's pieces of kappa + 2 landed) and
-        // the barrier.  Group 0 runs R, D, M and group 1 runs M, R, D, so on every SIMD one wave starts with the
-        // matrix pipe while its partner starts with memory instructions.
-        if constexpr (DT == VQA_FP8_E4M3) {
-            // fp8: the block-scaled MFMA consumes two K-steps at once, so the loop works on K-step PAIRS.  Pair j:
-            // (A) this wave's pieces of pair j have landed (counted vmcnt), barrier; (B) read all 24 fragments of the pair
-            // (both halves of every 32-byte operand in one place, so they form register tuples without copies),
-            // lgkmcnt(0), barrier; (C) issue the DMA pieces of X pair j + 3 (into the stages just read; the 6-stage X ring
-            // holds three pairs) / Q pair j + 1 (the 2-stage Q ring holds one pair); (D) 32 scaled MFMAs.
-            static_assert(kSx == 6 && kSq == 2, "the fp8 pair loop assumes three X pairs and one Q pair of ring stages");
-            v8i a2[8], b2[4];
-            for (int kt = 0; kt < KT; kt += 2) {  // KT is even: pairs never straddle tiles
-                const int kappa = ti * KT + kt;
-                if (wm) {
-                    if (kappa + 5 < total) wait_vmcnt<16>();  // issued through pair j + 2: two pairs may stay in flight
-                    else wait_vmcnt<0>();
-                } else {
-                    wait_vmcnt<0>();
-                }
-                block_barrier();
-                VQA_READ_HALVES(a2, b2, 0);
-                VQA_READ_HALVES(a2, b2, 1);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                VQA_LOOP_BARRIER();
-#if !(VQA_ABLATE & 1)
-                if (wm) {
-                    issue_x();
-                    issue_x();
-                } else {
-                    issue_q();
-                    issue_q();
-                }
-#endif
-                VQA_SB();
-                mma_block_mx<0, 8>(acc, a2, b2);
-            }
-            block_barrier();  // every wave is done with the MFMAs before the epilogue's barriers interleave with (A)
-        } else {
-        // (the first fragments of this tile were read before the loop / under the previous tile's last K-step, so their
-        // LDS latency and the pipeline refill hide under the previous tile's epilogue)
-        if constexpr (DT == VQA_F16) {
-            frag_t a1[8], b1[4];  // second register set: the next K-step's fragments load under this K-step's MFMAs
-            for (int kt = 0; kt < KT; kt += 2) {  // KT is even (rows are padded to two K-steps)
-                const int kappa = ti * KT + kt;
-                VQA_KSTEP(a0, b0, a1, b1, kappa, true);
-                VQA_KSTEP(a1, b1, a0, b0, kappa + 1, kt + 2 < KT || ti + 1 < ntile);
-            }
-        } else {
-            // fp32: 4x the MFMAs per K-step and one register set (a second one spills): issue the DMA pieces, multiply,
-            // then refill the same registers; the reads' latency hides under the partner wave's MFMAs
-            for (int kt = 0; kt < KT; ++kt) {
-                const int kappa = ti * KT + kt;
-                VQA_ISSUE();
-                VQA_SB();
-                VQA_MMA(a0, b0);
-                VQA_SB();
-                if (kt + 1 < KT || ti + 1 < ntile) VQA_READ_FRAGS(a0, b0);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                wait_pieces(kappa + 2);
-                VQA_LOOP_BARRIER();
-            }
-        }
-        }  // storage types other than fp8
-
-        // ---- epilogue; scores stay in registers ------------------------------------------------------------------
-        // acc[mi][ni][j] = score(row = row0 + 128 wm + 16 mi + 4 g + j, query = 64 wn + 16 ni + c)
-        const uint32_t row0 = ((uint32_t)first_tile + (uint32_t)ti * gridDim.x) * kTileRows;  // n < 2^32 rows
+    // ---- epilogue pieces (shared by both loop forms); scores stay in registers -----------------------------------
+    // acc[mi][ni][j] = score(row = row0 + 128 wm + 16 mi + 4 g + j, query = 64 wn + 16 ni + c)
+    auto mask_ragged = [&](f32x4 (&acc)[8][4], uint32_t row0) __attribute__((always_inline)) {
         const long long left = N - (long long)row0;
         const int rows_left = left < kTileRows ? (int)left : kTileRows;
         if (rows_left < kTileRows) {  // ragged last tile of the shard: rows past the end never compete (NaN fails every
@@ -557,48 +464,46 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
                     for (int ni = 0; ni < 4; ++ni) acc[mi][ni][j] = dead ? __builtin_nanf("") : acc[mi][ni][j];
                 }
         }
-        if (MODE == 0) {
-            // two sub-maxima per query and tile (one per row half wm) -> seeds [query][seed tile][2].  Each is the score of
-            // a distinct row, so the k-th largest of any k of them bounds the k-th best score from below.
-            const int seed_tiles = tile_end - tile_begin;
-            const int tile_local = first_tile - tile_begin + ti * (int)gridDim.x;
+    };
+    // MODE 0: two sub-maxima per query and tile (one per row half wm) -> seeds [query][seed tile][2].  Each is the score
+    // of a distinct row, so the k-th largest of any k of them bounds the k-th best score from below.
+    auto seed_epilogue = [&](const f32x4 (&acc)[8][4], uint32_t row0, int ti) __attribute__((always_inline)) {
+        const int seed_tiles = tile_end - tile_begin;
+        const int tile_local = first_tile - tile_begin + ti * (int)gridDim.x;
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                const int q = wn * 64 + ni * 16 + c;
-                const vqa_key up = upper ? upper[q] : ~0ull;
-                float m = -INFINITY;
-                int arg = 0;
+        for (int ni = 0; ni < 4; ++ni) {
+            const int q = wn * 64 + ni * 16 + c;
+            const vqa_key up = upper ? upper[q] : ~0ull;
+            float m = -INFINITY;
+            int arg = 0;
 #pragma unroll
-                for (int mi = 0; mi < 8; ++mi)
+            for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int r = wm * 128 + mi * 16 + g * 4 + j;
-                        const float v = acc[mi][ni][j];
-                        if (v > m && (!upper || vqa_make_key(v, row0 + (uint32_t)r) < up)) {
-                            m = v;
-                            arg = r;
-                        }
+                for (int j = 0; j < 4; ++j) {
+                    const int r = wm * 128 + mi * 16 + g * 4 + j;
+                    const float v = acc[mi][ni][j];
+                    if (v > m && (!upper || vqa_make_key(v, row0 + (uint32_t)r) < up)) {
+                        m = v;
+                        arg = r;
                     }
-                vqa_key key = (m > -INFINITY && q < nq) ? vqa_make_key(m, row0 + (uint32_t)arg) : 0ull;
-                // max over the four lane groups g that hold the other rows of this query (lanes c, c + 16, c + 32, c + 48)
-                vqa_key o = __shfl_xor(key, 16, 64);
-                key = o > key ? o : key;
-                o = __shfl_xor(key, 32, 64);
-                key = o > key ? o : key;
-                if (g == 0) out[((size_t)q * seed_tiles + tile_local) * kSeedsPerTile + wm] = key;
-            }
-            continue;
+                }
+            vqa_key key = (m > -INFINITY && q < nq) ? vqa_make_key(m, row0 + (uint32_t)arg) : 0ull;
+            // max over the four lane groups g that hold the other rows of this query (lanes c, c + 16, c + 32, c + 48)
+            vqa_key o = __shfl_xor(key, 16, 64);
+            key = o > key ? o : key;
+            o = __shfl_xor(key, 32, 64);
+            key = o > key ? o : key;
+            if (g == 0) out[((size_t)q * seed_tiles + tile_local) * kSeedsPerTile + wm] = key;
         }
-        // X stage of the tile's last K-step: every read of it completed before the re-align barrier and its next
-        // refill (K-step + kSx) is issued in the next tile's first L segment
-        // (fp8: every X stage holds a pair in flight, so there is no spill area and a list holds kCap keys)
-        L.ext = reinterpret_cast<vqa_key*>(smem + (sx == 0 ? kSx - 1 : sx - 1) * kOperandBytes);
-        constexpr int kSpill = DT == VQA_FP8_E4M3 ? 0 : kExt;
-        static_assert(kPx < kSx, "the X stage of the K-step just computed must idle until the next K-step's pieces are issued");
-        uint32_t pend[4] = {0u, 0u, 0u, 0u};  // accumulators whose append was refused (list full): retried below
+    };
+    // MODE 1: every accumulator that beats its query's threshold is appended to the query's candidate list.  Returns true
+    // when some append was refused (list full); the refused accumulators are left in pend[] for process_pending.
+    auto append_epilogue = [&](const f32x4 (&acc)[8][4], uint32_t row0, uint32_t (&pend)[4], int spill)
+                               __attribute__((always_inline)) -> bool {
         bool refused = false;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
+            pend[ni] = 0u;
             const int q = wn * 64 + ni * 16 + c;
             const float th = L.thr[q];
             float m = -INFINITY;
@@ -624,7 +529,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
                             const float v = acc[mi][ni][j];
                             if (v >= th) {
                                 const uint32_t pos = row0 + (uint32_t)(wm * 128 + mi * 16 + g * 4 + j);
-                                if (vqa_make_key(v, pos) < up && !append_candidate(L, q, v, pos, kSpill)) {
+                                if (vqa_make_key(v, pos) < up && !append_candidate(L, q, v, pos, spill)) {
                                     pend[ni] |= 1u << (mi * 4 + j);
                                     refused = true;
                                 }
@@ -634,10 +539,82 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
                 }
             }
         }
+        return refused;
+    };
+
+    // ---- fp16 / fp32: one barrier per K-step, the two groups memory-first / matrix-first ----------------------------
+    // The whole tile loop exists twice (group 0: memory instructions first, group 1: matrix instructions first) and
+    // the wave-uniform branch sits OUTSIDE it: a diamond around each K-step makes hipcc spill the accumulators.
+    auto tile_loop = [&](auto mem_first_tag) __attribute__((always_inline)) {
+    constexpr bool kMemFirst = decltype(mem_first_tag)::value;
+    // prologue: the first K-steps of this wave's stream; K-steps 0 and 1 landed
+    if (grp) {
+        for (int i = 0; i < kPx; ++i) issue_x();
+    } else {
+        for (int i = 0; i < kPq; ++i) issue_q();
+    }
+    wait_pieces(1);
+    block_barrier();
+    frag_t a0[8], b0[4];  // fragments of the K-step about to be multiplied (carried across tiles)
+    if (ntile > 0) {
+        VQA_READ_FRAGS(a0, b0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    block_barrier();  // every wave holds its first fragments before a piece of K-step + kS may overwrite the stage
+    for (int ti = 0; ti < ntile; ++ti) {
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // One barrier per K-step.  Iteration kappa: (R) read the fragments of kappa + 1 into the other register set,
+        // (D) issue this wave's LDS-DMA pieces of kappa + kP, (M) 32 MFMAs of kappa; then lgkmcnt(0) (the stage of
+        // kappa + 1 may be refilled after the barrier), a counted vmcnt (this wave's pieces of kappa + 2 landed) and
+        // the barrier.  Group 0 runs R, D, M and group 1 runs M, R, D, so on every SIMD one wave starts with the
+        // matrix pipe while its partner starts with memory instructions.
+        // (the first fragments of this tile were read before the loop / under the previous tile's last K-step, so their
+        // LDS latency and the pipeline refill hide under the previous tile's epilogue)
+        if constexpr (DT == VQA_F16) {
+            frag_t a1[8], b1[4];  // second register set: the next K-step's fragments load under this K-step's MFMAs
+            for (int kt = 0; kt < KT; kt += 2) {  // KT is even (rows are padded to two K-steps)
+                const int kappa = ti * KT + kt;
+                VQA_KSTEP(a0, b0, a1, b1, kappa, true);
+                VQA_KSTEP(a1, b1, a0, b0, kappa + 1, kt + 2 < KT || ti + 1 < ntile);
+            }
+        } else {
+            // fp32: 4x the MFMAs per K-step and one register set (a second one spills): issue the DMA pieces, multiply,
+            // then refill the same registers; the reads' latency hides under the partner wave's MFMAs
+            for (int kt = 0; kt < KT; ++kt) {
+                const int kappa = ti * KT + kt;
+                VQA_ISSUE();
+                VQA_SB();
+                VQA_MMA(a0, b0);
+                VQA_SB();
+                if (kt + 1 < KT || ti + 1 < ntile) VQA_READ_FRAGS(a0, b0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                wait_pieces(kappa + 2);
+                VQA_LOOP_BARRIER();
+            }
+        }
+
+        // ---- epilogue ------------------------------------------------------------------------------------------------
+        const uint32_t row0 = ((uint32_t)first_tile + (uint32_t)ti * gridDim.x) * kTileRows;  // n < 2^32 rows
+        mask_ragged(acc, row0);
+        if (MODE == 0) {
+            seed_epilogue(acc, row0, ti);
+            continue;
+        }
+        // X stage of the tile's last K-step: every read of it completed before the re-align barrier and its next
+        // refill (K-step + kSx) is issued in the next tile's first L segment
+        L.ext = reinterpret_cast<vqa_key*>(smem + (sx == 0 ? kSx - 1 : sx - 1) * kOperandBytes);
+        constexpr int kSpill = kExt;
+        static_assert(kPx < kSx, "the X stage of the K-step just computed must idle until the next K-step's pieces are issued");
+        uint32_t pend[4];  // accumulators whose append was refused (list full): retried below
         // every wave passed the re-align barrier after its last fragment reads completed, so the idle stage (L.ext)
         // is free: a list holds up to kCap + kExt keys inside this epilogue and is back below kCap when it ends
         // (water <= kCap: every list that spilled into L.ext is compacted).
-        if (refused) atomicOr(&L.cnt[0], kOverBit);
+        if (append_epilogue(acc, row0, pend, kSpill)) atomicOr(&L.cnt[0], kOverBit);
         __syncthreads();
         for (;;) {
             const int over = L.cnt[0] & kOverBit;  // stable here: set before the barrier above, cleared only behind the next
@@ -655,8 +632,145 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         }
     }
     };
-    if (wm) tile_loop(std::false_type{});
-    else tile_loop(std::true_type{});
+
+    // ---- fp8: the block-scaled MFMA consumes two K-steps at once (32 bytes per lane and operand), so the loop works on
+    // K-step PAIRS, and a second fragment register set does not fit beside the accumulators.  The two wave groups
+    // (partners on every SIMD) therefore run ONE SLOT APART, one s_barrier per slot:
+    //     group A (waves 0-3, queries   0-127):  R0 M0 R1 M1 ... R(P-1) M(P-1) E | R0 M0 ...
+    //     group B (waves 4-7, queries 128-255):  -- R0 M0 R1 ...        R(P-1) M(P-1) E | R0 ...
+    // R = read the 24 fragments of a pair, M = its 32 scaled MFMAs, E = threshold test + appends of the finished tile;
+    // while one wave of a SIMD multiplies, its partner reads (or runs its epilogue), so the LDS reads no longer idle the
+    // matrix pipe.  Groups split the QUERIES: each owns its half of every query stage (refilled one slot after it was
+    // read) and its 128 candidate lists (appends, compaction and the rare refusal repair stay inside the group; the
+    // other group idles through a repair's barriers).  X pairs are shared: pair j is read by A in slot a, by B in
+    // slot a + 1, and refilled with pair j + 3 at slot a + 2 (3 pairs of ring = 4 slots of HBM prefetch, as before).
+    // Waves 4-7 issue the X stream (their M slots), waves 0-3 the Q halves (every slot; vmcnt retires in order, so the
+    // deep and the shallow stream stay in different waves).
+    auto stagger_loop = [&](auto early_tag) __attribute__((always_inline)) {
+        constexpr bool kEarly = decltype(early_tag)::value;
+        const int P = KT >> 1;     // K-step pairs per tile (KT is even: pairs never straddle tiles)
+        const int J = ntile * P;   // pairs of this workgroup
+        const int fq = grp * 128, fq_other = 128 - fq;  // the groups' "append refused" flags: bit 30 of cnt[fq]
+        const uint32_t voff_lane = (uint32_t)lane * 16;
+        // rows [128 half, +128) of both query stages of K-step pair jj: 16 KiB = 4 waves x 4 KiB
+        auto issue_q_half = [&](int half, int jj) {
+            const int off = (lw >> 1) * kOperandBytes + half * (kOperandBytes / 2) + (lw & 1) * 4096;
+            glds16x4<false>(reinterpret_cast<const char*>(Qs) + (size_t)(2 * jj) * kOperandBytes + off, voff_lane,
+                            qring_lds + off);
+        };
+        v8i a2[8], b2[4];
+#if VQA_ABLATE & 2
+        for (int i = 0; i < 8; ++i) a2[i] = v8i{lane, 1, 2, 3, 4, 5, 6, 7};
+        for (int i = 0; i < 4; ++i) b2[i] = v8i{7, 6, 5, lane, 3, 2, 1, 0};
+#endif
+        f32x4 acc[8][4];
+        uint32_t pend[4] = {0u, 0u, 0u, 0u};
+        uint32_t row0 = 0;
+        // a group's refused appends: compact its lists, retry, until none is refused; every wave runs the barriers
+        auto repair = [&](bool mine, int f) __attribute__((always_inline)) {
+            for (;;) {
+                if (!(L.cnt[f] & kOverBit)) break;  // stable: set before the last barrier, cleared only behind the next
+                if (mine) compact_pass(L, wave, lane, k, k + 1, kCap);
+                __syncthreads();
+                if (mine && lw == 0 && lane == 0) L.cnt[f] &= ~kOverBit;
+                __syncthreads();
+                if (mine && process_pending(L, acc, pend, wm, wn, c, g, row0, upper, 0)) atomicOr(&L.cnt[f], kOverBit);
+                __syncthreads();
+            }
+        };
+        // prologue: X pairs 0-2 in flight and pair 0 landed, group A's query half of pair 0 landed; B idles in slot 0
+        if (kEarly) {
+            if (J > 0) issue_q_half(0, 0);
+            wait_vmcnt<0>();
+        } else {
+            for (int i = 0; i < 6; ++i) issue_x();
+            if (total >= 6) wait_vmcnt<16>();
+            else wait_vmcnt<0>();
+        }
+        block_barrier();
+        if (!kEarly) block_barrier();
+        int j = 0;
+        for (int ti = 0; ti < ntile; ++ti) {
+            for (int jj = 0; jj < P; ++jj, ++j) {
+                // ---- R slot: fragments of pair j.  A: issue group B's query half of pair j (B read its half of pair
+                // j - 1 one slot ago); B: pair j + 1 of the X stream has landed when the slot ends (A reads it next)
+                if (MODE == 1 && jj == 0 && ti > 0) compact_pass(L, wave, lane, k, k + (kCap - k + 1) / 2, kCap);
+#if !(VQA_ABLATE & 33)
+                if (kEarly) issue_q_half(1, jj);
+#endif
+#if VQA_ABLATE & 2
+                sx = sx + 2 >= kSx ? sx + 2 - kSx : sx + 2;
+#else
+                VQA_READ_HALVES(a2, b2, 0);
+                VQA_READ_HALVES(a2, b2, 1);
+#endif
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (kEarly) {
+                    wait_vmcnt<0>();
+                } else {
+                    if (j + 2 < J) wait_vmcnt<8>();
+                    else wait_vmcnt<0>();
+                }
+                block_barrier();
+                if (MODE == 1 && kEarly && jj == 0 && ti > 0) repair(false, fq_other);  // group B's E slot just ended
+                // ---- M slot.  A: issue its own query half of pair j + 1 (read one slot ago); B: X pair j + 3 into the
+                // stages both groups have read
+#if !(VQA_ABLATE & 1)
+                if (kEarly) {
+#if !(VQA_ABLATE & 32)
+                    if (j + 1 < J) issue_q_half(0, jj + 1 == P ? 0 : jj + 1);
+#endif
+                } else {
+                    issue_x();
+                    issue_x();
+                }
+#endif
+                if (jj == 0) {
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                // The MFMAs are register-only, so nothing but these two pins keeps hipcc from moving them across the slot's
+                // barriers (it sank them below the closing barrier: both groups then multiplied in their R slots).
+                asm volatile("" : "+v"(a2[0]), "+v"(a2[1]), "+v"(a2[2]), "+v"(a2[3]), "+v"(a2[4]), "+v"(a2[5]), "+v"(a2[6]),
+                             "+v"(a2[7]));
+                VQA_SB();
+#if !(VQA_ABLATE & 4)
+                mma_block_mx<0, 8>(acc, a2, b2);
+#endif
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi)
+                    asm volatile("" ::"v"(acc[mi][0]), "v"(acc[mi][1]), "v"(acc[mi][2]), "v"(acc[mi][3]));
+                if (kEarly) wait_vmcnt<0>();
+                block_barrier();
+                if (MODE == 1 && !kEarly && jj == P - 1) repair(false, fq_other);  // group A's E slot just ended
+            }
+            // ---- E slot
+            row0 = ((uint32_t)first_tile + (uint32_t)ti * gridDim.x) * kTileRows;
+            mask_ragged(acc, row0);
+            if (MODE == 0) {
+                seed_epilogue(acc, row0, ti);
+                block_barrier();
+            } else {
+                if (append_epilogue(acc, row0, pend, 0)) atomicOr(&L.cnt[fq], kOverBit);
+                block_barrier();
+                repair(true, fq);
+            }
+        }
+        if (kEarly) {  // group B's last E slot
+            block_barrier();
+            if (MODE == 1) repair(false, fq_other);
+        }
+    };
+
+    if constexpr (kStagger) {
+        if (grp) stagger_loop(std::false_type{});
+        else stagger_loop(std::true_type{});
+    } else {
+        if (grp) tile_loop(std::false_type{});
+        else tile_loop(std::true_type{});
+    }
 
     if (MODE == 0) return;
     // ---- flush: every list sorted best first, k keys per query (0 = empty) ------------------------------------
