@@ -118,7 +118,10 @@ constexpr int kTileRows = 256;          // corpus rows per tile
 constexpr int kQ = VQA_QUERY_TILE;      // 256 queries per tile
 constexpr int kRowBytes = 64;           // bytes of every row per K-step (32 fp16 / 64 fp8 / 16 fp32 elements)
 constexpr int kOperandBytes = 256 * kRowBytes;  // 16 KiB: one operand slice (256 rows x one K-step)
-constexpr int kSx = 6, kPx = 5;  // X ring: stages, K-steps issued ahead (HBM stream: deep); one stage idles per K-step
+#ifndef VQA_SX
+#define VQA_SX 6
+#endif
+constexpr int kSx = VQA_SX, kPx = VQA_SX - 1;  // X ring: stages, K-steps issued ahead (HBM stream: deep); one stage idles per K-step
 constexpr int kSq = 2, kPq = 2;  // Q ring: stages, K-steps issued ahead (L2 resident: shallow)
 constexpr int kXRingBytes = kSx * kOperandBytes;
 constexpr int kQRingBytes = kSq * kOperandBytes;
@@ -128,7 +131,7 @@ constexpr int kCap = (kLdsTotal - kPipeBytes - 2 * kQ * 4) / (kQ * 8);  // 15 ca
 constexpr int kExt = kOperandBytes / (kQ * 8);                           // 8 more in the idle X stage during an epilogue
 constexpr int kMaxK = kCap - 3;                                         // 12
 constexpr int kSeedsPerTile = 2;  // seed pass: sub-maxima kept per query and tile (one per row half)
-static_assert(kPipeBytes == 128 * 1024, "ring sizes");
+static_assert(kPipeBytes <= 144 * 1024, "ring sizes");
 
 constexpr int kOverBit = 1 << 30;  // "an append was refused" flag, kept in bit 30 of cnt[0] (LDS is fully used)
 constexpr int kCntMask = 0xFFFFFF;
@@ -172,6 +175,17 @@ __device__ __forceinline__ void compact_pass(const Lists& L, int wave, int lane,
     }
 }
 
+// Load one key from global memory, complete when the call returns.  Inline asm on purpose: a load hipcc can see leaves a
+// "possibly pending" destination register on the paths that skip its use, and the waitcnt pass then puts an
+// unconditional s_waitcnt vmcnt(0) where the K loop next writes that register -- which drained the loader waves' whole
+// LDS-DMA queue every second K-step (found in the disassembly; the ring was 5 K-steps deep on paper only).
+// (uniform base in SGPRs + a 32-bit lane offset: nothing 64-bit per lane stays live across the K loop)
+__device__ __forceinline__ vqa_key load_key_now(const vqa_key* base, int idx) {
+    vqa_key v;
+    asm volatile("global_load_dwordx2 %0, %1, %2\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"((uint32_t)idx * 8u), "s"(base) : "memory");
+    return v;
+}
+
 __device__ __forceinline__ bool append_candidate(const Lists& L, int q, float v, uint32_t pos, int spill) {
     const int slot = atomicAdd(&L.cnt[q], 1) & kCntMask;  // ds_add_rtn_u32
     if (slot < kCap) {
@@ -206,7 +220,7 @@ __device__ __forceinline__ bool process_pending(const Lists& L, const f32x4 (&ac
         if (bits) {
             const int q = wn * 64 + ni * 16 + c;
             const float th = L.thr[q];
-            const vqa_key up = upper ? upper[q] : ~0ull;
+            const vqa_key up = upper ? load_key_now(upper, q) : ~0ull;
             uint32_t keep = 0;
             while (bits) {
                 const int b = __builtin_ctz(bits);
@@ -473,7 +487,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int q = wn * 64 + ni * 16 + c;
-            const vqa_key up = upper ? upper[q] : ~0ull;
+            const vqa_key up = upper ? load_key_now(upper, q) : ~0ull;
             float m = -INFINITY;
             int arg = 0;
 #pragma unroll
@@ -519,7 +533,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
             if (m >= th) {
                 // rare: some accumulator of this (lane, query) beats the threshold.  Two static levels (row group, then
                 // element) instead of a 32-way select: ~50 instructions for the usual single survivor.
-                const vqa_key up = upper ? upper[q] : ~0ull;
+                const vqa_key up = upper ? load_key_now(upper, q) : ~0ull;
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi) {
                     const float mm = fmaxf(fmaxf(acc[mi][ni][0], acc[mi][ni][1]), fmaxf(acc[mi][ni][2], acc[mi][ni][3]));
@@ -678,13 +692,35 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
                 __syncthreads();
             }
         };
-        // prologue: X pairs 0-2 in flight and pair 0 landed, group A's query half of pair 0 landed; B idles in slot 0
-        if (kEarly) {
-            if (J > 0) issue_q_half(0, 0);
-            wait_vmcnt<0>();
-        } else {
-            for (int i = 0; i < 6; ++i) issue_x();
-            if (total >= 6) wait_vmcnt<16>();
+        // All LDS-DMA is issued from R slots: the reading wave has slack, while a piece issued in front of the MFMAs costs
+        // the matrix pipe ~100 cycles each (measured: M slots of 8 pieces + 32 MFMAs ran ~2000 cycles).  Per R slot a
+        // wave issues the OTHER group's next query half first (it must land within the slot) and then one K-step of the X
+        // stream (group A the even K-steps, group B the odd ones; forced complete two slots later by the next counted wait
+        // -- vmcnt retires in order, so the shallow pieces go first and vmcnt(4) leaves the X pieces in flight).
+        static_assert(kSx % 2 == 0, "the fp8 loop alternates the X K-steps between the two groups");
+        int xk = grp, x_kt = grp;  // next K-step this group issues, its position inside the tile
+        const char* xs = reinterpret_cast<const char*>(X) + ((size_t)first_tile * KT + grp) * kOperandBytes;
+        uint32_t xd = xring_lds + grp * kOperandBytes + lw * 4096;
+        auto issue_x2 = [&]() -> bool {
+            if (xk >= total) return false;
+            glds16x4<VQA_XNT != 0>(xs, voff, xd);
+            xk += 2;
+            xs += 2 * kOperandBytes;
+            x_kt += 2;
+            if (x_kt >= KT) {
+                x_kt -= KT;
+                xs += tile_jump;
+            }
+            xd += 2 * kOperandBytes;
+            if (xd >= xring_lds + kXRingBytes) xd -= kXRingBytes;
+            return true;
+        };
+        // prologue: the ring full (K-steps 0 .. kSx - 1), pair 0 and group A's query half of pair 0 landed; B idles in slot 0
+        {
+            if (kEarly && J > 0) issue_q_half(0, 0);
+            int n = 0;
+            for (int i = 0; i < kSx / 2; ++i) n += issue_x2() ? 1 : 0;
+            if (n == kSx / 2) wait_vmcnt<4 * (kSx / 2 - 1)>();  // this group's first K-step landed
             else wait_vmcnt<0>();
         }
         block_barrier();
@@ -692,11 +728,18 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         int j = 0;
         for (int ti = 0; ti < ntile; ++ti) {
             for (int jj = 0; jj < P; ++jj, ++j) {
-                // ---- R slot: fragments of pair j.  A: issue group B's query half of pair j (B read its half of pair
-                // j - 1 one slot ago); B: pair j + 1 of the X stream has landed when the slot ends (A reads it next)
+                // ---- R slot: fragments of pair j
                 if (MODE == 1 && jj == 0 && ti > 0) compact_pass(L, wave, lane, k, k + (kCap - k + 1) / 2, kCap);
+                bool xi = false;
 #if !(VQA_ABLATE & 33)
-                if (kEarly) issue_q_half(1, jj);
+                if (kEarly) {
+                    issue_q_half(1, jj);  // group B's half of pair j (B read its half of pair j - 1 one slot ago)
+                } else if (j + 1 < J) {
+                    issue_q_half(0, jj + 1 == P ? 0 : jj + 1);  // group A's half of pair j + 1 (A read pair j one slot ago)
+                }
+#endif
+#if !(VQA_ABLATE & 1)
+                if (j >= 1) xi = issue_x2();  // into pair j - 1's stages: both groups have read them
 #endif
 #if VQA_ABLATE & 2
                 sx = sx + 2 >= kSx ? sx + 2 - kSx : sx + 2;
@@ -705,26 +748,11 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
                 VQA_READ_HALVES(a2, b2, 1);
 #endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (kEarly) {
-                    wait_vmcnt<0>();
-                } else {
-                    if (j + 2 < J) wait_vmcnt<8>();
-                    else wait_vmcnt<0>();
-                }
+                if (xi) wait_vmcnt<4>();
+                else wait_vmcnt<0>();
                 block_barrier();
                 if (MODE == 1 && kEarly && jj == 0 && ti > 0) repair(false, fq_other);  // group B's E slot just ended
-                // ---- M slot.  A: issue its own query half of pair j + 1 (read one slot ago); B: X pair j + 3 into the
-                // stages both groups have read
-#if !(VQA_ABLATE & 1)
-                if (kEarly) {
-#if !(VQA_ABLATE & 32)
-                    if (j + 1 < J) issue_q_half(0, jj + 1 == P ? 0 : jj + 1);
-#endif
-                } else {
-                    issue_x();
-                    issue_x();
-                }
-#endif
+                // ---- M slot: nothing but the 32 MFMAs
                 if (jj == 0) {
 #pragma unroll
                     for (int mi = 0; mi < 8; ++mi)
@@ -742,7 +770,6 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi)
                     asm volatile("" ::"v"(acc[mi][0]), "v"(acc[mi][1]), "v"(acc[mi][2]), "v"(acc[mi][3]));
-                if (kEarly) wait_vmcnt<0>();
                 block_barrier();
                 if (MODE == 1 && !kEarly && jj == P - 1) repair(false, fq_other);  // group A's E slot just ended
             }
