@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy rate)
+F32_MFMA_PEAK_TFLOPS = 157.3  # same guide, Matrix cores: f32-input MFMA = the f32 vector rate (155 measured)
 
 
 def build_shard(n, d, seed, device, dtype, chunk=1 << 18):
@@ -179,6 +180,12 @@ def main():
                          "bytes_per_launch": info.bytes_per_launch, "flops_per_launch": info.flops_per_launch,
                          "mfma_tflops": round(info.flops_per_launch / (kern_ms * 1e-3) / 1e12, 1) if launches else None},
         }
+        if args.dtype == "fp32" and launches:
+            # an fp32 index at B = 256 is MFMA-bound (128 flop/B against a balance of ~20): price it against the f32 MFMA peak
+            tf = info.flops_per_launch / (kern_ms * 1e-3) / 1e12
+            result["roofline"].update({"bound": "mfma", "achieved": round(tf, 1), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+                                       "hbm_gbs": round(achieved, 1)})
 
     # ---- outside the timed region: recall@10 against the CPU oracle and the CPU baseline (rank 0, N = 1 only for the
     # baseline; the recall check runs on rank 0's shard through the single-shard path)
