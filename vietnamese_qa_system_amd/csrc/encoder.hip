@@ -130,6 +130,21 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const _Float16* __restrict_
     row_layer_norm(x, H, lane, g, b, eps, out + (size_t)t * H);
 }
 
+// erf GELU, 0.5 x (1 + erf(x / sqrt 2)), with erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16
+// output's 5e-4): one v_rcp, one v_exp and a degree-5 Horner chain instead of libm's branchy erff (the FFN1 epilogue
+// spent ~25 us per layer in it).
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    float p = 1.061405429f;
+    p = p * t - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    const float e = 1.0f - p * t * __expf(-z * z);  // erf(|x| / sqrt 2)
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
 // ---- GEMM: C[M, N] = A[M, K] . W[N, K]^T + bias[N]; EPI 0: identity, 1: erf GELU.  K % 64 == 0 (BK = 64) or K % 32 == 0
 // (BK = 32 instantiation for small hidden sizes). -----------------------------------------------------------------------
 constexpr int kGemmBM = 128, kGemmBN = 128;
@@ -231,9 +246,174 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const _Float16* __restrict
                 const int m = bm + wr * 64 + mi * 16 + g * 4 + j;
                 if (m >= M) continue;
                 float v = acc[mi][ni][j] + bv;
-                if (EPI == 1) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                if (EPI == 1) v = gelu_erf(v);
                 C[(size_t)m * N + n] = (_Float16)v;
             }
+    }
+}
+
+// ---- GEMM for the large shapes (M >= 1024 tokens, N % 128 == 0, K % 64 == 0): 256 x 128 tiles, 8 waves, operands go
+// global -> LDS by LDS-DMA into a 3-stage ring (K tile kt + 2 is issued while kt is multiplied; counted vmcnt, one barrier
+// per K tile).  The DMA writes 64 lanes x 16 B contiguously, so the XOR swizzle of the LDS image is applied on the GLOBAL
+// side: lane i of a piece (8 rows x 128 B) fetches row i >> 3, logical 16-byte slot (i & 7) ^ (i >> 3).  MFMA operand
+// roles are swapped against the small kernel (A operand = weight rows, B operand = token rows), so a lane's 4 accumulator
+// values are 4 consecutive output features of one token: 8-byte stores instead of 2-byte ones.
+// Token rows past M are read (and their results dropped): the caller's activation buffers are padded to 256 rows.
+constexpr int kBigBM = 256, kBigBN = 128, kBigRowBytes = 128;  // K tile = 64 halves
+constexpr int kBigAStage = kBigBM * kBigRowBytes, kBigWStage = kBigBN * kBigRowBytes;
+constexpr int kBigStage = kBigAStage + kBigWStage;  // 48 KiB
+constexpr int kBigStages = 3;
+constexpr int kBigLds = kBigStages * kBigStage;     // 144 KiB
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// N_PIECES pieces of 1 KiB: piece p reads base + p * piece_stride + voff (per lane) and lands at lds_dst + p * 1024
+template <int N_PIECES>
+__device__ __forceinline__ void big_dma(const char* base, size_t piece_stride, uint32_t voff, uint32_t lds_dst) {
+    // the instruction offset moves the global AND the LDS address, so piece p's scalar base is pre-decremented by p * 1024
+    const char* b0 = base;
+    const char* b1 = base + piece_stride - 1024;
+    uint32_t keep;
+    if constexpr (N_PIECES == 4) {
+        const char* b2 = base + 2 * piece_stride - 2048;
+        const char* b3 = base + 3 * piece_stride - 3072;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %6\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2\n\t"
+            "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+            "global_load_lds_dwordx4 %1, %4 offset:2048\n\t"
+            "global_load_lds_dwordx4 %1, %5 offset:3072\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(lds_dst)
+            : "memory");
+    } else {
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %4\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, %2\n\t"
+            "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(voff), "s"(b0), "s"(b1), "s"(lds_dst)
+            : "memory");
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_big_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+                                                       const float* __restrict__ bias, _Float16* __restrict__ C, int M, int N,
+                                                       int K, int tiles_n, int tiles_total) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    typedef __attribute__((address_space(3))) char* lds_ptr;
+    const uint32_t lds_base = (uint32_t)(size_t)(lds_ptr)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;  // token rows [64 wr, +64) x output features [64 wc, +64) of the tile
+    const int c = lane & 15, g = lane >> 4;
+    // Persistent workgroups (one per CU): the K-tile stream runs on across output tiles, so the next tile's first two K
+    // tiles are in flight under this tile's epilogue.  XCD-aware tile order: consecutive workgroups go to different XCDs
+    // (8 of them, private L2 each); every XCD works through a contiguous run of tiles (feature tile fastest), so its
+    // workgroups share token rows and the weight matrix in L2.
+    const int G = gridDim.x, wg = blockIdx.x;
+    const bool swz = (tiles_total % 8 == 0) && (G % 8 == 0);
+    const int per = swz ? G >> 3 : G, first = swz ? wg >> 3 : wg, span = swz ? tiles_total >> 3 : tiles_total;
+    const int tile0 = swz ? (wg & 7) * span : 0;
+    const int my_tiles = first < span ? (span - first + per - 1) / per : 0;
+    const int KT = K / 64, total = my_tiles * KT;
+
+    // LDS-DMA geometry (constant per lane): row i >> 3 of the piece, logical slot (i & 7) ^ (i >> 3)
+    const size_t row_bytes = (size_t)K * 2;
+    const uint32_t voff = (uint32_t)((lane >> 3) * row_bytes + (((lane & 7) ^ (lane >> 3)) << 4));
+    const uint32_t a_dst = lds_base + 32 * wave * kBigRowBytes, w_dst = lds_base + kBigAStage + 16 * wave * kBigRowBytes;
+    int is_tile = 0, is_kt = 0, is_stage = 0;  // issue cursor: tile, K tile inside it, ring stage
+    const char* a_src = nullptr;
+    const char* w_src = nullptr;
+    auto issue_next = [&]() {
+        if (is_kt == 0) {
+            const int t = tile0 + first + is_tile * per;
+            a_src = reinterpret_cast<const char*>(A) + (size_t)((t / tiles_n) * kBigBM + 32 * wave) * row_bytes;  // 4 pieces
+            w_src = reinterpret_cast<const char*>(W) + (size_t)((t % tiles_n) * kBigBN + 16 * wave) * row_bytes;  // 2 pieces
+        }
+        big_dma<4>(a_src + (size_t)is_kt * kBigRowBytes, 8 * row_bytes, voff, a_dst + is_stage * kBigStage);
+        big_dma<2>(w_src + (size_t)is_kt * kBigRowBytes, 8 * row_bytes, voff, w_dst + is_stage * kBigStage);
+        if (++is_kt == KT) {
+            is_kt = 0;
+            ++is_tile;
+        }
+        if (++is_stage == kBigStages) is_stage = 0;
+    };
+    // fragment geometry: row (.. + c), logical slot 4 ks + g stored at position (4 ks + g) ^ (row & 7), row & 7 == c & 7
+    const int f0 = c * kBigRowBytes + ((g ^ (c & 7)) << 4), f1 = c * kBigRowBytes + (((4 + g) ^ (c & 7)) << 4);
+    const int a_row0 = wr * 64 * kBigRowBytes, w_row0 = kBigAStage + wc * 64 * kBigRowBytes;
+
+    if (total > 0) issue_next();
+    if (total > 1) issue_next();
+    if (total > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int kappa = 0, stage = 0;
+    for (int i = 0; i < my_tiles; ++i) {
+        f32x4 acc[4][4];  // [feature tile ni][token tile mi]
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < KT; ++kt, ++kappa) {
+            if (kappa + 2 < total) issue_next();  // into the stage of kappa - 1: every wave passed the barrier behind its reads
+            const char* st = lds + stage * kBigStage;
+            if (++stage == kBigStages) stage = 0;
+            half8 w0[4], x0[4], w1[4], x1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                w0[j] = *reinterpret_cast<const half8*>(st + w_row0 + j * 16 * kBigRowBytes + f0);
+                x0[j] = *reinterpret_cast<const half8*>(st + a_row0 + j * 16 * kBigRowBytes + f0);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                w1[j] = *reinterpret_cast<const half8*>(st + w_row0 + j * 16 * kBigRowBytes + f1);
+                x1[j] = *reinterpret_cast<const half8*>(st + a_row0 + j * 16 * kBigRowBytes + f1);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[ni], x0[mi], acc[ni][mi], 0, 0, 0);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[ni], x1[mi], acc[ni][mi], 0, 0, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the stage are done before its refill
+            if (kappa + 2 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // own pieces of kappa + 1 landed
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        // epilogue: acc[ni][mi][j] = C[token bm + 64 wr + 16 mi + c][feature bn + 64 wc + 16 ni + 4 g + j]
+        const int t = tile0 + first + i * per;
+        const int bm = (t / tiles_n) * kBigBM, bn = (t % tiles_n) * kBigBN;
+        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int n0 = bn + wc * 64 + ni * 16 + g * 4;
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int m = bm + wr * 64 + mi * 16 + c;
+                if (m >= M) continue;
+                half4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[ni][mi][j] + bv[j];
+                    if (EPI == 1) v = gelu_erf(v);
+                    o[j] = (_Float16)v;
+                }
+                *reinterpret_cast<half4*>(C + (size_t)m * N + n0) = o;
+            }
+        }
     }
 }
 
@@ -517,6 +697,27 @@ int upload_f16(vqa_encoder* e, const float* src, size_t n, _Float16* dst) {
 
 template <int EPI>
 int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, _Float16* C, int M, int N, int K, hipStream_t s) {
+    if (M >= 1024 && N % kBigBN == 0 && K % 64 == 0 && !getenv("VQA_GEMM_SMALL")) {
+        static bool attr_set_dev[64] = {};
+        int dev = 0;
+        VQA_HIP_CHECK(hipGetDevice(&dev));
+        if (!attr_set_dev[dev & 63]) {
+            VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<EPI>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
+            attr_set_dev[dev & 63] = true;
+        }
+        static int num_cu[64] = {};
+        if (!num_cu[dev & 63]) {
+            hipDeviceProp_t prop;
+            VQA_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+            num_cu[dev & 63] = prop.multiProcessorCount;
+        }
+        const int tiles_n = N / kBigBN, tiles = tiles_n * ((M + kBigBM - 1) / kBigBM);
+        const int grid = tiles < num_cu[dev & 63] ? tiles : num_cu[dev & 63];
+        hipLaunchKernelGGL(gemm_big_kernel<EPI>, dim3(grid), dim3(512), kBigLds, s, A, W, bias, C, M, N, K, tiles_n, tiles);
+        VQA_HIP_CHECK(hipGetLastError());
+        return VQA_OK;
+    }
     dim3 grid((N + kGemmBN - 1) / kGemmBN, (M + kGemmBM - 1) / kGemmBM);
     if (K % 64 == 0)
         hipLaunchKernelGGL((gemm_nt_kernel<EPI, 64>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K);
@@ -603,12 +804,19 @@ extern "C" int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encod
             if ((rc = upload_f32(e, lw.ln2_b, H, &L.ln2_b)) != VQA_OK) break;
         }
         if (rc != VQA_OK) break;
-        const size_t T = max_tokens;
+        // token rows padded to the large GEMM's 256-row tiles: rows past B * L are read (never written back), so clear them once
+        const size_t T = ((size_t)max_tokens + kBigBM - 1) / kBigBM * kBigBM;
         if ((rc = dev_alloc(e, (void**)&e->x, T * H * 2)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->qkv, T * 3 * H * 2)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->ctx, T * H * 2)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->tmp, T * H * 2)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->ffn, T * F * 2)) != VQA_OK) break;
+        if (hipMemset(e->x, 0, T * H * 2) != hipSuccess || hipMemset(e->ctx, 0, T * H * 2) != hipSuccess ||
+            hipMemset(e->ffn, 0, T * F * 2) != hipSuccess) {
+            vqa_set_error("vqa_encoder_create: clearing the activation buffers failed");
+            rc = VQA_EHIP;
+            break;
+        }
     } while (0);
     if (rc != VQA_OK) {
         vqa_encoder_destroy(e);
