@@ -277,10 +277,12 @@ static LaunchPlan plan_launch(const vqa_index* ix) {
     // candidate lists on each workgroup's first tiles.  Costs <= 512 tiles of extra scoring (1.3 % at 10M rows) and halves
     // the appends of the main pass against 256 seed tiles (measured: net gain).
     if (ix->two_pass) {
-        // more seed tiles = tighter starting thresholds = fewer appends; never more than 1/32 of a small shard
-        // (a 1M-row fp32 shard spent 13 % of its search in the seed pass with the fixed count)
+        // more seed tiles = tighter starting thresholds = fewer appends; never more than 1/16 of a small shard
+        // (a 1M-row fp32 shard spent 13 % of its search in the seed pass with the fixed count; 1/16: step 3.37 -> 3.19 ms)
         int want = ix->seed_mult * ix->max_grid;
-        if (want > p.tiles / 32) want = p.tiles / 32 > 0 ? p.tiles / 32 : 1;
+        const char* sd = getenv("VQA_SEED_DIV");
+        const int div = sd ? atoi(sd) : 16;  // VQA_SEED_DIV: dev override, 0 = no cap
+        if (div > 0 && want > p.tiles / div) want = p.tiles / div > 0 ? p.tiles / div : 1;
         p.seed_tiles = p.tiles < want ? p.tiles : want;
         p.grid0 = p.seed_tiles < ix->max_grid ? p.seed_tiles : ix->max_grid;
     }
