@@ -55,6 +55,27 @@ def test_phobert_base_shape_vs_oracle(native_lib, layers, b, l):
     enc.close()
 
 
+def test_small_batches_replay_a_graph(native_lib):
+    """B * L <= 4096 tokens: the first call of a shape runs eagerly, the second captures a hipGraph over the encoder's
+    staging buffers, later ones replay it -- every call must see ITS inputs and agree with the oracle."""
+    from vietnamese_qa_system_amd.encoder import QuestionEncoder
+    cfg = dict(E.PHOBERT_BASE, layers=2)
+    w = E.synthetic_weights(cfg, seed=3, layers=2)
+    enc = QuestionEncoder(w, cfg, max_tokens=4 * 24)
+    outs = []
+    for seed in (1, 2, 3, 4):  # same shape, different tokens: eager, capture + replay, replay, replay
+        ids, mask = E.synthetic_tokens(cfg, 4, 24, seed=seed)
+        got = enc.forward(ids, mask, pooling="mean").cpu().numpy()
+        ref = E.encode(w, cfg, ids, mask, pooling="mean")
+        assert _cos(got, ref).min() > 0.999 and np.abs(got - ref).max() < 2e-2, seed
+        outs.append(got)
+    assert not np.allclose(outs[1], outs[2])  # a replay that ignored its inputs would repeat the captured call's output
+    ids, mask = E.synthetic_tokens(cfg, 4, 24, seed=2)
+    again = enc.forward(ids, mask, pooling="mean").cpu().numpy()
+    assert np.array_equal(again, outs[1])  # same inputs through the replayed graph: bit-identical
+    enc.close()
+
+
 def test_encoder_feeds_retrieval(native_lib):
     """configs[1] in miniature: encoder forward -> fp16 index search; ids must match the all-oracle pipeline."""
     from vietnamese_qa_system_amd import Embeddings

@@ -635,6 +635,19 @@ struct vqa_encoder {
     std::vector<void*> allocs;
     // activations
     _Float16 *x = nullptr, *qkv = nullptr, *ctx = nullptr, *tmp = nullptr, *ffn = nullptr;
+    // small batches are launch-bound (12 layers x 7 kernels of a few microseconds each): their launch sequence is captured
+    // once per (B, L, pooling, normalize) into a hipGraph over these fixed staging buffers and replayed
+    int32_t *g_ids = nullptr, *g_mask = nullptr;  // [max_tokens]
+    float* g_out = nullptr;                       // [max_tokens, hidden] (B <= max_tokens)
+    struct Graph {
+        int B, L, pooling, normalize;
+        hipGraphExec_t exec;
+        bool seen_once;  // the first call of a shape runs eagerly (lazy hipFuncSetAttribute calls are not capturable)
+    };
+    std::vector<Graph> graphs;
+    hipStream_t cap_stream = nullptr;  // capture happens on a stream of our own (the caller's may be the null stream, which
+                                       // cannot be captured); the instantiated graph is launched on the caller's stream
+    bool use_graphs = true;
 };
 
 namespace {
@@ -733,6 +746,9 @@ extern "C" void vqa_encoder_destroy(vqa_encoder* e) {
     if (!e) return;
     DevGuard g(e->device);
     for (void* p : e->allocs) (void)hipFree(p);
+    for (auto& gr : e->graphs)
+        if (gr.exec) (void)hipGraphExecDestroy(gr.exec);
+    if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     delete e;
 }
 
@@ -811,6 +827,18 @@ extern "C" int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encod
         if ((rc = dev_alloc(e, (void**)&e->ctx, T * H * 2)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->tmp, T * H * 2)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->ffn, T * F * 2)) != VQA_OK) break;
+        if ((rc = dev_alloc(e, (void**)&e->g_ids, (size_t)max_tokens * 4)) != VQA_OK) break;
+        if ((rc = dev_alloc(e, (void**)&e->g_mask, (size_t)max_tokens * 4)) != VQA_OK) break;
+        if ((rc = dev_alloc(e, (void**)&e->g_out, (size_t)max_tokens * H * 4)) != VQA_OK) break;
+        {
+            const char* gv = getenv("VQA_ENCODER_GRAPH");
+            e->use_graphs = !(gv && gv[0] == '0');
+            if (e->use_graphs && hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+                (void)hipGetLastError();
+                e->cap_stream = nullptr;
+                e->use_graphs = false;
+            }
+        }
         if (hipMemset(e->x, 0, T * H * 2) != hipSuccess || hipMemset(e->ctx, 0, T * H * 2) != hipSuccess ||
             hipMemset(e->ffn, 0, T * F * 2) != hipSuccess) {
             vqa_set_error("vqa_encoder_create: clearing the activation buffers failed");
@@ -826,18 +854,9 @@ extern "C" int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encod
     return VQA_OK;
 }
 
-extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L,
-                                   int32_t pooling, int32_t normalize, float* out, void* hip_stream) {
-    VQA_REQUIRE(e, "vqa_encoder_forward: encoder is null");
-    VQA_REQUIRE(input_ids && attn_mask && out, "vqa_encoder_forward: null pointer");
-    VQA_REQUIRE(B >= 1 && L >= 1, "vqa_encoder_forward: B=%d L=%d", B, L);
-    VQA_REQUIRE((long long)B * L <= e->max_tokens, "vqa_encoder_forward: B*L=%lld exceeds the workspace of %d tokens",
-                (long long)B * L, e->max_tokens);
-    VQA_REQUIRE(L + e->cfg.pad_id + 1 <= e->cfg.max_pos, "vqa_encoder_forward: L=%d needs position %d, the table has %d rows", L,
-                L + e->cfg.pad_id, e->cfg.max_pos);
-    VQA_REQUIRE(pooling == VQA_POOL_CLS || pooling == VQA_POOL_MEAN, "vqa_encoder_forward: pooling %d", pooling);
-    hipStream_t s = (hipStream_t)hip_stream;
-    DevGuard guard(e->device);
+// the launch sequence of one forward pass (no validation, no allocation, no synchronisation: capturable)
+static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L,
+                          int32_t pooling, int32_t normalize, float* out, hipStream_t s) {
     const int T = B * L, H = e->cfg.hidden, F = e->cfg.ffn, heads = e->cfg.heads, dh = H / heads;
     const float eps = e->cfg.ln_eps;
     const int row_blocks = (T + 3) / 4;
@@ -878,5 +897,53 @@ extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, con
     }
     hipLaunchKernelGGL(pool_normalize_kernel, dim3((B + 3) / 4), dim3(256), 0, s, e->x, attn_mask, B, L, H, pooling, normalize, out);
     VQA_HIP_CHECK(hipGetLastError());
+    return VQA_OK;
+}
+
+extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L,
+                                   int32_t pooling, int32_t normalize, float* out, void* hip_stream) {
+    VQA_REQUIRE(e, "vqa_encoder_forward: encoder is null");
+    VQA_REQUIRE(input_ids && attn_mask && out, "vqa_encoder_forward: null pointer");
+    VQA_REQUIRE(B >= 1 && L >= 1, "vqa_encoder_forward: B=%d L=%d", B, L);
+    VQA_REQUIRE((long long)B * L <= e->max_tokens, "vqa_encoder_forward: B*L=%lld exceeds the workspace of %d tokens",
+                (long long)B * L, e->max_tokens);
+    VQA_REQUIRE(L + e->cfg.pad_id + 1 <= e->cfg.max_pos, "vqa_encoder_forward: L=%d needs position %d, the table has %d rows", L,
+                L + e->cfg.pad_id, e->cfg.max_pos);
+    VQA_REQUIRE(pooling == VQA_POOL_CLS || pooling == VQA_POOL_MEAN, "vqa_encoder_forward: pooling %d", pooling);
+    hipStream_t s = (hipStream_t)hip_stream;
+    DevGuard guard(e->device);
+    const int T = B * L;
+    // Launch-bound sizes replay a captured graph (unless the caller's stream is itself being captured: then the kernels
+    // simply join the caller's capture).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    if (!e->use_graphs || T > 4096 || cap != hipStreamCaptureStatusNone)
+        return encoder_launch(e, input_ids, attn_mask, B, L, pooling, normalize, out, s);
+    vqa_encoder::Graph* gr = nullptr;
+    for (auto& c : e->graphs)
+        if (c.B == B && c.L == L && c.pooling == pooling && c.normalize == normalize) gr = &c;
+    if (!gr) {  // first call of this shape: eager (sets the kernels' attributes), remembered
+        e->graphs.push_back({B, L, pooling, normalize, nullptr, true});
+        return encoder_launch(e, input_ids, attn_mask, B, L, pooling, normalize, out, s);
+    }
+    const size_t H = e->cfg.hidden;
+    VQA_HIP_CHECK(hipMemcpyAsync(e->g_ids, input_ids, (size_t)T * 4, hipMemcpyDeviceToDevice, s));
+    VQA_HIP_CHECK(hipMemcpyAsync(e->g_mask, attn_mask, (size_t)T * 4, hipMemcpyDeviceToDevice, s));
+    if (!gr->exec) {
+        hipGraph_t graph = nullptr;
+        VQA_HIP_CHECK(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
+        const int rc = encoder_launch(e, e->g_ids, e->g_mask, B, L, pooling, normalize, e->g_out, e->cap_stream);
+        const hipError_t end = hipStreamEndCapture(e->cap_stream, &graph);
+        if (rc != VQA_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        VQA_HIP_CHECK(end);
+        const hipError_t inst = hipGraphInstantiate(&gr->exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        VQA_HIP_CHECK(inst);
+    }
+    VQA_HIP_CHECK(hipGraphLaunch(gr->exec, s));
+    VQA_HIP_CHECK(hipMemcpyAsync(out, e->g_out, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));
     return VQA_OK;
 }
