@@ -5,15 +5,15 @@
 // exact inner product of the query with every stored row + k largest).
 //
 // Shape of the work: S[q, n] = sum_j Q[q, j] * X[n, j]   with Q [256, d] (one query tile), X [N, d] row-major.
-// X and Q are stored in HBM in the TILED layout of convert.hip: the slice of one 256-row tile and one K-step of 32
-// elements is a contiguous 16 KiB block, already in the XOR-swizzled image that makes every ds_read_b128 fragment
+// X and Q are stored in HBM in the TILED layout of convert.hip: the slice of one 256-row tile and one K-step (64 bytes of
+// every row) is a contiguous 16 KiB block, already in the XOR-swizzled image that makes every ds_read_b128 fragment
 // read bank-conflict free.  One persistent workgroup (8 waves, one per CU) walks corpus tiles; per K-step the X block
-// (HBM, sequential) and the Q block (L2 resident) go global -> LDS by 16-byte LDS-DMA, 1 KiB contiguous per
-// wave-instruction, into a 4-deep ring (3 K-steps in flight, counted vmcnt, never drained in the loop).
+// (HBM, sequential, nt) and the Q block (L2 resident) go global -> LDS by 16-byte LDS-DMA, 1 KiB contiguous per
+// wave-instruction, into a 6-stage X ring and a 2-stage Q ring (counted vmcnt, never drained in the loop).
 // Wave (wm, wn) owns rows [128 wm, +128) x queries [64 wn, +64) as 8 x 4 tiles of v_mfma_f32_16x16x32_f16
 // (A = corpus rows, B = queries: a lane's 32 accumulators of one column group all belong to ONE query).
-// The two wave groups wm = 0 / wm = 1 (partners on each SIMD) run half a phase apart: while one group issues its
-// 16-MFMA cluster the other reads its next fragments from LDS and issues its LDS-DMA pieces (s_barrier ping-pong).
+// fp16 / fp32: one barrier per K-step, the two wave groups (partners on each SIMD) run memory-first / matrix-first.
+// fp8 (block-scaled MFMA over K-step pairs): the groups split the queries and run one slot apart (stagger_loop).
 // After the K loop the scores never leave registers: each lane compares its accumulators with the query's current
 // threshold (k-th best score so far, in LDS); survivors are appended to the query's LDS candidate list with one LDS
 // atomic; lists are compacted (rank-by-counting inside one wave) when they fill.  No B x N score matrix exists.
