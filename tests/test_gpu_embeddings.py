@@ -123,3 +123,43 @@ def test_embeddings_string_ids_and_text_encoder_hook(native_lib):
     assert hit[0] == "doc-17" and abs(hit[1] - 1.0) < 2e-3
     with pytest.raises(RuntimeError, match="no text encoder"):
         Embeddings().index([{"id": 1, "text": "x"}])
+
+
+def test_hybrid_search_combines_dense_and_bm25(native_lib, tmp_path):
+    """``Embeddings(hybrid=True, content=True)`` (heavy_ranker.py:78): the result is the convex combination of the dense
+    score and the normalised BM25 score over 10 x limit candidates of each half; survives save/load."""
+    from vietnamese_qa_system_amd import Embeddings
+    from vietnamese_qa_system_amd.sparse import BM25Index, combine
+    x, _ = _corpus(200, 64, 1)
+    words = ["hà nội", "sài gòn", "huế", "đà nẵng", "cần thơ", "hải phòng", "sông hồng", "phở bò", "bánh mì", "cà phê"]
+    texts = [f"{words[i % 10]} {words[(i * 7 + 3) % 10]} tài liệu {i}" for i in range(200)]
+    queries = ["phở bò hà nội", "cà phê sài gòn", "tài liệu 42"]
+    qv = {t: torch.from_numpy(x[17 * (j + 1)]) for j, t in enumerate(queries)}  # query j embeds exactly like document 17 (j + 1)
+    table = {t: torch.from_numpy(x[i]) for i, t in enumerate(texts)}
+
+    def fake_encoder(ts):
+        return torch.stack([qv[t] if t in qv else table[t] for t in ts])
+
+    docs = [{"id": i + 1, "text": t, "source": "wiki"} for i, t in enumerate(texts)]
+    hyb = Embeddings(hybrid=True, content=True, encoder=fake_encoder)
+    hyb.index(docs)
+    dense_only = Embeddings(encoder=fake_encoder, min_score=None)
+    dense_only.index(docs)
+    bm25 = BM25Index().index(texts)
+    limit = 3
+    got = hyb.batchsearch(queries, limit)
+    dense = dense_only.batchsearch(queries, 10 * limit)
+    for j, query in enumerate(queries):
+        d = [(i, s) for i, s in dense[j] if s > 0]
+        sp = [(r + 1, s) for r, s in bm25.search(query, 10 * limit)]
+        want = combine(d, sp, limit, 0.5, True)
+        assert [h["id"] for h in got[j]] == [u for u, _ in want]
+        assert np.allclose([h["score"] for h in got[j]], [s for _, s in want], atol=1e-6)
+        assert got[j][0]["text"] == texts[got[j][0]["id"] - 1]
+    # the keyword half changes the ranking: dense alone puts document 17 (j + 1) + 1 first with score ~1
+    assert dense[0][0][0] == 18 and got[0][0]["id"] != 18 or got[0][0]["score"] < 0.99
+    hyb.save(str(tmp_path / "hyb"))
+    back = Embeddings(encoder=fake_encoder).load(str(tmp_path / "hyb"))
+    assert back.hybrid and back.batchsearch(queries, limit) == got
+    # vector queries carry no text: dense scores only
+    assert len(hyb.batchsearch(x[:2], 2)[0]) == 2

@@ -31,6 +31,7 @@ import torch.distributed as dist
 from . import docstore
 from .index import DeviceIndex, resolve_dtype
 from .sharded import ShardedSearcher, shard_bounds
+from .sparse import BM25Index, combine
 
 META_FILE, IDS_FILE, DOCS_FILE = "meta.json", "ids.i64", "documents.db"
 VECTOR_FILES = {"float16": "vectors.f16", "float32": "vectors.f32"}
@@ -72,9 +73,10 @@ class Embeddings:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.device = int(device) if device is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
-        if self.hybrid:
-            warnings.warn("hybrid=True: only the dense (inner-product) score is computed; txtai's BM25 half is not built",
-                          stacklevel=2)
+        # hybrid=True (heavy_ranker.py:78): dense + BM25 keyword scores, convex combination with `weights` (txtai default 0.5)
+        self.weights = float(cfg.get("weights", 0.5))
+        self._sparse: Optional[BM25Index] = None
+        self._row_ids: Optional[np.ndarray] = None  # device-level id of every global row position (sparse hits -> ids)
         self._index: Optional[DeviceIndex] = None
         self._searcher: Optional[ShardedSearcher] = None
         self._host_ids: Optional[list] = None  # non-integer external ids, by row position
@@ -120,6 +122,8 @@ class Embeddings:
                 chunks.append(self._encode([str(d.get("text", "")) for d in docs[c0:c0 + batch_size]]).float())
             vectors = torch.cat(chunks) if chunks else torch.zeros((0, 1))
         self.index_vectors([d["id"] for d in docs], vectors, documents=docs if self.content else None)
+        if self.hybrid:  # every rank indexes the whole corpus' text (host side, small next to the vectors)
+            self._sparse = BM25Index().index(str(d.get("text", "")) for d in docs)
 
     def index_vectors(self, ids: Optional[Sequence], vectors, documents: Optional[List[dict]] = None) -> None:
         """Index precomputed embeddings [n, d] (float32, or float16 values already normalised).  With
@@ -145,6 +149,14 @@ class Embeddings:
         else:
             self._host_ids = list(ids)
             id_base = lo  # the device returns global row positions, mapped through _host_ids on the host
+        # what the dense path reports for global row position p (the sparse half speaks row positions)
+        if not int_ids:
+            self._row_ids = np.arange(n, dtype=np.int64)
+        elif dev_ids is None:
+            self._row_ids = np.arange(n, dtype=np.int64) + (id_base - lo)
+        else:
+            self._row_ids = np.asarray(ids, dtype=np.int64)
+        self._sparse = None
         if self._index is not None:
             self._index.close()
         normalize = self.normalize and v.dtype == torch.float32
@@ -189,9 +201,29 @@ class Embeddings:
         q = self._query_vectors(queries)
         if q.shape[1] != self.d:
             raise ValueError(f"query dimension {q.shape[1]} != index dimension {self.d}")
-        scores, ids = self._searcher.search(q, int(limit))
+        limit = int(limit)
+        texts = list(queries) if not isinstance(queries, (np.ndarray, torch.Tensor)) and len(queries) and isinstance(queries[0], str) else None
+        if self.hybrid and self._sparse is not None and texts is not None and 0.0 < self.weights < 1.0:
+            return self._hybrid(q, texts, limit)
+        scores, ids = self._searcher.search(q, limit)
         torch.cuda.current_stream(q.device).synchronize()
         return self._format(scores.cpu().numpy(), ids.cpu().numpy())
+
+    def _hybrid(self, q: torch.Tensor, texts: List[str], limit: int) -> List[list]:
+        """txtai's hybrid search [recalled, see sparse.py]: 10 x limit candidates from each half, per-id convex combination
+        ``weights * dense + (1 - weights) * bm25`` (BM25 normalised to 0..1), best ``limit``."""
+        cand = min(10 * limit, 1024, max(self.n, 1))
+        scores, ids = self._searcher.search(q, cand)
+        torch.cuda.current_stream(q.device).synchronize()
+        ds, di = scores.cpu().numpy(), ids.cpu().numpy()
+        out_s = np.full((len(texts), limit), -np.inf, dtype=np.float32)
+        out_i = np.full((len(texts), limit), -1, dtype=np.int64)
+        for b, text in enumerate(texts):
+            dense = [(int(i), float(s)) for i, s in zip(di[b], ds[b]) if i >= 0 and s > 0]  # txtai drops dense scores <= 0
+            sparse = [(int(self._row_ids[r]), s) for r, s in self._sparse.search(text, cand)]
+            for j, (uid, sc) in enumerate(combine(dense, sparse, limit, self.weights, self._sparse.normalize)):
+                out_i[b, j], out_s[b, j] = uid, sc
+        return self._format(out_s, out_i)
 
     def search(self, query: Query, limit: int = 3) -> list:
         """``heavy_ranker.py:98``: the ``limit`` best documents for one query, best first."""
@@ -251,8 +283,11 @@ class Embeddings:
                 "pooling": self.pooling, "path": self.path, "content": self.content, "hybrid": self.hybrid,
                 "id_base": self._index.id_base, "has_ids": ids is not None, "host_ids": self._host_ids,
                 "vector_dtype": vec_dtype}
+        meta["weights"] = self.weights
         with open(os.path.join(path, META_FILE), "w") as f:
             json.dump(meta, f)
+        if self._sparse is not None:
+            self._sparse.save(path)
         if self.content and self._docs_mem is not None:
             db = os.path.join(path, DOCS_FILE)
             if os.path.exists(db):
@@ -301,4 +336,12 @@ class Embeddings:
         db = os.path.join(path, DOCS_FILE)
         self._docs_db = db if os.path.isfile(db) else None
         self._docs_mem = None
+        self.weights = float(meta.get("weights", 0.5))
+        self._sparse = BM25Index.load(path) if self.hybrid else None
+        if self._host_ids is not None:
+            self._row_ids = np.arange(n, dtype=np.int64)
+        elif meta["has_ids"]:
+            self._row_ids = np.fromfile(os.path.join(path, IDS_FILE), dtype=np.int64)
+        else:
+            self._row_ids = np.arange(n, dtype=np.int64) + int(meta["id_base"])
         return self
