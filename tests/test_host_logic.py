@@ -95,7 +95,7 @@ def test_embeddings_document_normalisation_and_validation():
         Embeddings(pooling="max")
     with pytest.raises(ValueError):
         Embeddings(dtype="int4")
-    with pytest.warns(UserWarning, match="dense"):
-        Embeddings(hybrid=True, content=True, path="sentence-transformers/paraphrase-multilingual-mpnet-base-v2")
+    emb = Embeddings(hybrid=True, content=True, path="sentence-transformers/paraphrase-multilingual-mpnet-base-v2")  # heavy_ranker.py:78-83
+    assert emb.hybrid and emb.content and emb.weights == 0.5
     with pytest.raises(FileNotFoundError):
         Embeddings().load("/nonexistent/index/dir")
