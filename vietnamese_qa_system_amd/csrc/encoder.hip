@@ -710,7 +710,8 @@ int upload_f16(vqa_encoder* e, const float* src, size_t n, _Float16* dst) {
 
 template <int EPI>
 int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, _Float16* C, int M, int N, int K, hipStream_t s) {
-    if (M >= 1024 && N % kBigBN == 0 && K % 64 == 0 && !getenv("VQA_GEMM_SMALL")) {
+    static const bool force_small = getenv("VQA_GEMM_SMALL") != nullptr;  // dev override, read once
+    if (M >= 1024 && N % kBigBN == 0 && K % 64 == 0 && !force_small) {
         static bool attr_set_dev[64] = {};
         int dev = 0;
         VQA_HIP_CHECK(hipGetDevice(&dev));
