@@ -39,8 +39,10 @@ def test_tiny_fixture_all_poolings(native_lib, golden_dir):
     enc.close()
 
 
-# (2, 40, 32) and (1, 64, 16): >= 1024 tokens run the 256 x 128 LDS-DMA GEMM (1280 tokens: a ragged last row tile)
-@pytest.mark.parametrize("layers,b,l", [(2, 8, 32), (12, 12, 24), (2, 3, 80), (1, 2, 256), (2, 40, 32), (1, 64, 16)])
+# (2, 40, 32) and (1, 64, 16): >= 1024 tokens run the 256 x 128 LDS-DMA GEMM (1280 tokens: a ragged last row tile);
+# (12, 1, 32), (2, 2, 32), (2, 3, 9): <= 64 tokens run the skinny GEMM (single query; full 4 token tiles; ragged 27 tokens)
+@pytest.mark.parametrize("layers,b,l", [(2, 8, 32), (12, 12, 24), (2, 3, 80), (1, 2, 256), (2, 40, 32), (1, 64, 16),
+                                        (12, 1, 32), (2, 2, 32), (2, 3, 9)])
 def test_phobert_base_shape_vs_oracle(native_lib, layers, b, l):
     from vietnamese_qa_system_amd.encoder import QuestionEncoder
     cfg = dict(E.PHOBERT_BASE, layers=layers)

@@ -417,6 +417,90 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const _Float16* __restric
     }
 }
 
+// ---- GEMM for a handful of tokens (M <= 64: single queries, the reference's own calling pattern heavy_ranker.py:97-98):
+// the work is streaming the weight matrix once.  One workgroup per 16 output features, its 4 waves split K four ways
+// (so even N = 768 puts 192 waves on the chip), operands go global -> registers (16 B per lane, the MFMA fragment itself:
+// weight rows as the A operand, token rows as the B operand), next K block prefetched while the current one multiplies;
+// the four partial tiles are summed through LDS and wave 0 applies bias / GELU and stores 8 bytes per lane.
+template <int EPI, int MT>  // MT token tiles of 16
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+                                                          const float* __restrict__ bias, _Float16* __restrict__ C, int M,
+                                                          int N, int K) {
+    __shared__ f32x4 red[3][MT][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int kq = K >> 2;  // this wave's K range: [wave * kq, +kq), a multiple of 64
+    const _Float16* wp = W + (size_t)(n0 + c) * K + wave * kq + 8 * g;
+    const _Float16* ap[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        const int row = mi * 16 + c < M ? mi * 16 + c : M - 1;  // rows past M are computed on a copy of the last row and dropped
+        ap[mi] = A + (size_t)row * K + wave * kq + 8 * g;
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    half8 w0 = *reinterpret_cast<const half8*>(wp), w1 = *reinterpret_cast<const half8*>(wp + 32);
+    half8 x0[MT], x1[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        x0[mi] = *reinterpret_cast<const half8*>(ap[mi]);
+        x1[mi] = *reinterpret_cast<const half8*>(ap[mi] + 32);
+    }
+    for (int k = 0; k < kq; k += 64) {
+        half8 nw0 = w0, nw1 = w1, nx0[MT], nx1[MT];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            nx0[mi] = x0[mi];
+            nx1[mi] = x1[mi];
+        }
+        if (k + 64 < kq) {  // next 64 k of this wave's range
+            nw0 = *reinterpret_cast<const half8*>(wp + k + 64);
+            nw1 = *reinterpret_cast<const half8*>(wp + k + 96);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+                nx0[mi] = *reinterpret_cast<const half8*>(ap[mi] + k + 64);
+                nx1[mi] = *reinterpret_cast<const half8*>(ap[mi] + k + 96);
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, x0[mi], acc[mi], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1, x1[mi], acc[mi], 0, 0, 0);
+        w0 = nw0;
+        w1 = nw1;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            x0[mi] = nx0[mi];
+            x1[mi] = nx1[mi];
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) red[wave - 1][mi][lane] = acc[mi];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    // acc[mi][j] = C[token 16 mi + c][feature n0 + 4 g + j]
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0 + 4 * g);
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        const int m = mi * 16 + c;
+        if (m >= M) continue;
+        const f32x4 sum = acc[mi] + red[0][mi][lane] + red[1][mi][lane] + red[2][mi][lane];
+        half4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = sum[j] + bv[j];
+            if (EPI == 1) v = gelu_erf(v);
+            o[j] = (_Float16)v;
+        }
+        *reinterpret_cast<half4*>(C + (size_t)m * N + n0 + 4 * g) = o;
+    }
+}
+
 // ---- attention: one workgroup per (sequence, head); K and V of the head in LDS (fp32), one wave per query row ------
 __global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ mask,
                                                         int L, int H, int heads, _Float16* __restrict__ ctx) {
@@ -711,6 +795,19 @@ int upload_f16(vqa_encoder* e, const float* src, size_t n, _Float16* dst) {
 template <int EPI>
 int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, _Float16* C, int M, int N, int K, hipStream_t s) {
     static const bool force_small = getenv("VQA_GEMM_SMALL") != nullptr;  // dev override, read once
+    if (M <= 64 && N % 16 == 0 && K % 256 == 0 && !force_small) {
+        const int mt = (M + 15) / 16;
+#define VQA_SKINNY(MT)                                                                                           \
+    case MT:                                                                                                     \
+        hipLaunchKernelGGL((gemm_skinny_kernel<EPI, MT>), dim3(N / 16), dim3(256), 0, s, A, W, bias, C, M, N, K); \
+        break;
+        switch (mt) {
+            VQA_SKINNY(1) VQA_SKINNY(2) VQA_SKINNY(3) VQA_SKINNY(4)
+        }
+#undef VQA_SKINNY
+        VQA_HIP_CHECK(hipGetLastError());
+        return VQA_OK;
+    }
     if (M >= 1024 && N % kBigBN == 0 && K % 64 == 0 && !force_small) {
         static bool attr_set_dev[64] = {};
         int dev = 0;
