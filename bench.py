@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: queries/sec (+ recall@10) of the dense-retrieval hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 50 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -81,8 +81,8 @@ def cpu_oracle_topk(shard, q, k, dtype, rows=None, chunk_rows=1 << 19):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)  # the chip's clock management settles over the first ~8 launches
     ap.add_argument("--docs-per-gpu", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--batch", type=int, default=256)
