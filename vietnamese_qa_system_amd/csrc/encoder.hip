@@ -430,12 +430,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const _Float16* __rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
+    const int m0 = blockIdx.y * (16 * MT);  // token chunk of this workgroup (more than 64 tokens: several chunks per feature slice)
     const int kq = K >> 2;  // this wave's K range: [wave * kq, +kq), a multiple of 64
     const _Float16* wp = W + (size_t)(n0 + c) * K + wave * kq + 8 * g;
     const _Float16* ap[MT];
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
-        const int row = mi * 16 + c < M ? mi * 16 + c : M - 1;  // rows past M are computed on a copy of the last row and dropped
+        const int row = m0 + mi * 16 + c < M ? m0 + mi * 16 + c : M - 1;  // rows past M: a copy of the last row, dropped
         ap[mi] = A + (size_t)row * K + wave * kq + 8 * g;
     }
     f32x4 acc[MT];
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const _Float16* __rest
     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0 + 4 * g);
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
-        const int m = mi * 16 + c;
+        const int m = m0 + mi * 16 + c;
         if (m >= M) continue;
         const f32x4 sum = acc[mi] + red[0][mi][lane] + red[1][mi][lane] + red[2][mi][lane];
         half4 o;
@@ -795,11 +796,13 @@ int upload_f16(vqa_encoder* e, const float* src, size_t n, _Float16* dst) {
 template <int EPI>
 int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, _Float16* C, int M, int N, int K, hipStream_t s) {
     static const bool force_small = getenv("VQA_GEMM_SMALL") != nullptr;  // dev override, read once
-    if (M <= 64 && N % 16 == 0 && K % 256 == 0 && !force_small) {
-        const int mt = (M + 15) / 16;
-#define VQA_SKINNY(MT)                                                                                           \
-    case MT:                                                                                                     \
-        hipLaunchKernelGGL((gemm_skinny_kernel<EPI, MT>), dim3(N / 16), dim3(256), 0, s, A, W, bias, C, M, N, K); \
+    static const int skinny_max = getenv("VQA_SKINNY_MAX") ? atoi(getenv("VQA_SKINNY_MAX")) : 512;  // dev override; measured crossover with the 128 x 128 kernel ~ 700 tokens
+    if (M <= skinny_max && N % 16 == 0 && K % 256 == 0 && !force_small) {
+        const int mt = M >= 64 ? 4 : (M + 15) / 16;
+        const int chunks = (M + 16 * mt - 1) / (16 * mt);
+#define VQA_SKINNY(MT)                                                                                                          \
+    case MT:                                                                                                                    \
+        hipLaunchKernelGGL((gemm_skinny_kernel<EPI, MT>), dim3(N / 16, chunks), dim3(256), 0, s, A, W, bias, C, M, N, K);        \
         break;
         switch (mt) {
             VQA_SKINNY(1) VQA_SKINNY(2) VQA_SKINNY(3) VQA_SKINNY(4)
