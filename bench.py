@@ -228,6 +228,7 @@ def main():
         print(json.dumps(result), flush=True)
     index.close()
     if world > 1:
+        dist.barrier()  # rank 0's recall check (CPU oracle, tens of seconds) ends before any rank tears the group down
         dist.destroy_process_group()
 
 
