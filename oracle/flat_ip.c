@@ -12,7 +12,7 @@
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  *
- * Build: gcc -O3 -march=native -fopenmp -shared -fPIC oracle/flat_ip.c -o oracle/libflat_ip.so
+ * Build: gcc -O3 -march=x86-64-v3 -fopenmp -shared -fPIC oracle/flat_ip.c -o oracle/libflat_ip.so
  */
 #include <math.h>
 #include <stdint.h>
