@@ -41,8 +41,10 @@ extern "C" {
 #define VQA_INDEX_HAS_IDS 1 /* reserve the id vector even though ids_or_null is NULL (filled later by vqa_index_set_rows) */
 
 /* limits of the fused scoring + top-k kernel */
-#define VQA_MAX_K 12       /* top-k per query found by ONE pass over the index (LDS candidate lists; BASELINE k = 10) */
-#define VQA_MAX_K_TOTAL 1024 /* larger k run ceil(k / 12) passes, each continuing strictly below the previous pass */
+#define VQA_MAX_K 12       /* top-k per query found by ONE exact pass over the index (LDS candidate lists; BASELINE k = 10) */
+#define VQA_MAX_K_TOTAL 1024 /* larger k: one pass keeping every workgroup's local top 12, verified on the device; when the
+                              * check fails, ceil(k / 12) exact passes (each continuing strictly below the previous one) run
+                              * behind a device-side gate */
 #define VQA_QUERY_TILE 256 /* queries scored per pass over the index (BASELINE batch = 256) */
 
 typedef struct vqa_index vqa_index;     /* opaque: one row shard of the corpus on one device */
@@ -82,7 +84,8 @@ int32_t vqa_index_dtype(const vqa_index* index);
  * out_scores [B, k] float and out_ids [B, k] int64 (device): best first; ties by row position ascending; when
  * the shard holds fewer than k rows the tail is padded with (-inf, -1).  out_pos_or_null [B, k] int64 receives
  * the row positions inside this shard (or NULL).  1 <= k <= VQA_MAX_K_TOTAL (k <= VQA_MAX_K: one pass over the index;
- * beyond that ceil(k / VQA_MAX_K) passes); any B >= 1 (processed in tiles of VQA_QUERY_TILE queries). */
+ * beyond that one verified pass, with ceil(k / VQA_MAX_K) gated exact passes as the fallback); any B >= 1 (processed in
+ * tiles of VQA_QUERY_TILE queries). */
 int vqa_index_search(vqa_index* index, const void* q, int32_t q_dtype, int32_t B, int32_t k, float* out_scores,
                      int64_t* out_ids, int64_t* out_pos_or_null, void* hip_stream);
 

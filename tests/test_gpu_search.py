@@ -182,6 +182,35 @@ def test_large_k_runs_continuation_passes(native_lib, n, d, b, k):
         assert np.all(np.isneginf(s[:, kk:])) and np.all(i[:, kk:] == -1)
 
 
+def test_large_k_clustered_rows_take_the_gated_fallback(native_lib, monkeypatch):
+    """k > 12 first tries ONE pass (every workgroup keeps its local top 12) and verifies it on the device; when one
+    workgroup owns more than 12 of the top-k the gated continuation passes must take over -- same exact result.  Here the
+    40 best rows of every query sit in one 256-row tile.  The multi-pass path alone (VQA_WIDE_K=0) must agree too."""
+    from vietnamese_qa_system_amd.index import DeviceIndex
+    n, d, b, k = 70001, 64, 5, 40
+    x, _ = _mk(n, d, b, seed=77)
+    rng = np.random.default_rng(5)
+    u = rng.standard_normal(d).astype(np.float32)
+    u /= np.linalg.norm(u)
+    q = R.l2_normalize(u + 0.03 * rng.standard_normal((b, d)).astype(np.float32)).astype(np.float16)  # queries around u
+    x[256:316] = R.l2_normalize(u + 0.03 * rng.standard_normal((60, d)).astype(np.float32)).astype(np.float16)  # so are 60 rows of tile 1
+    full = R.full_scores(q.astype(np.float32), x, R.DTYPE_F16)
+    top = np.argsort(-full, axis=1)[:, :k]
+    assert ((top >= 256) & (top < 316)).all()  # the whole top-40 of every query sits in one tile = one workgroup
+    results = []
+    for wide in ("1", "0"):
+        monkeypatch.setenv("VQA_WIDE_K", wide)
+        ix = DeviceIndex(x, id_base=1, dtype="fp16", device=0)
+        s, i, p = ix.search(torch.from_numpy(q).cuda(), k, return_positions=True)
+        torch.cuda.synchronize()
+        s, i, p = s.cpu().numpy(), i.cpu().numpy(), p.cpu().numpy()
+        ix.close()
+        R.check_topk(s, p, full, k, score_tol=SCORE_TOL, tie_tol=TIE_TOL)
+        assert np.array_equal(i, p + 1)
+        results.append((s, p))
+    assert np.array_equal(results[0][1], results[1][1]) and np.array_equal(results[0][0], results[1][0])
+
+
 def test_large_k_ties_across_pass_boundaries(native_lib, golden_dir):
     g = np.load(f"{golden_dir}/retr_ties.npz")
     x, q = g["x"].astype(np.float16), g["q"].astype(np.float16)

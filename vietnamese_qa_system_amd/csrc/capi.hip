@@ -45,6 +45,8 @@ struct vqa_index {
     vqa_key* partial = nullptr;  // [max_grid, 256, max(max_k, seeds per query)]: seed pass output, then main pass lists
     float* thr0 = nullptr;       // [256]
     vqa_key* upper = nullptr;    // [256] last key returned per query (continuation passes of a search with k > 12)
+    int* wide_flag = nullptr;    // 1 = the one-pass large-k result could not be verified: the gated continuation passes run
+    bool wide = true;            // VQA_WIDE_K=0 disables the one-pass large-k attempt
     // opt-in kernel timing (bench.py): event pairs around the main scoring kernel
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -73,6 +75,7 @@ extern "C" void vqa_index_destroy(vqa_index* ix) {
     if (ix->partial) (void)hipFree(ix->partial);
     if (ix->thr0) (void)hipFree(ix->thr0);
     if (ix->upper) (void)hipFree(ix->upper);
+    if (ix->wide_flag) (void)hipFree(ix->wide_flag);
     for (hipEvent_t e : ix->ev) (void)hipEventDestroy(e);
     delete ix;
 }
@@ -163,6 +166,8 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
     ix->max_grid = ix->num_cu;
     const char* tp = getenv("VQA_TWO_PASS");
     ix->two_pass = !(tp && tp[0] == '0');
+    const char* wk = getenv("VQA_WIDE_K");
+    ix->wide = !(wk && wk[0] == '0');
     const char* sm = getenv("VQA_SEED_MULT");
     if (sm && sm[0] >= '1' && sm[0] <= '4') ix->seed_mult = sm[0] - '0';
     const int eb = elem_bytes(dtype);
@@ -198,7 +203,8 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
         if (hipMalloc(&ix->q_stage, (size_t)VQA_QUERY_TILE * ix->d_pad * eb) != hipSuccess ||
             hipMalloc((void**)&ix->partial, (size_t)4 * ix->max_grid * VQA_QUERY_TILE * list_len * sizeof(vqa_key)) != hipSuccess ||
             hipMalloc((void**)&ix->thr0, VQA_QUERY_TILE * sizeof(float)) != hipSuccess ||
-            hipMalloc((void**)&ix->upper, VQA_QUERY_TILE * sizeof(vqa_key)) != hipSuccess) {
+            hipMalloc((void**)&ix->upper, VQA_QUERY_TILE * sizeof(vqa_key)) != hipSuccess ||
+            hipMalloc((void**)&ix->wide_flag, sizeof(int)) != hipSuccess) {
             vqa_set_error("vqa_index_create: workspace allocation failed");
             rc = VQA_ENOMEM;
             break;
@@ -361,7 +367,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             for (int done = 0; done < k; done += max_k) {
                 const int kk = k - done < max_k ? k - done : max_k;
                 int rc = vqa_launch_merge_partials(ix->partial, 1, max_k, nq, kk, ix->ids, ix->id_base, os, oi, op, nullptr, 1.0f, k,
-                                                   done, nullptr, false, stream);
+                                                   done, nullptr, false, nullptr, stream);
                 if (rc != VQA_OK) return rc;
             }
             continue;
@@ -369,7 +375,48 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
         int rc = vqa_launch_tile_rows(reinterpret_cast<const char*>(q) + (size_t)q0 * ix->d * qeb, q_dtype, 0, VQA_QUERY_TILE, nq,
                                       ix->d, ix->d_pad, ix->dtype, ix->scale, ix->q_stage, stream);
         if (rc != VQA_OK) return rc;
-        // k <= 12: one pass.  Larger k: further passes, each admitting only keys strictly below the last key already
+        // k <= 12: one pass.  Larger k, first attempt: ONE pass in which every workgroup keeps its local top 12 above the
+        // seeded threshold (the k-th largest seed, a valid lower bound of the k-th best score), merged to k results.  The
+        // global top-k is inside the union of the local lists unless some workgroup owns more than 12 of them (with 256
+        // workgroups: probability ~1e-10 at k = 256 on unclustered data); vqa_launch_verify_wide checks exactly that on
+        // the device and raises wide_flag.  The exact continuation passes below are then launched GATED on the flag: they
+        // return at once when the one-pass result stands (no host round trip), and overwrite it when it does not.
+        const int* gate = nullptr;
+        if (k > max_k && ix->wide && k <= 3 * p.grid1 && p.seed_tiles > 0) {
+            ScoreTopkArgs a;
+            a.x = ix->rows;
+            a.q = ix->q_stage;
+            a.n = ix->n;
+            a.d_pad = ix->d_pad;
+            a.nq = nq;
+            a.k = max_k;
+            a.upper = nullptr;
+            a.thr_init = nullptr;
+            a.partial = ix->partial;
+            a.tile_begin = 0;
+            a.tile_end = p.seed_tiles;
+            a.grid = p.grid0;
+            a.seed_only = true;
+            VQA_HIP_CHECK(hipMemsetAsync(ix->wide_flag, 0, sizeof(int), stream));
+            rc = vqa_launch_score_topk(ix->dtype, a, stream);
+            if (rc != VQA_OK) return rc;
+            rc = vqa_launch_merge_partials(ix->partial, p.seed_tiles, vqa_score_topk_seeds_per_tile(), nq, k, nullptr, 0, nullptr,
+                                           nullptr, nullptr, ix->thr0, 1.0f, k, 0, nullptr, true, nullptr, stream);
+            if (rc != VQA_OK) return rc;
+            a.thr_init = ix->thr0;
+            a.tile_end = p.tiles;
+            a.grid = p.grid1;
+            a.seed_only = false;
+            rc = vqa_launch_score_topk(ix->dtype, a, stream);
+            if (rc != VQA_OK) return rc;
+            rc = vqa_launch_merge_partials(ix->partial, p.grid1, max_k, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr,
+                                           1.0f / (ix->scale * ix->scale), k, 0, ix->upper, false, nullptr, stream);
+            if (rc != VQA_OK) return rc;
+            rc = vqa_launch_verify_wide(ix->partial, p.grid1, max_k, nq, ix->upper, ix->wide_flag, stream);
+            if (rc != VQA_OK) return rc;
+            gate = ix->wide_flag;
+        }
+        // Exact passes: k <= 12 needs one; larger k ceil(k / 12), each admitting only keys strictly below the last key already
         // returned (keys are distinct, so the continuation is exact); every pass is a full scan of the shard.
         for (int done = 0; done < k; done += max_k) {
             const int kk = k - done < max_k ? k - done : max_k;
@@ -382,6 +429,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             a.nq = nq;
             a.k = kk;
             a.upper = upper;
+            a.gate = gate;
             if (p.grid0 > 0) {
                 a.thr_init = nullptr;
                 a.partial = ix->partial;
@@ -392,7 +440,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
                 rc = vqa_launch_score_topk(ix->dtype, a, stream);
                 if (rc != VQA_OK) return rc;
                 rc = vqa_launch_merge_partials(ix->partial, p.seed_tiles, vqa_score_topk_seeds_per_tile(), nq, kk, nullptr, 0, nullptr,
-                                               nullptr, nullptr, ix->thr0, 1.0f, kk, 0, nullptr, true, stream);
+                                               nullptr, nullptr, ix->thr0, 1.0f, kk, 0, nullptr, true, gate, stream);
                 if (rc != VQA_OK) return rc;
             }
             a.thr_init = p.grid0 > 0 ? ix->thr0 : nullptr;
@@ -406,7 +454,8 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             if (rc != VQA_OK) return rc;
             if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
             rc = vqa_launch_merge_partials(ix->partial, p.grid1, kk, nq, kk, ix->ids, ix->id_base, os, oi, op, nullptr,
-                                           1.0f / (ix->scale * ix->scale), k, done, done + kk < k ? ix->upper : nullptr, false, stream);
+                                           1.0f / (ix->scale * ix->scale), k, done, done + kk < k ? ix->upper : nullptr, false, gate,
+                                           stream);
             if (rc != VQA_OK) return rc;
         }
     }

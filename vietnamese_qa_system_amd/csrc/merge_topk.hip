@@ -44,7 +44,9 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
                                                                        long long* __restrict__ out_pos,
                                                                        float* __restrict__ out_thr, float score_scale,
                                                                        int out_stride, int out_offset,
-                                                                       vqa_key* __restrict__ out_last_key, int query_major) {
+                                                                       vqa_key* __restrict__ out_last_key, int query_major,
+                                                                       const int* __restrict__ gate) {
+    if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     vqa_key* keys = reinterpret_cast<vqa_key*>(smem);    // [parts * list_len]
     vqa_key* red = keys + (size_t)parts * list_len;      // [4]
@@ -124,12 +126,31 @@ __global__ __launch_bounds__(kMergeThreads) void merge_shards_kernel(const float
     }
 }
 
+// One-pass large-k check (one thread per (query, workgroup list)): a FULL list whose last (smallest kept) key lies above the
+// query's k-th merged key may have dropped a row that belongs to the top-k.
+__global__ void verify_wide_kernel(const vqa_key* __restrict__ partial, int parts, int list_len, int nq,
+                                   const vqa_key* __restrict__ kth, int* __restrict__ flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= parts * nq) return;
+    const int p = i / nq, q = i - p * nq;
+    const vqa_key last = partial[((size_t)p * VQA_QUERY_TILE + q) * list_len + (list_len - 1)];
+    if (last != 0ull && last > kth[q]) atomicExch(flag, 1);
+}
+
 }  // namespace
+
+int vqa_launch_verify_wide(const vqa_key* partial, int32_t parts, int32_t list_len, int32_t nq, const vqa_key* kth, int* flag,
+                           hipStream_t stream) {
+    const int n = parts * nq;
+    hipLaunchKernelGGL(verify_wide_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, partial, parts, list_len, nq, kth, flag);
+    VQA_HIP_CHECK(hipGetLastError());
+    return VQA_OK;
+}
 
 int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t list_len, int32_t nq, int32_t k,
                               const int64_t* ids, int64_t id_base, float* out_scores, int64_t* out_ids, int64_t* out_pos,
                               float* out_thr, float score_scale, int32_t out_stride, int32_t out_offset,
-                              vqa_key* out_last_key, bool query_major, hipStream_t stream) {
+                              vqa_key* out_last_key, bool query_major, const int* gate, hipStream_t stream) {
     VQA_REQUIRE(parts >= 1 && list_len >= 1 && nq >= 1 && nq <= VQA_QUERY_TILE && k >= 1,
                 "merge_partials: bad shape parts=%d list_len=%d nq=%d k=%d", parts, list_len, nq, k);
     const size_t lds = ((size_t)parts * list_len + 4) * sizeof(vqa_key);
@@ -147,7 +168,7 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
     hipLaunchKernelGGL(merge_partials_kernel, dim3(nq), dim3(kMergeThreads), lds, stream, partial, parts, list_len, k,
                        reinterpret_cast<const long long*>(ids), (long long)id_base, out_scores,
                        reinterpret_cast<long long*>(out_ids), reinterpret_cast<long long*>(out_pos), out_thr, score_scale,
-                       out_stride, out_offset, out_last_key, query_major ? 1 : 0);
+                       out_stride, out_offset, out_last_key, query_major ? 1 : 0, gate);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

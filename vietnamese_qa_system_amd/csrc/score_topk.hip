@@ -290,7 +290,9 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
                                                               const float* __restrict__ thr_init,
                                                               const vqa_key* __restrict__ upper,
                                                               vqa_key* __restrict__ out, long long N, int KT, int nq, int k,
-                                                              int tile_begin, int tile_end) {
+                                                              int tile_begin, int tile_end, const int* __restrict__ gate) {
+    // gated launch (fallback passes of a large-k search, capi.hip): nothing to do when the one-pass result was verified
+    if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     Lists L;
     L.thr = reinterpret_cast<float*>(smem + kPipeBytes);
@@ -841,7 +843,7 @@ static int launch_dt(const ScoreTopkArgs& a, int KT, int lds, hipStream_t stream
     }
     auto kern = a.seed_only ? score_topk_kernel<0, DT> : score_topk_kernel<1, DT>;
     hipLaunchKernelGGL(kern, dim3(a.grid), dim3(kThreads), lds, stream, a.x, a.q, a.thr_init, a.upper, a.partial, (long long)a.n,
-                       KT, a.nq, a.k, a.tile_begin, a.tile_end);
+                       KT, a.nq, a.k, a.tile_begin, a.tile_end, a.gate);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

@@ -59,6 +59,7 @@ struct ScoreTopkArgs {
     int32_t tile_begin;   // first corpus tile (of 256 rows) this launch covers
     int32_t tile_end;     // one past the last
     int32_t grid;         // workgroups
+    const int* gate = nullptr;  // device flag or nullptr: the kernel returns at once when *gate == 0
     bool seed_only = false;  // MODE 0: writes 2 sub-maxima per query and tile to `partial` as [query][tile - tile_begin][2]
 };
 int vqa_launch_score_topk(int dtype, const ScoreTopkArgs& a, hipStream_t stream);
@@ -74,7 +75,11 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
                               int32_t out_stride /* row stride of the out arrays */, int32_t out_offset /* first column */,
                               vqa_key* out_last_key /* [nq] k-th key per query (0 when fewer exist) or nullptr */,
                               bool query_major /* lists are [query][parts][list_len] instead of [parts][256][list_len] */,
-                              hipStream_t stream);
+                              const int* gate /* device flag or nullptr: no-op when *gate == 0 */, hipStream_t stream);
+// one-pass large-k check: sets *flag = 1 when some workgroup's list (list_len keys, full) ends ABOVE the query's k-th merged
+// key `kth` -- that list may have dropped a row of the true top-k (capi.hip, vqa_index_search)
+int vqa_launch_verify_wide(const vqa_key* partial, int32_t parts, int32_t list_len, int32_t nq, const vqa_key* kth, int* flag,
+                           hipStream_t stream);
 
 // row-major [valid, d] f32|f16 rows (device) -> TILED layout, storage type `dtype`, at rows [first, first + count);
 // rows valid..count-1 are written as zeros (query tile: first = 0, count = 256, valid = nq); values are multiplied by
