@@ -84,6 +84,64 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
     }
 }
 
+// Large k: the k rounds of the selection kernel above cost ~1.5 us each; past k = 32 the lists are sorted instead --
+// bitonic sort of the (zero-padded, power-of-two) key array in LDS, descending, then the first k keys are the result.
+// Keys are distinct (score, position) pairs, so the sorted order is the result order.
+__global__ __launch_bounds__(kMergeThreads) void merge_partials_sort_kernel(const vqa_key* __restrict__ partial, int parts,
+                                                                            int list_len, int k, int m_pow2,
+                                                                            const long long* __restrict__ ids, long long id_base,
+                                                                            float* __restrict__ out_scores,
+                                                                            long long* __restrict__ out_ids,
+                                                                            long long* __restrict__ out_pos,
+                                                                            float* __restrict__ out_thr, float score_scale,
+                                                                            int out_stride, int out_offset,
+                                                                            vqa_key* __restrict__ out_last_key, int query_major,
+                                                                            const int* __restrict__ gate) {
+    if (gate && *gate == 0) return;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    vqa_key* keys = reinterpret_cast<vqa_key*>(smem);  // [m_pow2]
+    const int q = blockIdx.x;
+    const int m = parts * list_len;
+    for (int i = threadIdx.x; i < m_pow2; i += kMergeThreads) {
+        vqa_key v = 0ull;
+        if (i < m) {
+            if (query_major) {
+                v = partial[(size_t)q * m + i];
+            } else {
+                const int p = i / list_len, j = i - p * list_len;
+                v = partial[((size_t)p * VQA_QUERY_TILE + q) * list_len + j];
+            }
+        }
+        keys[i] = v;
+    }
+    __syncthreads();
+    for (int size = 2; size <= m_pow2; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = threadIdx.x; t < (m_pow2 >> 1); t += kMergeThreads) {
+                const int lo = ((t / stride) * stride << 1) + (t % stride), hi = lo + stride;
+                const bool desc = (lo & size) == 0;  // descending runs first: the final pass sorts the whole array descending
+                const vqa_key a = keys[lo], b = keys[hi];
+                if ((a < b) == desc) {
+                    keys[lo] = b;
+                    keys[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int r = threadIdx.x; r < k; r += kMergeThreads) {
+        const vqa_key best = r < m_pow2 ? keys[r] : 0ull;
+        const bool empty = best == 0ull;
+        const long long pos = empty ? -1 : (long long)vqa_key_pos(best);
+        const size_t o = (size_t)q * out_stride + out_offset + r;
+        if (out_scores) out_scores[o] = empty ? -INFINITY : vqa_key_score(best) * score_scale;
+        if (out_ids) out_ids[o] = empty ? -1 : (ids ? ids[pos] : id_base + pos);
+        if (out_pos) out_pos[o] = pos;
+        if (out_thr && r == k - 1) out_thr[q] = empty ? -INFINITY : vqa_key_score(best);
+        if (out_last_key && r == k - 1) out_last_key[q] = best;
+    }
+}
+
 __global__ __launch_bounds__(kMergeThreads) void merge_shards_kernel(const float* __restrict__ scores,
                                                                      const long long* __restrict__ ids,
                                                                      long long score_rank_stride, long long id_rank_stride,
@@ -163,6 +221,19 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
             VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(merge_partials_kernel),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             attr_set_dev[dev & 63] = true;
+        }
+    }
+    if (k > 32) {  // sort instead of k selection rounds
+        int m_pow2 = 1;
+        while (m_pow2 < parts * list_len) m_pow2 <<= 1;
+        const size_t lds_sort = (size_t)m_pow2 * sizeof(vqa_key);
+        if (lds_sort <= 64 * 1024) {
+            hipLaunchKernelGGL(merge_partials_sort_kernel, dim3(nq), dim3(kMergeThreads), lds_sort, stream, partial, parts, list_len,
+                               k, m_pow2, reinterpret_cast<const long long*>(ids), (long long)id_base, out_scores,
+                               reinterpret_cast<long long*>(out_ids), reinterpret_cast<long long*>(out_pos), out_thr, score_scale,
+                               out_stride, out_offset, out_last_key, query_major ? 1 : 0, gate);
+            VQA_HIP_CHECK(hipGetLastError());
+            return VQA_OK;
         }
     }
     hipLaunchKernelGGL(merge_partials_kernel, dim3(nq), dim3(kMergeThreads), lds, stream, partial, parts, list_len, k,
