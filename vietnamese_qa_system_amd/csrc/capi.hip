@@ -38,6 +38,7 @@ struct vqa_index {
     int max_grid = 0;
     bool two_pass = true;
     int seed_mult = 2;  // seed pass covers seed_mult * CUs tiles (VQA_SEED_MULT = 1..4)
+    int seed_div = 16;  // ... but at most 1 / seed_div of the shard's tiles (VQA_SEED_DIV: dev override, 0 = no cap)
     // workspace (allocated once; search never allocates)
     void* q_stage = nullptr;     // one 256-row tile in TILED layout
     void* q_rows = nullptr;      // staging for host -> device row chunks in set_rows (lazy)
@@ -168,6 +169,8 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
     ix->two_pass = !(tp && tp[0] == '0');
     const char* wk = getenv("VQA_WIDE_K");
     ix->wide = !(wk && wk[0] == '0');
+    const char* sd = getenv("VQA_SEED_DIV");
+    if (sd) ix->seed_div = atoi(sd);
     const char* sm = getenv("VQA_SEED_MULT");
     if (sm && sm[0] >= '1' && sm[0] <= '4') ix->seed_mult = sm[0] - '0';
     const int eb = elem_bytes(dtype);
@@ -286,8 +289,7 @@ static LaunchPlan plan_launch(const vqa_index* ix) {
         // more seed tiles = tighter starting thresholds = fewer appends; never more than 1/16 of a small shard
         // (a 1M-row fp32 shard spent 13 % of its search in the seed pass with the fixed count; 1/16: step 3.37 -> 3.19 ms)
         int want = ix->seed_mult * ix->max_grid;
-        const char* sd = getenv("VQA_SEED_DIV");
-        const int div = sd ? atoi(sd) : 16;  // VQA_SEED_DIV: dev override, 0 = no cap
+        const int div = ix->seed_div;
         if (div > 0 && want > p.tiles / div) want = p.tiles / div > 0 ? p.tiles / div : 1;
         p.seed_tiles = p.tiles < want ? p.tiles : want;
         p.grid0 = p.seed_tiles < ix->max_grid ? p.seed_tiles : ix->max_grid;
