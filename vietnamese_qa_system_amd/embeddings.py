@@ -245,17 +245,13 @@ class Embeddings:
                 texts = docstore.fetch_docs(self._docs_db, wanted)
             elif self._docs_mem is not None:
                 texts = {i: self._docs_mem[self._ext_id(i)].get("text") for i in set(wanted) if self._ext_id(i) in self._docs_mem}
-        out = []
-        for b in range(scores.shape[0]):
-            row = []
-            for j in range(scores.shape[1]):
-                if not keep[b, j]:
-                    continue
-                ext = self._ext_id(int(ids[b, j]))
-                sc = float(scores[b, j])
-                row.append({"id": ext, "text": texts.get(int(ids[b, j])), "score": sc} if self.content else (ext, sc))
-            out.append(row)
-        return out
+        # plain Python lists first: per-element numpy indexing costs more than the GPU search of a 256-query batch
+        il, sl, kl = ids.tolist(), scores.tolist(), keep.tolist()
+        ext = (lambda i: self._host_ids[i]) if self._host_ids is not None else (lambda i: i)
+        if self.content:
+            return [[{"id": ext(i), "text": texts.get(i), "score": s} for i, s, k in zip(ir, sr, kr) if k]
+                    for ir, sr, kr in zip(il, sl, kl)]
+        return [[(ext(i), s) for i, s, k in zip(ir, sr, kr) if k] for ir, sr, kr in zip(il, sl, kl)]
 
     def _ext_id(self, device_id: int):
         return self._host_ids[device_id] if self._host_ids is not None else device_id
