@@ -57,6 +57,23 @@ def test_phobert_base_shape_vs_oracle(native_lib, layers, b, l):
     enc.close()
 
 
+def test_baseline_config1_encoder_batch_at_full_size(native_lib):
+    """BASELINE configs[1]'s encoder batch at full size: PhoBERT-base shape, 12 layers, B = 256, L = 32 (8192 token rows,
+    the persistent LDS-DMA GEMM path) against the fp64 oracle -- every pooled vector, both poolings."""
+    from vietnamese_qa_system_amd.encoder import QuestionEncoder
+    cfg = dict(E.PHOBERT_BASE)
+    w = E.synthetic_weights(cfg, seed=0)
+    ids, mask = E.synthetic_tokens(cfg, 256, 32, seed=1)
+    enc = QuestionEncoder(w, cfg, max_tokens=256 * 32)
+    for pooling in ("cls", "mean"):
+        got = enc.forward(ids, mask, pooling=pooling).cpu().numpy()
+        ref = E.encode(w, cfg, ids, mask, pooling=pooling)
+        assert _cos(got, ref).min() > 0.999, (pooling, _cos(got, ref).min())
+        assert np.abs(got - ref).max() < 2e-2
+        assert np.abs(np.linalg.norm(got, axis=1) - 1).max() < 1e-5
+    enc.close()
+
+
 def test_small_batches_replay_a_graph(native_lib):
     """B * L <= 4096 tokens: the first call of a shape runs eagerly, the second captures a hipGraph over the encoder's
     staging buffers, later ones replay it -- every call must see ITS inputs and agree with the oracle."""

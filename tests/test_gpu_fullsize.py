@@ -45,6 +45,42 @@ def shard():
     del x
 
 
+def test_full_size_fp8_index_properties(native_lib, shard):
+    """The same shard as an fp8 (e4m3) index (7.68 GB): needles first in position order, shard invariance bit for bit,
+    and sampled exactness against the oracle scoring the SAME e4m3 codes (parity bar of the fp8 MFMA: 5e-5 / 1e-4)."""
+    from vietnamese_qa_system_amd.index import DeviceIndex, merge_topk
+    x, q, pos, dup = shard
+    xf = x  # fp16 source values; the index quantises 16 * x to e4m3 itself
+    full = DeviceIndex(xf, id_base=1, dtype="fp8", device=0)
+    s, i, p = full.search(q, K, return_positions=True)
+    torch.cuda.synchronize()
+    s_h, p_h = s.cpu().numpy(), p.cpu().numpy()
+    assert np.all(np.diff(s_h, axis=1) <= 0) and np.array_equal(i.cpu().numpy(), p_h + 1)
+    assert np.array_equal(p_h[:32, 0], pos) and np.array_equal(p_h[:32, 1], dup) and np.array_equal(s_h[:32, 0], s_h[:32, 1])
+    half = N // 2
+    lo = DeviceIndex(xf[:half], id_base=1, dtype="fp8", device=0)
+    s0, i0, _ = lo.search(q, K)
+    lo.close()
+    hi = DeviceIndex(xf[half:], id_base=1 + half, dtype="fp8", device=0)
+    s1, i1, _ = hi.search(q, K)
+    hi.close()
+    ms, mi = merge_topk(torch.stack([s0, s1]), torch.stack([i0, i1]), K)
+    torch.cuda.synchronize()
+    assert torch.equal(mi, i) and torch.equal(ms, s)
+    rng = np.random.default_rng(29)
+    sample = np.sort(rng.choice(N, size=min(N, 50_000), replace=False))
+    xs = x[torch.from_numpy(sample).to(x.device)].float().cpu().numpy()
+    codes = R.e4m3_encode(xs * 16.0)
+    qd = R.e4m3_decode(R.e4m3_encode(q.float().cpu().numpy() * 16.0)) / 256.0  # what the kernel multiplies, scores / 256
+    ref = R.full_scores(qd, codes, R.DTYPE_FP8_E4M3)
+    kth = s_h[:, K - 1][:, None].astype(np.float64)
+    beat = ref > kth + 1e-4
+    for b in range(B):
+        missing = set(sample[beat[b]].tolist()) - set(p_h[b].tolist())
+        assert not missing, f"query {b}: rows {sorted(missing)[:5]} beat the returned k-th score but are not in the result"
+    full.close()
+
+
 def test_full_size_properties(native_lib, shard):
     from vietnamese_qa_system_amd.index import DeviceIndex, merge_topk
     x, q, pos, dup = shard
