@@ -6,7 +6,7 @@ from vietnamese_qa_system_amd import build as b
 
 def one(spec):
     tag, _, defs = spec.partition(":")
-    return b.build_variant(tag, [d for d in defs.split(",") if d])
+    return b.build_variant(tag, [d for d in defs.split(",") if d])  # "tag:-mllvm -some-flag" passes raw hipcc flags
 
 with ThreadPoolExecutor(max_workers=3) as ex:
     for out in ex.map(one, sys.argv[1:]):

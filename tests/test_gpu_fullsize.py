@@ -96,6 +96,11 @@ def test_full_size_properties(native_lib, shard):
     assert np.array_equal(i_h, p_h + 1)
     assert all(len(set(row)) == K for row in p_h.tolist())
 
+    # ---- run to run: the append order inside a candidate list depends on wave timing, the result must not
+    for _ in range(3):
+        s2, i2, _ = full.search(q, K)
+        assert torch.equal(s2, s) and torch.equal(i2, i)
+
     # ---- planted needles: self-score = sum of squares of the stored fp16 values; the copy further down ties with it
     qq = q[:32].float().cpu().numpy()
     self_score = (qq.astype(np.float64) ** 2).sum(1)

@@ -60,7 +60,11 @@ def build(force: bool = False) -> str:
 def build_variant(tag: str, defines: list[str]) -> str:
     """Dev helper: a second copy of the library with extra -D flags (timing ablations), lib/libvqa_retrieval_<tag>.so."""
     os.makedirs(OBJ_DIR, exist_ok=True)
-    objs = [_compile(src, tuple(f"-D{d}" for d in defines), "_" + tag) for src in sources()]
+    # a "define" that starts with '-' is passed to hipcc as it is (compiler-flag experiments)
+    extra = []
+    for d in defines:
+        extra += d.split() if d.startswith("-") else [f"-D{d}"]
+    objs = [_compile(src, tuple(extra), "_" + tag) for src in sources()]
     out = os.path.join(LIB_DIR, f"libvqa_retrieval_{tag}.so")
     r = subprocess.run([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", out, *objs], capture_output=True, text=True)
     if r.returncode != 0:
