@@ -412,7 +412,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             rc = vqa_launch_score_topk(ix->dtype, a, stream);
             if (rc != VQA_OK) return rc;
             rc = vqa_launch_merge_partials(ix->partial, p.grid1, max_k, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr,
-                                           1.0f / (ix->scale * ix->scale), k, 0, ix->upper, false, nullptr, stream);
+                                           1.0f / (ix->scale * ix->scale), k, 0, ix->upper, true, nullptr, stream);
             if (rc != VQA_OK) return rc;
             rc = vqa_launch_verify_wide(ix->partial, p.grid1, max_k, nq, ix->upper, ix->wide_flag, stream);
             if (rc != VQA_OK) return rc;
@@ -456,7 +456,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             if (rc != VQA_OK) return rc;
             if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
             rc = vqa_launch_merge_partials(ix->partial, p.grid1, kk, nq, kk, ix->ids, ix->id_base, os, oi, op, nullptr,
-                                           1.0f / (ix->scale * ix->scale), k, done, done + kk < k ? ix->upper : nullptr, false, gate,
+                                           1.0f / (ix->scale * ix->scale), k, done, done + kk < k ? ix->upper : nullptr, true, gate,
                                            stream);
             if (rc != VQA_OK) return rc;
         }

@@ -191,7 +191,7 @@ __global__ void verify_wide_kernel(const vqa_key* __restrict__ partial, int part
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= parts * nq) return;
     const int p = i / nq, q = i - p * nq;
-    const vqa_key last = partial[((size_t)p * VQA_QUERY_TILE + q) * list_len + (list_len - 1)];
+    const vqa_key last = partial[((size_t)q * parts + p) * list_len + (list_len - 1)];  // lists are query-major
     if (last != 0ull && last > kth[q]) atomicExch(flag, 1);
 }
 

@@ -806,10 +806,10 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     __syncthreads();
     compact_pass(L, wave, lane, k, 1, kCap);
     __syncthreads();
-    vqa_key* dst = out + (size_t)blockIdx.x * kQ * k;
+    // query-major [query][workgroup][k]: K2 then reads one contiguous run per query
     for (int i = tid; i < kQ * k; i += kThreads) {
         const int q = i / k, j = i - q * k;
-        dst[i] = j < list_count(L, q) ? L.cand[q * kCap + j] : 0ull;
+        out[((size_t)q * gridDim.x + blockIdx.x) * k + j] = j < list_count(L, q) ? L.cand[q * kCap + j] : 0ull;
     }
 }
 

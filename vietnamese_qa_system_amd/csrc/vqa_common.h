@@ -51,7 +51,7 @@ struct ScoreTopkArgs {
     const void* q;        // staged query tile, same layout (one tile), zero padded
     const float* thr_init; // [VQA_QUERY_TILE] starting thresholds or nullptr (-inf)
     const vqa_key* upper = nullptr;  // [VQA_QUERY_TILE] exclusive upper bound keys (continuation passes) or nullptr
-    vqa_key* partial;     // [grid, VQA_QUERY_TILE, k] per-workgroup sorted partial lists (output)
+    vqa_key* partial;     // main pass: [VQA_QUERY_TILE, grid, k] per-workgroup sorted partial lists, query-major (output)
     int64_t n;            // rows in the shard
     int32_t d_pad;        // padded row length in elements (multiple of 64)
     int32_t nq;           // valid queries in the tile (1..VQA_QUERY_TILE)
