@@ -1023,8 +1023,8 @@ extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, con
     vqa_encoder::Graph* gr = nullptr;
     for (auto& c : e->graphs)
         if (c.B == B && c.L == L && c.pooling == pooling && c.normalize == normalize) gr = &c;
-    if (!gr) {  // first call of this shape: eager (sets the kernels' attributes), remembered
-        e->graphs.push_back({B, L, pooling, normalize, nullptr, true});
+    if (!gr) {  // first call of this shape: eager (sets the kernels' attributes), remembered -- up to 64 shapes, then eager only
+        if (e->graphs.size() < 64) e->graphs.push_back({B, L, pooling, normalize, nullptr, true});
         return encoder_launch(e, input_ids, attn_mask, B, L, pooling, normalize, out, s);
     }
     const size_t H = e->cfg.hidden;
