@@ -36,8 +36,12 @@ def test_exported_dynamic_symbols_are_only_ours(native_lib):
     assert set(declared_symbols()) <= exported
 
 
-def test_code_object_targets_gfx950_only(native_lib):
-    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", native_lib], capture_output=True, text=True)
+def test_code_object_targets_gfx950_only(native_lib, tmp_path):
+    # llvm-objdump --offloading drops the extracted bundles next to its input: work on a copy outside the tree
+    import shutil
+    copy = shutil.copy(native_lib, tmp_path / "lib.so")
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", str(copy)], capture_output=True, text=True,
+                         cwd=tmp_path)
     archs = set(re.findall(r"gfx[0-9a-f]+", out.stdout + out.stderr))
     assert archs == {"gfx950"}, archs
 
