@@ -7,6 +7,7 @@ GPU box; it is git-ignored (``*.so``).  hipcc cross-compiles gfx950 without a GP
 """
 from __future__ import annotations
 
+import fcntl
 import os
 import subprocess
 import sys
@@ -32,10 +33,29 @@ def _deps_mtime() -> float:
     return max(os.path.getmtime(f) for f in files)
 
 
+_TOOL_ENV_PREFIXES = ("ROCP", "ROCPROF", "HSA_TOOLS", "ROCTX", "RPD_")
+
+
+def _clean_env() -> dict:
+    """Environment for the hipcc child: a profiler's preload / tool variables are dropped.  Under ``rocprofv3`` the
+    preloaded tool library initialises the GPU in every process it is loaded into, and hipcc then ``exec``s clang --
+    an exec from a GPU-initialised process, which takes a machine of this pool down.  The compiler needs none of them."""
+    env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(_TOOL_ENV_PREFIXES)}
+    return env
+
+
+def under_profiler() -> bool:
+    return "LD_PRELOAD" in os.environ or any(k.startswith(_TOOL_ENV_PREFIXES) for k in os.environ)
+
+
+def is_fresh() -> bool:
+    return os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= _deps_mtime()
+
+
 def _compile(src: str, extra=(), tag: str = "") -> str:
     obj = os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + tag + ".o")
     cmd = [HIPCC, *FLAGS, *extra, "-c", src, "-o", obj]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=_clean_env())
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
     if r.stderr.strip():
@@ -45,15 +65,25 @@ def _compile(src: str, extra=(), tag: str = "") -> str:
 
 def build(force: bool = False) -> str:
     """Compile every .hip under csrc/ for gfx950 and link the C-ABI shared library.  Returns its path."""
-    if not force and os.path.exists(LIB_PATH) and os.path.getmtime(LIB_PATH) >= _deps_mtime():
+    if not force and is_fresh():
         return LIB_PATH
     os.makedirs(OBJ_DIR, exist_ok=True)
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        objs = list(ex.map(_compile, sources()))
-    cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB_PATH, *objs]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    # one builder at a time (the ranks of a torch.distributed.run job all call this before they touch the GPU)
+    with open(os.path.join(LIB_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and is_fresh():
+                return LIB_PATH
+            with ThreadPoolExecutor(max_workers=4) as ex:
+                objs = list(ex.map(_compile, sources()))
+            tmp = LIB_PATH + f".tmp{os.getpid()}"
+            cmd = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", tmp, *objs]
+            r = subprocess.run(cmd, capture_output=True, text=True, env=_clean_env())
+            if r.returncode != 0:
+                raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+            os.replace(tmp, LIB_PATH)  # a reader never sees a half-written library
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
@@ -66,7 +96,8 @@ def build_variant(tag: str, defines: list[str]) -> str:
         extra += d.split() if d.startswith("-") else [f"-D{d}"]
     objs = [_compile(src, tuple(extra), "_" + tag) for src in sources()]
     out = os.path.join(LIB_DIR, f"libvqa_retrieval_{tag}.so")
-    r = subprocess.run([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", out, *objs], capture_output=True, text=True)
+    r = subprocess.run([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", out, *objs], capture_output=True, text=True,
+                       env=_clean_env())
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     return out

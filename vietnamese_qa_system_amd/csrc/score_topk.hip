@@ -285,6 +285,36 @@ __device__ __forceinline__ void block_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+#ifdef VQA_STAMPS
+// dev-only diagnostic build (scripts/stamp_timeline.py): s_memtime stamps of one workgroup's K-steps during one tile, written
+// by scalar stores to a buffer no other code reads.  Stamp values arrive asynchronously (SMEM): they are only stored after
+// an lgkmcnt(0).  The instrumentation itself costs ~10 % (measured), so it is never part of the product build.
+constexpr int kStampWg = 5, kStampTile = 40, kStampSlots = 8;
+__device__ unsigned long long g_stamps[8 * 64 * kStampSlots];
+#define VQA_STAMP(J)                                                              \
+    do {                                                                          \
+        VQA_SB();                                                                 \
+        if (stamp_on) asm volatile("s_memtime %0" : "=s"(stamp_t[J]));            \
+        VQA_SB();                                                                 \
+    } while (0)
+#define VQA_STAMP_FLUSH(KT)                                                                                            \
+    do {                                                                                                               \
+        if (stamp_on) {                                                                                                \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+            unsigned long long* sp_ = g_stamps + ((size_t)wave * 64 + (KT)) * kStampSlots;                             \
+            asm volatile(                                                                                              \
+                "s_store_dwordx2 %1, %0, 0x0\n\ts_store_dwordx2 %2, %0, 0x8\n\ts_store_dwordx2 %3, %0, 0x10\n\t"        \
+                "s_store_dwordx2 %4, %0, 0x18\n\ts_store_dwordx2 %5, %0, 0x20\n\ts_store_dwordx2 %6, %0, 0x28\n\t"      \
+                "s_store_dwordx2 %7, %0, 0x30\n\ts_store_dwordx2 %8, %0, 0x38"                                           \
+                :: "s"(sp_), "s"(stamp_t[0]), "s"(stamp_t[1]), "s"(stamp_t[2]), "s"(stamp_t[3]), "s"(stamp_t[4]),       \
+                   "s"(stamp_t[5]), "s"(stamp_t[6]), "s"(stamp_t[7]) : "memory");                                       \
+        }                                                                                                              \
+    } while (0)
+#else
+#define VQA_STAMP(J) (void)0
+#define VQA_STAMP_FLUSH(KT) (void)0
+#endif
+
 template <int MODE, int DT>
 __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __restrict__ X, const void* __restrict__ Qs,
                                                               const float* __restrict__ thr_init,
@@ -446,22 +476,34 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
 // One K-step: fragments in (CA, CB) are multiplied; the next K-step's go to (NA, NB) when PREFETCH.
 #define VQA_KSTEP(CA, CB, NA, NB, KAPPA, PREFETCH)                 \
     do {                                                           \
+        VQA_STAMP(0);                                              \
         if (!kMemFirst) {                                          \
             VQA_MMA_RANGE(CA, CB, 0, VQA_SPLIT);                   \
             VQA_SB();                                              \
+            VQA_STAMP(1);                                          \
             if (PREFETCH) VQA_READ_FRAGS(NA, NB);                  \
+            VQA_STAMP(2);                                          \
             VQA_ISSUE();                                           \
             VQA_SB();                                              \
+            VQA_STAMP(3);                                          \
             VQA_MMA_RANGE(CA, CB, VQA_SPLIT, 8);                   \
         } else {                                                   \
+            VQA_STAMP(1);                                          \
             if (PREFETCH) VQA_READ_FRAGS(NA, NB);                  \
+            VQA_STAMP(2);                                          \
             VQA_ISSUE();                                           \
             VQA_SB();                                              \
+            VQA_STAMP(3);                                          \
             VQA_MMA(CA, CB);                                       \
         }                                                          \
+        VQA_STAMP(4);                                              \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         \
+        VQA_STAMP(5);                                              \
         wait_pieces((KAPPA) + 2);                                  \
+        VQA_STAMP(6);                                              \
         VQA_LOOP_BARRIER();                                        \
+        VQA_STAMP(7);                                              \
+        VQA_STAMP_FLUSH((KAPPA) - ti * KT);                        \
     } while (0)
 
     // ---- epilogue pieces (shared by both loop forms); scores stay in registers -----------------------------------
@@ -558,6 +600,39 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         return refused;
     };
 
+    // ---- tile epilogue shared by the fp16 / fp32 loop forms: threshold test + appends (MODE 1) or sub-maxima (MODE 0).
+    // `ext_stage`: an X ring stage that stays idle until every wave has passed the next workgroup barrier
+    auto finish_tile = [&](f32x4 (&acc)[8][4], int ti, int ext_stage) __attribute__((always_inline)) {
+        const uint32_t row0 = ((uint32_t)first_tile + (uint32_t)ti * gridDim.x) * kTileRows;  // n < 2^32 rows
+        mask_ragged(acc, row0);
+        if (MODE == 0) {
+            seed_epilogue(acc, row0, ti);
+            return;
+        }
+        L.ext = reinterpret_cast<vqa_key*>(smem + ext_stage * kOperandBytes);
+        constexpr int kSpill = kExt;
+        uint32_t pend[4];  // accumulators whose append was refused (list full): retried below
+        // every wave passed the re-align barrier after its last fragment reads completed, so the idle stage (L.ext)
+        // is free: a list holds up to kCap + kExt keys inside this epilogue and is back below kCap when it ends
+        // (water <= kCap: every list that spilled into L.ext is compacted).
+        if (append_epilogue(acc, row0, pend, kSpill)) atomicOr(&L.cnt[0], kOverBit);
+        __syncthreads();
+        for (;;) {
+            const int over = L.cnt[0] & kOverBit;  // stable here: set before the barrier above, cleared only behind the next
+            // normal tiles: compact lists that are nearly full; after a refusal: compact everything above k
+            compact_pass(L, wave, lane, k, over ? k + 1 : k + (kCap - k + 1) / 2, kCap + kSpill);
+            // Fast path: no trailing barrier.  What compaction wrote (thr, cnt, cand) is next read in the next tile's
+            // epilogue, 24+ barriers away; the spill stage L.ext is refilled only behind the next tile's first barrier,
+            // which no wave passes before every wave has finished compacting.
+            if (!over) break;
+            __syncthreads();
+            if (tid == 0) L.cnt[0] &= ~kOverBit;
+            __syncthreads();
+            if (process_pending(L, acc, pend, wm, wn, c, g, row0, upper, kSpill)) atomicOr(&L.cnt[0], kOverBit);
+            __syncthreads();
+        }
+    };
+
     // ---- fp16 / fp32: one barrier per K-step, the two groups memory-first / matrix-first ----------------------------
     // The whole tile loop exists twice (group 0: memory instructions first, group 1: matrix instructions first) and
     // the wave-uniform branch sits OUTSIDE it: a diamond around each K-step makes hipcc spill the accumulators.
@@ -591,6 +666,10 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         // matrix pipe while its partner starts with memory instructions.
         // (the first fragments of this tile were read before the loop / under the previous tile's last K-step, so their
         // LDS latency and the pipeline refill hide under the previous tile's epilogue)
+#ifdef VQA_STAMPS
+        const bool stamp_on = blockIdx.x == kStampWg && ti == kStampTile;
+        unsigned long long stamp_t[kStampSlots] = {};
+#endif
         if constexpr (DT == VQA_F16) {
             frag_t a1[8], b1[4];  // second register set: the next K-step's fragments load under this K-step's MFMAs
             for (int kt = 0; kt < KT; kt += 2) {  // KT is even (rows are padded to two K-steps)
@@ -614,39 +693,162 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
             }
         }
 
-        // ---- epilogue ------------------------------------------------------------------------------------------------
-        const uint32_t row0 = ((uint32_t)first_tile + (uint32_t)ti * gridDim.x) * kTileRows;  // n < 2^32 rows
-        mask_ragged(acc, row0);
-        if (MODE == 0) {
-            seed_epilogue(acc, row0, ti);
-            continue;
-        }
         // X stage of the tile's last K-step: every read of it completed before the re-align barrier and its next
         // refill (K-step + kSx) is issued in the next tile's first L segment
-        L.ext = reinterpret_cast<vqa_key*>(smem + (sx == 0 ? kSx - 1 : sx - 1) * kOperandBytes);
-        constexpr int kSpill = kExt;
         static_assert(kPx < kSx, "the X stage of the K-step just computed must idle until the next K-step's pieces are issued");
-        uint32_t pend[4];  // accumulators whose append was refused (list full): retried below
-        // every wave passed the re-align barrier after its last fragment reads completed, so the idle stage (L.ext)
-        // is free: a list holds up to kCap + kExt keys inside this epilogue and is back below kCap when it ends
-        // (water <= kCap: every list that spilled into L.ext is compacted).
-        if (append_epilogue(acc, row0, pend, kSpill)) atomicOr(&L.cnt[0], kOverBit);
-        __syncthreads();
-        for (;;) {
-            const int over = L.cnt[0] & kOverBit;  // stable here: set before the barrier above, cleared only behind the next
-            // normal tiles: compact lists that are nearly full; after a refusal: compact everything above k
-            compact_pass(L, wave, lane, k, over ? k + 1 : k + (kCap - k + 1) / 2, kCap + kSpill);
-            // Fast path: no trailing barrier.  What compaction wrote (thr, cnt, cand) is next read in the next tile's
-            // epilogue, 24+ barriers away; the spill stage L.ext is refilled only behind the next tile's first barrier,
-            // which no wave passes before every wave has finished compacting.
-            if (!over) break;
-            __syncthreads();
-            if (tid == 0) L.cnt[0] &= ~kOverBit;
-            __syncthreads();
-            if (process_pending(L, acc, pend, wm, wn, c, g, row0, upper, kSpill)) atomicOr(&L.cnt[0], kOverBit);
-            __syncthreads();
-        }
+        finish_tile(acc, ti, (sx == 0 ? kSx - 1 : sx - 1));
     }
+    };
+
+#ifndef VQA_SLOT
+#define VQA_SLOT 1  // fp16: 1 = anti-phase slot loop below, 0 = tile_loop (one barrier per K-step; measured 4 % slower)
+#endif
+    // ---- fp16, anti-phase slots: two barriers per K-step, and in every slot one group only multiplies while the other
+    // only moves data, so the two waves of a SIMD (one of each group) never compete for the matrix pipe and never leave
+    // it idle behind each other's memory phases (stamped timeline of tile_loop: the younger wave's second MFMA half waits
+    // for the older wave's whole MFMA block, then everything waits for it at the barrier).
+    //     K-step kappa, slot 1:  group 0: read fragments(kappa), issue Q(kappa + 2)   | group 1: 32 MFMAs of kappa
+    //                  slot 2:  group 0: 32 MFMAs of kappa                            | group 1: read fragments(kappa + 1), issue X(kappa + 5)
+    // A wave never reads and multiplies at the same time, so ONE fragment register set suffices.  Rings: X 5 stages
+    // (X(kappa + 5) goes where X(kappa) was: last read in slot 1), Q 3 stages (Q(kappa + 2) goes where Q(kappa - 1) was);
+    // together the same 128 KiB.  Waits: group 0 ends slot 1 with vmcnt(4) (Q(kappa + 1) landed for group 1's reads in
+    // slot 2); group 1 ends slot 1 with vmcnt(12) (X(kappa + 1) landed, three K-steps stay in flight).
+    // Pieces are always issued (past the end of the stream: the last block again, into a stage nobody reads any more).
+    // MODE 1: the X stage of a tile's last K-step is the epilogue's spill area (finish_tile), so group 1 holds that
+    // K-step's issue back to the next tile's first K-step (two issues there, vmcnt(8) in between).
+    auto slot_loop = [&](auto loader_q_tag) __attribute__((always_inline)) {
+        constexpr bool kQ0 = decltype(loader_q_tag)::value;  // group 0: Q loader, multiplies in slot 2
+        constexpr int SX = 5, SQ = 3;
+        static_assert((SX + SQ) * kOperandBytes == kPipeBytes, "slot loop rings fill the pipe area");
+        const uint32_t ring_lds = kQ0 ? smem_lds + SX * kOperandBytes : smem_lds;
+        constexpr int kRing = (kQ0 ? SQ : SX) * kOperandBytes;
+        const char* src = kQ0 ? reinterpret_cast<const char*>(Qs)
+                              : reinterpret_cast<const char*>(X) + (size_t)first_tile * KT * kOperandBytes;
+        uint32_t dst = ring_lds + lw * 4096;
+        int n_issued = 0, src_kt = 0;
+        auto issue = [&]() __attribute__((always_inline)) {
+            if constexpr (kQ0) glds16x4<false>(src, voff, dst);
+            else glds16x4<VQA_XNT != 0>(src, voff, dst);
+            ++n_issued;
+            if (n_issued < total) {  // past the end the cursor stays on the last block
+                src += kOperandBytes;
+                if (++src_kt == KT) {
+                    src_kt = 0;
+                    if constexpr (kQ0) src = reinterpret_cast<const char*>(Qs);
+                    else src += tile_jump;
+                }
+            }
+            dst += kOperandBytes;
+            if (dst >= ring_lds + kRing) dst -= kRing;
+        };
+        const int a_off = wm * 128 * kRowBytes + frag_off;                          // inside an X stage
+        const int b_off = SX * kOperandBytes + wn * 64 * kRowBytes + frag_off;      // inside a Q stage
+        int rx = 0, rq = 0;  // stages of the K-step this group reads next
+        frag_t fa[8], fb[4];
+#define VQA_SLOT_READ()                                                                                            \
+    do {                                                                                                           \
+        const char* xbuf_ = smem + rx * kOperandBytes;                                                             \
+        const char* qbuf_ = smem + rq * kOperandBytes;                                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                           \
+            fb[i_] = *reinterpret_cast<const frag_t*>(qbuf_ + b_off + i_ * 16 * kRowBytes);                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                           \
+            fa[i_] = *reinterpret_cast<const frag_t*>(xbuf_ + a_off + i_ * 16 * kRowBytes);                        \
+        if (++rx == SX) rx = 0;                                                                                    \
+        if (++rq == SQ) rq = 0;                                                                                    \
+    } while (0)
+#ifdef VQA_SLOT_SETPRIO
+#define VQA_SLOT_PRIO(P) __builtin_amdgcn_s_setprio(P)
+#else
+#define VQA_SLOT_PRIO(P) (void)0
+#endif
+// the MFMAs are register-only: these pins keep hipcc from moving them across the slot's barriers
+#define VQA_SLOT_MMA()                                                                                             \
+    do {                                                                                                           \
+        asm volatile("" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), \
+                     "+v"(fa[7]));                                                                                 \
+        VQA_SB();                                                                                                  \
+        VQA_SLOT_PRIO(1);                                                                                          \
+        mma_block<DT, 0, 8>(acc, fa, fb);                                                                          \
+        _Pragma("unroll") for (int mi_ = 0; mi_ < 8; ++mi_)                                                        \
+            asm volatile("" ::"v"(acc[mi_][0]), "v"(acc[mi_][1]), "v"(acc[mi_][2]), "v"(acc[mi_][3]));             \
+        VQA_SLOT_PRIO(0);                                                                                          \
+        VQA_SB();                                                                                                  \
+    } while (0)
+        // prologue: Q(0), Q(1) / X(0 .. 4) issued; K-step 0 landed; group 1 holds fragments(0)
+        if constexpr (kQ0) {
+            issue();
+            issue();
+            wait_vmcnt<4>();
+        } else {
+            for (int i = 0; i < SX; ++i) issue();
+            wait_vmcnt<4 * (SX - 1)>();
+        }
+        block_barrier();
+        if constexpr (!kQ0) {
+            VQA_SLOT_READ();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        block_barrier();
+        bool owe = false;  // group 1: an issue was held back at the end of the previous tile
+        for (int ti = 0; ti < ntile; ++ti) {
+            f32x4 acc[8][4];
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef VQA_STAMPS
+            const bool stamp_on = blockIdx.x == kStampWg && ti == kStampTile;
+            unsigned long long stamp_t[kStampSlots] = {};
+#endif
+            int ext_stage = 0;
+            for (int kt = 0; kt < KT; ++kt) {
+                VQA_STAMP(0);
+                // ---- slot 1
+                if constexpr (kQ0) {
+                    VQA_SLOT_READ();
+                    VQA_STAMP(1);
+                    issue();
+                    VQA_STAMP(2);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    wait_vmcnt<4>();
+                } else {
+                    VQA_SLOT_MMA();
+                    VQA_STAMP(1);
+                    if (owe) wait_vmcnt<8>();
+                    else wait_vmcnt<12>();
+                    VQA_STAMP(2);
+                }
+                VQA_STAMP(3);
+                block_barrier();
+                VQA_STAMP(4);
+                // ---- slot 2
+                if constexpr (kQ0) {
+                    VQA_SLOT_MMA();
+                    VQA_STAMP(5);
+                    VQA_STAMP(6);
+                } else {
+                    if (kt == KT - 1) ext_stage = rx == 0 ? SX - 1 : rx - 1;  // stage of this tile's last K-step
+                    VQA_SLOT_READ();
+                    VQA_STAMP(5);
+                    if (owe) {
+                        issue();
+                        owe = false;
+                    }
+                    if (MODE == 1 && kt == KT - 1) owe = true;
+                    else issue();
+                    VQA_STAMP(6);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                block_barrier();
+                VQA_STAMP(7);
+                VQA_STAMP_FLUSH(kt);
+            }
+            if constexpr (kQ0) ext_stage = rx == 0 ? SX - 1 : rx - 1;  // group 0 read this tile's last K-step last
+            finish_tile(acc, ti, ext_stage);
+        }
+        wait_vmcnt<0>();  // the pieces issued past the end of the stream land before this workgroup's LDS is released
+#undef VQA_SLOT_READ
+#undef VQA_SLOT_MMA
     };
 
     // ---- fp8: the block-scaled MFMA consumes two K-steps at once (32 bytes per lane and operand), so the loop works on
@@ -796,11 +998,17 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     if constexpr (kStagger) {
         if (grp) stagger_loop(std::false_type{});
         else stagger_loop(std::true_type{});
+    } else if constexpr (VQA_SLOT != 0 && DT == VQA_F16) {
+        if (grp) slot_loop(std::false_type{});
+        else slot_loop(std::true_type{});
     } else {
         if (grp) tile_loop(std::false_type{});
         else tile_loop(std::true_type{});
     }
 
+#ifdef VQA_STAMPS
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");
+#endif
     if (MODE == 0) return;
     // ---- flush: every list sorted best first, k keys per query (0 = empty) ------------------------------------
     __syncthreads();
@@ -862,3 +1070,10 @@ int vqa_launch_score_topk(int dtype, const ScoreTopkArgs& a, hipStream_t stream)
     if (dtype == VQA_FP8_E4M3) return launch_dt<VQA_FP8_E4M3>(a, KT, lds, stream);
     return launch_dt<VQA_F32>(a, KT, lds, stream);
 }
+
+#ifdef VQA_STAMPS
+extern "C" int vqa_debug_read_stamps(unsigned long long* out, int n) {
+    const size_t bytes = sizeof(unsigned long long) * (size_t)(n < 8 * 64 * kStampSlots ? n : 8 * 64 * kStampSlots);
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
