@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: queries/sec (+ recall@10) of the dense-retrieval hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus 1 --steps 100 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -9,6 +9,12 @@ A "step" = one pass of the hot path over one batch: 256 L2-normalised query vect
 row shard (10M x 768 fp16 per GPU by default = BASELINE.json configs[2]; N GPUs hold N x 10M rows = configs[3]
 at N = 8), fused MFMA scoring + top-10, and for N > 1 the RCCL all-gather of per-shard (score, id) candidates and
 the final merge.  Inputs (index, queries) are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Protocol: W untimed warm-up steps, then EXACTLY K steps between barrier + synchronize pairs
+(``ms_per_step`` / ``value`` come from that wall-clock bracket, max over ranks); every timed step is also bracketed by
+an event pair on its stream -> ``step_ms`` median / p10 / p90; the dominant kernel is timed by HIP events on its own
+launch stream inside the library (``roofline``).  After the timed region, outside it: recall@10 against the oracle over
+the full shard, an end-to-end leg (question encoder + search + merge) and the CPU baseline.
 
 The oracle (``oracle/``) is used here only (a) as the ``cpu_baseline`` timed on the host cores over a bounded sample
 and (b) as the checker for recall@10 -- never as the thing measured.
@@ -21,18 +27,29 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s measured copy rate)
 F32_MFMA_PEAK_TFLOPS = 157.3  # same guide, Matrix cores: f32-input MFMA = the f32 vector rate (155 measured)
+F16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: ~2.5 PF dense bf16/fp16
+FP8_SCALE = 16.0
 
 
-def build_shard(n, d, seed, device, dtype, chunk=1 << 18):
+def ensure_library():
+    """Build the HIP library BEFORE anything touches the GPU (all ranks call this; a file lock lets one build).  Under a
+    profiler the tool library initialises the GPU in every child it is preloaded into, so a stale library is refused
+    there instead of being rebuilt: run `python -m vietnamese_qa_system_amd.build` first."""
+    from vietnamese_qa_system_amd import build
+    if build.is_fresh():
+        return
+    if build.under_profiler():
+        raise SystemExit("libvqa_retrieval.so is stale and a profiler environment is active: build first with "
+                         "`python -m vietnamese_qa_system_amd.build`, then profile")
+    build.build()
+
+
+def build_shard(torch, n, d, seed, device, dtype, chunk=1 << 18):
     """Synthetic corpus shard generated ON the device: i.i.d. standard normal rows, L2-normalised in fp32
     (SURVEY.md section 8d); kept as fp16 for an fp16 index (= the stored values), as fp32 for fp32 / fp8 indexes."""
     gen = torch.Generator(device=device)
@@ -46,10 +63,7 @@ def build_shard(n, d, seed, device, dtype, chunk=1 << 18):
     return buf
 
 
-FP8_SCALE = 16.0
-
-
-def cpu_oracle_topk(shard, q, k, dtype, rows=None, chunk_rows=1 << 19):
+def cpu_oracle_topk(np, shard, q, k, dtype, rows=None, chunk_rows=1 << 19):
     """Exact top-k of the oracle over the first ``rows`` rows of the device shard, streamed to the host in chunks.
     ``dtype``: 'fp16' / 'fp32' score the stored values as they are; 'fp8' scores the e4m3 codes of 16 * x (rows and
     queries, exactly what the index stores) and divides by 256; 'ref32' scores the un-quantised fp32 rows."""
@@ -78,11 +92,67 @@ def cpu_oracle_topk(shard, q, k, dtype, rows=None, chunk_rows=1 << 19):
     return best_s, best_p
 
 
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def percentiles(np, xs):
+    a = np.asarray(xs, dtype=np.float64)
+    return {"median": round(float(np.median(a)), 4), "p10": round(float(np.percentile(a, 10)), 4),
+            "p90": round(float(np.percentile(a, 90)), 4), "min": round(float(a.min()), 4), "max": round(float(a.max()), 4)}
+
+
+def cpu_baseline(np, torch, shard, q_host, k, dtype, n, sample_rows, budget_s=25.0):
+    """The oracle's blocked flat inner-product search (oracle/retrieval.py:search_blocked = fp32 GEMM on the host BLAS +
+    exact top-k per block: faiss IndexFlatIP semantics) timed on the host cores over a BOUNDED sample of the same
+    workload, host-resident fp32 rows (the device->host copy is outside the timing).  B = 256 and B = 1 (the
+    reference's own calling pattern, heavy_ranker.py:97-98) at 1k / 100k / sample rows."""
+    from oracle import retrieval as R
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    rows = min(sample_rows, n)
+    x = shard[:rows].cpu()
+    if dtype == "fp8":  # the values an fp8 index scores: e4m3(16 x) / 16
+        x = torch.from_numpy(R.e4m3_decode(R.e4m3_encode(x.numpy() * FP8_SCALE)) / FP8_SCALE)
+    x = x.float().contiguous()
+    q32 = np.ascontiguousarray(q_host, dtype=np.float32)
+    R.search_blocked(q32[:8], x[:4096], k)  # BLAS / thread pool warm-up
+    points, spent = [], 0.0
+    for nrows in sorted({min(1000, rows), min(100_000, rows), rows}):
+        for b in (q32.shape[0], 1):
+            reps, best = 0, float("inf")
+            t_begin = time.perf_counter()
+            while reps < 5 and (reps < 2 or time.perf_counter() - t_begin < budget_s / 8):
+                t0 = time.perf_counter()
+                R.search_blocked(q32[:b], x[:nrows], k)
+                best = min(best, time.perf_counter() - t0)
+                reps += 1
+            spent += time.perf_counter() - t_begin
+            points.append({"rows": nrows, "batch": b, "seconds": round(best, 5), "queries_per_s": round(b / best, 2),
+                           "gflops": round(2.0 * b * nrows * x.shape[1] / best / 1e9, 1)})
+    full = next(p for p in points if p["rows"] == rows and p["batch"] == q32.shape[0])
+    one = next(p for p in points if p["rows"] == rows and p["batch"] == 1)
+    return {"value": round(q32.shape[0] / (full["seconds"] * (n / rows)), 3), "unit": "queries/s", "cores": cores, "kind": "port",
+            "cpu_model": cpu_model(),
+            "sample": (f"oracle/retrieval.py:search_blocked (fp32 torch.mm on the host BLAS + exact top-k per 16384-row block) on "
+                       f"{q32.shape[0]} queries x the first {rows} rows of the shard, host-resident fp32, best of {5} runs "
+                       f"{full['seconds']:.3f} s; value = {q32.shape[0]} / (t * {n}/{rows}); whole leg {spent:.1f} s of CPU work"),
+            "value_batch1": round(1.0 / (one["seconds"] * (n / rows)), 3),
+            "points": points}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)  # the chip's clock management settles over the first ~8 launches
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)  # the chip's clock management settles over the first ~8 launches
     ap.add_argument("--docs-per-gpu", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--batch", type=int, default=256)
@@ -91,6 +161,8 @@ def main():
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--verify-queries", type=int, default=16, help="queries checked against the CPU oracle over the FULL shard")
     ap.add_argument("--no-cpu", action="store_true", help="skip cpu_baseline and the recall check (profiling runs)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (encoder + search) leg")
+    ap.add_argument("--e2e-steps", type=int, default=30)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -98,32 +170,32 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    ensure_library()  # before the first GPU call of this process
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the measured path")
-    # one process per GPU; VQA_BENCH_SHARE_GPU=1 (dev only) lets several ranks share a device to exercise the N > 1 path
+    # one process per GPU; VQA_BENCH_SHARE_GPU=1 (dev / tests) lets several ranks share a device to exercise the N > 1 path
     # on a 1-GPU box (then over gloo, since RCCL refuses two ranks on one device)
     share = os.environ.get("VQA_BENCH_SHARE_GPU") == "1"
     dev_index = local_rank % torch.cuda.device_count() if share else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    local_rank_dev = dev_index
     if world > 1:
         if share:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
 
-    from vietnamese_qa_system_amd import build
-    if local_rank == 0:
-        build.build()  # no-op when the in-tree .so is newer than the sources
-    if world > 1:
-        dist.barrier()  # the other ranks load the library only after rank 0 has (re)built it
     from vietnamese_qa_system_amd.index import DeviceIndex
     from vietnamese_qa_system_amd.sharded import sharded_index_searcher
 
     n, d, b, k = args.docs_per_gpu, args.dim, args.batch, args.k
-    shard = build_shard(n, d, 1234 + rank, device, args.dtype)
-    index = DeviceIndex(shard, id_base=1 + rank * n, dtype=args.dtype, device=local_rank_dev)
+    shard = build_shard(torch, n, d, 1234 + rank, device, args.dtype)
+    index = DeviceIndex(shard, id_base=1 + rank * n, dtype=args.dtype, device=dev_index)
     gq = torch.Generator(device=device)
     gq.manual_seed(99)
     q = torch.randn((b, d), generator=gq, device=device, dtype=torch.float32)
@@ -139,14 +211,18 @@ def main():
     for _ in range(args.warmup):
         out = searcher.search(q, k)
     index.set_timing(True)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for e0, e1 in ev:
+        e0.record()
         out = searcher.search(q, k)
+        e1.record()
     sync()
     elapsed = time.perf_counter() - t0
     kernel_ms, launches = index.get_timing()
     index.set_timing(False)
+    step_ms = [e0.elapsed_time(e1) for e0, e1 in ev]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -174,11 +250,17 @@ def main():
                                    + (", RCCL all-gather + merge" if world > 1 else ""),
                        "docs_total": world * n, "docs_per_gpu": n, "dim": d, "batch": b, "k": k,
                        "parallelism": f"row-shard x{world}"},
+            # per-step event times on rank 0's stream (the bracketed wall clock above is what value / ms_per_step report)
+            "step_ms": percentiles(np, step_ms),
             "roofline": {"bound": "hbm", "kernel": f"score_topk_kernel<1, {mode}>", "achieved": round(achieved, 1) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "traffic": traffic, "kernel_ms": round(kern_ms, 4), "launches": launches,
                          "bytes_per_launch": info.bytes_per_launch, "flops_per_launch": info.flops_per_launch,
-                         "mfma_tflops": round(info.flops_per_launch / (kern_ms * 1e-3) / 1e12, 1) if launches else None},
+                         "mfma_tflops": round(info.flops_per_launch / (kern_ms * 1e-3) / 1e12, 1) if launches else None,
+                         # what a step holds besides the dominant kernel: query staging, the seed pass (re-scores the first
+                         # seed rows once: outside kernel_ms, inside ms_per_step), two list merges, launch gaps
+                         "step_minus_kernel_ms": round(float(np.median(step_ms)) - kern_ms, 4) if launches else None,
+                         "seed_pass_rows": int(info.seed_tiles) * int(info.rows_per_tile)},
         }
         if args.dtype == "fp32" and launches:
             # an fp32 index at B = 256 is MFMA-bound (128 flop/B against a balance of ~20): price it against the f32 MFMA peak
@@ -187,8 +269,8 @@ def main():
                                        "frac": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
                                        "hbm_gbs": round(achieved, 1)})
 
-    # ---- outside the timed region: recall@10 against the CPU oracle and the CPU baseline (rank 0, N = 1 only for the
-    # baseline; the recall check runs on rank 0's shard through the single-shard path)
+    # ---- outside the timed region: recall@10 against the CPU oracle, the CPU baseline (rank 0, N = 1 only) and the
+    # end-to-end leg (every rank encodes the same queries: replicate-encode)
     if rank == 0 and not args.no_cpu:
         from oracle import retrieval as R
         s_gpu, i_gpu, p_gpu = index.search(q, k, return_positions=True)
@@ -199,11 +281,11 @@ def main():
         # the fp8 oracle encodes every row on the CPU (slow): it checks a 2M-row prefix through a second, prefix-only index
         vrows = n if args.dtype != "fp8" else min(n, 2_000_000)
         if vrows < n:
-            pre = DeviceIndex(shard[:vrows], id_base=1, dtype=args.dtype, device=local_rank_dev)
+            pre = DeviceIndex(shard[:vrows], id_base=1, dtype=args.dtype, device=dev_index)
             s_gpu, i_gpu, p_gpu = pre.search(q, k, return_positions=True)
             torch.cuda.synchronize(device)
             pre.close()
-        ref_s, ref_p = cpu_oracle_topk(shard, q16[:nv], k, args.dtype, rows=vrows)
+        ref_s, ref_p = cpu_oracle_topk(np, shard, q16[:nv], k, args.dtype, rows=vrows)
         verify_s = time.perf_counter() - t1
         recall = R.recall_at_k(p_gpu[:nv].cpu().numpy(), ref_p)
         score_err = float(np.abs(s_gpu[:nv].cpu().numpy() - ref_s).max())
@@ -211,25 +293,84 @@ def main():
         result["recall_check"] = {"queries": nv, "rows": vrows, "max_abs_score_err": score_err, "oracle_seconds": round(verify_s, 1),
                                   "oracle": "same stored values"}
         if args.dtype == "fp8":  # configs[4]: recall of the fp8 index against the un-quantised fp32 rows
-            _, ref32_p = cpu_oracle_topk(shard, q16[:nv], k, "ref32", rows=vrows)
+            _, ref32_p = cpu_oracle_topk(np, shard, q16[:nv], k, "ref32", rows=vrows)
             result["recall_at_10_vs_fp32"] = R.recall_at_k(p_gpu[:nv].cpu().numpy(), ref32_p)
         if world == 1:
-            rows = min(args.cpu_sample_rows if args.dtype != "fp8" else args.cpu_sample_rows // 4, n)
-            torch.set_num_threads(os.cpu_count())
-            t1 = time.perf_counter()
-            cpu_oracle_topk(shard, q16, k, args.dtype, rows=rows)
-            cpu_s = time.perf_counter() - t1
-            cpu_qps = b / (cpu_s * (n / rows))
-            result["cpu_baseline"] = {"value": round(cpu_qps, 3), "unit": "queries/s", "cores": os.cpu_count(), "kind": "port",
-                                      "sample": f"oracle/retrieval.py (numpy fp32 GEMM + exact top-k) on all {b} queries x the first "
-                                                f"{rows} rows of the shard in {cpu_s:.1f} s (includes the device->host copy of the sample); "
-                                                f"value = {b} / (t * {n}/{rows})"}
+            result["cpu_baseline"] = cpu_baseline(np, torch, shard, q16, k, args.dtype, n, args.cpu_sample_rows)
+
+    if not args.no_e2e and d == 768:
+        e2e = end_to_end(torch, np, searcher, device, dev_index, b, k, args.e2e_steps, sync)
+        if rank == 0:
+            result["end_to_end"] = e2e
     if rank == 0:
         print(json.dumps(result), flush=True)
     index.close()
     if world > 1:
         dist.barrier()  # rank 0's recall check (CPU oracle, tens of seconds) ends before any rank tears the group down
         dist.destroy_process_group()
+
+
+def end_to_end(torch, np, searcher, device, dev_index, b, k, steps, sync, L=32):
+    """Question encoder (PhoBERT-base shape, random-init weights, B x L = 256 x 32 synthetic token ids, CLS pooling +
+    L2 normalisation on the device) -> search of the resident shard -> merge: the whole path of `embeddings.search`
+    (heavy_ranker.py:98-101) per batch."""
+    from vietnamese_qa_system_amd.encoder import PHOBERT_BASE, QuestionEncoder
+    cfg = PHOBERT_BASE
+    g = torch.Generator(device=device)
+    g.manual_seed(4321)
+    h, f = cfg["hidden"], cfg["ffn"]
+
+    def w(*shape):
+        return torch.randn(shape, generator=g, device=device, dtype=torch.float32) * 0.02
+
+    weights = {"embeddings.word_embeddings.weight": w(cfg["vocab_size"], h), "embeddings.position_embeddings.weight": w(cfg["max_pos"], h),
+               "embeddings.token_type_embeddings.weight": w(cfg["type_vocab"], h),
+               "embeddings.LayerNorm.weight": torch.ones(h, device=device), "embeddings.LayerNorm.bias": torch.zeros(h, device=device)}
+    for i in range(cfg["layers"]):
+        p = f"encoder.layer.{i}."
+        for name, shape in (("attention.self.query", (h, h)), ("attention.self.key", (h, h)), ("attention.self.value", (h, h)),
+                            ("attention.output.dense", (h, h)), ("intermediate.dense", (f, h)), ("output.dense", (h, f))):
+            weights[p + name + ".weight"] = w(*shape)
+            weights[p + name + ".bias"] = w(shape[0])
+        for ln in ("attention.output.LayerNorm", "output.LayerNorm"):
+            weights[p + ln + ".weight"] = torch.ones(h, device=device)
+            weights[p + ln + ".bias"] = torch.zeros(h, device=device)
+    enc = QuestionEncoder(weights, cfg, device=dev_index, max_tokens=b * L)
+    del weights
+    ids = torch.randint(3, cfg["vocab_size"], (b, L), generator=g, device=device, dtype=torch.int32)
+    lens = torch.randint(8, L + 1, (b,), generator=g, device=device)
+    pos = torch.arange(L, device=device)[None, :]
+    mask = (pos < lens[:, None]).to(torch.int32)
+    ids = torch.where(mask.bool(), ids, torch.full_like(ids, cfg["pad_id"]))
+    ids[:, 0] = 0
+    ids[torch.arange(b, device=device), (lens - 1).to(torch.int64)] = 2
+    for _ in range(5):
+        qv = enc.forward(ids, mask, pooling="cls", normalize=True)
+        searcher.search(qv, k)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+          for _ in range(steps)]
+    sync()
+    t0 = time.perf_counter()
+    for e0, e1, e2 in ev:
+        e0.record()
+        qv = enc.forward(ids, mask, pooling="cls", normalize=True)
+        e1.record()
+        searcher.search(qv, k)
+        e2.record()
+    sync()
+    el = time.perf_counter() - t0
+    enc_ms = [e0.elapsed_time(e1) for e0, e1, _ in ev]
+    tot_ms = [e0.elapsed_time(e2) for e0, _, e2 in ev]
+    enc.close()
+    tokens = b * L
+    flops = tokens * cfg["layers"] * (2 * (h * 3 * h + h * h + 2 * h * f) + 4 * L * h)
+    enc_med = float(np.median(enc_ms))
+    return {"workload": f"PhoBERT-base-shape question encoder (random init, B={b}, L={L}, CLS pooling, L2 norm) + search + merge",
+            "steps": steps, "ms_per_batch": round(el / steps * 1e3, 4), "value": round(b * steps / el, 1), "unit": "queries/s",
+            "batch_ms": percentiles(np, tot_ms), "encoder_ms": percentiles(np, enc_ms),
+            "encoder_roofline": {"bound": "mfma", "achieved": round(flops / (enc_med * 1e-3) / 1e12, 1), "peak": F16_MFMA_PEAK_TFLOPS,
+                                 "unit": "TFLOP/s", "frac": round(flops / (enc_med * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, 4),
+                                 "flops_per_forward": flops, "note": "whole forward (GEMMs + attention + LayerNorm + pooling) over its median event time"}}
 
 
 if __name__ == "__main__":

@@ -12,7 +12,9 @@
  *   - all device work is enqueued asynchronously on the caller's hipStream_t (passed as void*); no hidden
  *     hipDeviceSynchronize / hipMalloc in search/merge/forward calls (they are hipGraph-capturable).
  *   - the caller allocates every output (device memory); the library owns only what it allocated in *_create.
- *   - different handles may be used from different host threads; one handle is not re-entrant.
+ *   - different handles may be used from different host threads at once (one-time per-device kernel setup is guarded);
+ *     ONE handle serves one call at a time: vqa_index_search and vqa_encoder_forward refuse a second concurrent call on
+ *     the same handle with VQA_EINVAL instead of sharing its workspace.
  */
 #ifndef VQA_RETRIEVAL_H
 #define VQA_RETRIEVAL_H
@@ -108,11 +110,12 @@ typedef struct vqa_launch_info {
     int32_t block;         /* threads per workgroup */
     int32_t lds_bytes;     /* dynamic LDS per workgroup */
     int32_t rows_per_tile; /* corpus rows scored per workgroup iteration */
-    int64_t rows_per_launch;  /* corpus rows the MAIN scoring kernel covers (n minus the rows of the seeding pass) */
+    int64_t rows_per_launch;  /* corpus rows the MAIN scoring kernel covers: every row of the shard (the seeding pass scores
+                               * its seed_tiles * rows_per_tile rows once more, in a launch of its own) */
     int64_t bytes_per_launch; /* algorithmic bytes of that launch: rows_per_launch * d * sizeof(element) */
     int64_t flops_per_launch; /* 2 * VQA_QUERY_TILE * rows_per_launch * d */
     int32_t seed_grid;        /* workgroups of the seeding pass (a few tiles each), 0 when the search is single pass */
-    int32_t reserved;
+    int32_t seed_tiles;       /* tiles of rows_per_tile rows the seeding pass scores */
 } vqa_launch_info;
 int vqa_index_launch_info(const vqa_index* index, int32_t B, int32_t k, vqa_launch_info* out);
 int vqa_index_set_timing(vqa_index* index, int32_t enabled);
@@ -148,7 +151,10 @@ typedef struct vqa_encoder_weights {
 int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encoder_config* cfg, const vqa_encoder_weights* w,
                        int32_t max_tokens /* B*L capacity of the activation workspace */);
 void vqa_encoder_destroy(vqa_encoder* enc);
-/* input_ids, attn_mask: [B, L] int32 device.  out: [B, hidden] fp32 device. */
+/* input_ids, attn_mask: [B, L] int32 device.  out: [B, hidden] fp32 device.
+ * Token ids outside [0, vocab_size) never index the embedding table: they are embedded as pad_id and a host-visible flag
+ * is raised, which makes the NEXT vqa_encoder_forward on the handle fail with VQA_EINVAL (the call that saw them cannot
+ * report it without a synchronisation). */
 int vqa_encoder_forward(vqa_encoder* enc, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L,
                         int32_t pooling, int32_t normalize, float* out, void* hip_stream);
 

@@ -171,6 +171,42 @@ def search(q: np.ndarray, x_stored: np.ndarray, k: int, *, dtype: int = DTYPE_F3
     return best_s.astype(np.float32), out_ids, best_p
 
 
+def search_blocked(q: np.ndarray, x32: np.ndarray, k: int, *, block: int = 16384, threads: int | None = None):
+    """The same search as :func:`search` written for SPEED on the host cores (the ``cpu_baseline`` leg of ``bench.py``;
+    stand-in for faiss ``IndexFlatIP.search``, which blocks the corpus the same way): per block of rows one fp32 GEMM
+    ``Q @ Xb^T`` (``torch.mm`` -> the host BLAS, all cores) and ``torch.topk`` on the ``[B, block]`` score block (small
+    enough to stay in the last-level cache), then one merge of the per-block winners.  ``x32`` [N, d] float32, host
+    resident.  Ties exactly at a block's k-th place follow ``torch.topk`` (unspecified); the final order is
+    score desc, position asc.  Returns ``(scores [B, k] float32, positions [B, k] int64)``."""
+    import torch
+    if threads:
+        torch.set_num_threads(int(threads))
+    qt = torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32))
+    xt = torch.from_numpy(x32) if isinstance(x32, np.ndarray) else x32
+    n = int(xt.shape[0])
+    kk = min(k, n)
+    vals, poss = [], []
+    with torch.no_grad():
+        for c0 in range(0, n, block):
+            xb = xt[c0:c0 + block]
+            s = qt @ xb.T
+            v, i = torch.topk(s, min(kk, xb.shape[0]), dim=1)
+            vals.append(v)
+            poss.append(i + c0)
+        v = torch.cat(vals, dim=1).numpy()
+        p = torch.cat(poss, dim=1).numpy()
+    out_s = np.empty((q.shape[0], kk), dtype=np.float32)
+    out_p = np.empty((q.shape[0], kk), dtype=np.int64)
+    if v.shape[1] > 4 * kk:  # shrink with one argpartition before the exact ordering
+        sel = np.argpartition(-v, kk - 1, axis=1)[:, :2 * kk] if v.shape[1] > 2 * kk else None
+        if sel is not None:
+            v, p = np.take_along_axis(v, sel, axis=1), np.take_along_axis(p, sel, axis=1)
+    for i in range(q.shape[0]):
+        o = _order_desc_pos_asc(v[i], p[i])[:kk]
+        out_s[i], out_p[i] = v[i, o], p[i, o]
+    return out_s, out_p
+
+
 def position_to_id(pos: np.ndarray, ids: np.ndarray | None, id_base: int = 0) -> np.ndarray:
     """faiss ``IDMap``: external id of a row position (``ids[pos]``, or ``id_base + pos`` without an id vector;
     a fresh sqlite AUTOINCREMENT table gives ``id_base = 1``, ``setup_db.py:14``)."""

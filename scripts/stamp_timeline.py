@@ -11,25 +11,26 @@ from vietnamese_qa_system_amd import _native as N
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=10_000_000)
 ap.add_argument("--d", type=int, default=768)
+ap.add_argument("--dtype", default="fp16")
 ap.add_argument("--names", default="start,p1,reads,dma,mfma,lgkm,vmcnt,barrier")
 ap.add_argument("--show", type=int, default=4, help="K-steps printed as a merged timeline")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 gen = torch.Generator(device=dev); gen.manual_seed(1234)
-buf = torch.empty((args.n, args.d), dtype=torch.float16, device=dev)
+buf = torch.empty((args.n, args.d), dtype=torch.float16 if args.dtype == "fp16" else torch.float32, device=dev)
 for c0 in range(0, args.n, 1 << 18):
     c1 = min(args.n, c0 + (1 << 18))
     x = torch.randn((c1 - c0, args.d), generator=gen, device=dev)
     x /= x.norm(dim=1, keepdim=True)
-    buf[c0:c1] = x.half()
-ix = DeviceIndex(buf, dtype="fp16")
+    buf[c0:c1] = x.to(buf.dtype)
+ix = DeviceIndex(buf, dtype=args.dtype)
 q = torch.randn((256, args.d), generator=gen, device=dev)
-q = (q / q.norm(dim=1, keepdim=True)).half()
+q = (q / q.norm(dim=1, keepdim=True)).to(buf.dtype)
 for _ in range(12):
     ix.search(q, 10)
 torch.cuda.synchronize()
 lib = N.load()
-KT = (args.d * 2 + 63) // 64
+KT = (args.d * 2 + 63) // 64 if args.dtype == "fp16" else (args.d + 127) // 128  # fp8: K-step pairs per tile
 out = np.zeros((8, 64, 8), dtype=np.uint64)
 lib.vqa_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert lib.vqa_debug_read_stamps(out.ctypes.data, out.size) == 0

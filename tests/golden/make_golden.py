@@ -63,9 +63,45 @@ def retr_ties() -> None:
              exp_scores=exp_sc)
 
 
+def retr_same_stored() -> None:
+    """Same-stored-value fixtures: the inputs ARE the values each index type keeps in HBM (fp16 values, OCP e4m3 codes of
+    16 * x, fp32 values), and the expected top-(K + 1) comes from torch float64 scoring of exactly those values (torch's own
+    float8_e4m3fn cast is the codec) -- neither ``oracle/`` nor the product is involved.  The GPU tests compare ids bit for
+    bit wherever the fp64 gap to the neighbouring ranks exceeds the fp32 accumulation error (2e-6), K + 1 scores are kept
+    for that purpose."""
+    g = torch.Generator().manual_seed(20260)
+    out = {}
+
+    def unit(n, d):
+        v = torch.randn((n, d), generator=g, dtype=torch.float32)
+        return v / v.norm(dim=1, keepdim=True)
+
+    def expect(qv: torch.Tensor, xv: torch.Tensor, scale: float = 1.0):
+        s = (qv.double() @ xv.double().T) * scale
+        order = torch.argsort(-s, dim=1, stable=True)[:, :K + 1]  # score desc, position asc
+        return order.numpy().astype(np.int64), torch.gather(s, 1, order).numpy()
+
+    # fp16 index (BASELINE configs[2] storage type): 2000 x 128 stored halves
+    x16, q16 = unit(2000, 128).half(), unit(64, 128).half()
+    out["f16_x"], out["f16_q"] = x16.numpy(), q16.numpy()
+    out["f16_pos"], out["f16_scores"] = expect(q16, x16)
+    # fp8 index (configs[4]): codes of 16 * x for rows and queries; score = <dec(q), dec(x)> / 256
+    x8 = (unit(2000, 128) * 16).to(torch.float8_e4m3fn)
+    q8 = (unit(64, 128) * 16).to(torch.float8_e4m3fn)
+    out["fp8_x_codes"], out["fp8_q_codes"] = x8.view(torch.uint8).numpy(), q8.view(torch.uint8).numpy()
+    out["fp8_pos"], out["fp8_scores"] = expect(q8.float(), x8.float(), 1.0 / 256)
+    # fp32 index (configs[1]): 1000 x 128 stored floats
+    x32, q32 = unit(1000, 128), unit(64, 128)
+    out["f32_x"], out["f32_q"] = x32.numpy(), q32.numpy()
+    out["f32_pos"], out["f32_scores"] = expect(q32, x32)
+    np.savez(os.path.join(HERE, "retr_same_stored.npz"), **out)
+
+
 if __name__ == "__main__":
-    retr_1k()
-    retr_ties()
+    import sys
+    which = sys.argv[1:] or ["retr_1k", "retr_ties", "retr_same_stored"]
+    for name in which:
+        {"retr_1k": retr_1k, "retr_ties": retr_ties, "retr_same_stored": retr_same_stored}[name]()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -163,3 +163,22 @@ def test_hybrid_search_combines_dense_and_bm25(native_lib, tmp_path):
     assert back.hybrid and back.batchsearch(queries, limit) == got
     # vector queries carry no text: dense scores only
     assert len(hyb.batchsearch(x[:2], 2)[0]) == 2
+
+
+def test_hybrid_search_against_hand_computed_expectation(native_lib):
+    """Expectation worked out by hand in tests/test_sparse.py (HAND_*), independent of sparse.combine / BM25Index: documents
+    embed as unit basis vectors, the query as 0.8 e0 + 0.6 e2, so the dense cosines are exactly 0.8 (doc 0) and 0.6 (doc 2)."""
+    from test_sparse import HAND_DOCS, HAND_HYBRID  # tests/ is on sys.path (pytest rootdir-relative imports)
+    from vietnamese_qa_system_amd import Embeddings
+    basis = np.eye(8, dtype=np.float32)
+    qvec = 0.8 * basis[0] + 0.6 * basis[2]
+
+    def enc(texts):
+        return torch.stack([torch.from_numpy(qvec if t == "đen mèo" else basis[HAND_DOCS.index(t)]) for t in texts])
+
+    emb = Embeddings(hybrid=True, content=True, encoder=enc, dtype="fp32")  # fp32 rows: 0.8 and 0.6 are not fp16 numbers
+    emb.index([{"id": i, "text": t} for i, t in enumerate(HAND_DOCS)])
+    got = emb.search("đen mèo", 3)
+    assert [h["id"] for h in got] == [u for u, _ in HAND_HYBRID]
+    assert np.allclose([h["score"] for h in got], [s for _, s in HAND_HYBRID], atol=2e-5)
+    assert [h["text"] for h in got] == [HAND_DOCS[u] for u, _ in HAND_HYBRID]

@@ -136,3 +136,25 @@ def test_recall_at_k():
     a = np.array([[1, 2, 3], [4, 5, 6]])
     assert R.recall_at_k(a, a) == 1.0
     assert abs(R.recall_at_k(a, np.array([[1, 2, 9], [7, 8, 9]])) - (2 / 3 + 0) / 2) < 1e-12
+
+
+@pytest.mark.parametrize("key,dtype", [("f16", R.DTYPE_F16), ("f32", R.DTYPE_F32), ("fp8", R.DTYPE_FP8_E4M3)])
+def test_oracle_against_same_stored_fp64_golden(golden_dir, key, dtype):
+    """The oracle scores the stored values of every index type like torch float64 does (fixture made without the oracle;
+    for fp8 the codes come from torch's own float8_e4m3fn cast, which also pins the oracle's codec)."""
+    g = np.load(f"{golden_dir}/retr_same_stored.npz")
+    if key == "fp8":
+        e4m3 = torch.arange(256, dtype=torch.uint8).view(torch.float8_e4m3fn).float().numpy()
+        assert np.array_equal(np.nan_to_num(R.e4m3_decode(np.arange(256, dtype=np.uint8)), nan=7e7), np.nan_to_num(e4m3, nan=7e7))
+        x = g["fp8_x_codes"]
+        q = R.e4m3_decode(g["fp8_q_codes"]) / 256.0
+        # the oracle's encoder reproduces the codes from the decoded values
+        assert np.array_equal(R.e4m3_encode(R.e4m3_decode(x)), x)
+    else:
+        x, q = g[f"{key}_x"], g[f"{key}_q"].astype(np.float32)
+    s, _, p = R.search(q, x, 10, dtype=dtype, acc="f64")
+    exp_pos, exp_sc = g[f"{key}_pos"], g[f"{key}_scores"]
+    assert np.abs(s - exp_sc[:, :10]).max() < 1e-6
+    gaps = exp_sc[:, :-1] - exp_sc[:, 1:]
+    clear = (gaps[:, :10] > 1e-9) & np.concatenate([np.ones((gaps.shape[0], 1), bool), gaps[:, :9] > 1e-9], axis=1)
+    assert np.array_equal(p[clear], exp_pos[:, :10][clear]) and clear.mean() > 0.99

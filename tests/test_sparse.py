@@ -83,3 +83,37 @@ def test_save_load_roundtrip(tmp_path):
     for q in ("thủ đô", "capital of France", "thành phố"):
         assert back.search(q, 4) == ix.search(q, 4)
     assert BM25Index.load(str(tmp_path / "missing")) is None
+
+
+# ---- expectations worked out by hand (not through sparse.py): 5 documents, 13 tokens, 6 terms, avgdl = 2.6 -----------------
+HAND_DOCS = ["mèo đen", "mèo trắng mèo", "chó đen", "chó trắng chó chó", "cá vàng"]
+# idf(df = 2) = ln(1 + 3.5 / 2.5) = ln 2.4 = 0.8754687;  idf(df = 1) = ln(1 + 4.5 / 1.5) = ln 4 = 1.3862944
+# query "mèo đen":
+#   doc 0 (len 2): each term tf = 1: 0.8754687 * 2.2 / (1 + 1.2 * (0.25 + 0.75 * 2 / 2.6)) = 0.9667338, two terms: 1.9334676
+#   doc 1 (len 3): mèo tf = 2:      0.8754687 * 2 * 2.2 / (2 + 1.2 * (0.25 + 0.75 * 3 / 2.6)) = 1.1538436
+#   doc 2 (len 2): đen tf = 1:      0.9667338
+HAND_RAW = [(0, 1.9334676), (1, 1.1538436), (2, 0.9667338)]
+# normalisation: avgfreq = 13 tokens / 6 terms = 2.1666667, avgidf = (4 * 0.8754687 + 2 * 1.3862944) / 6 = 1.0457439,
+#   avgscore = 1.0457439 * 2.1666667 * 2.2 / (2.1666667 + 1.2) = 1.4806078, maxscore = min(1.9334676 + 1.4806078, 6 * 1.4806078) = 3.4140754
+HAND_NORM = [(0, 0.5663225), (1, 0.3379666), (2, 0.2831612)]
+# hybrid, weights 0.5 / 0.5, dense cosine 0.8 for doc 0 and 0.6 for doc 2 (nothing else positive):
+#   doc 0: 0.4 + 0.2831612 = 0.6831612;  doc 2: 0.3 + 0.1415806 = 0.4415806;  doc 1: 0.1689833
+HAND_HYBRID = [(0, 0.6831612), (2, 0.4415806), (1, 0.1689833)]
+
+
+def test_bm25_against_hand_computed_scores():
+    raw = BM25Index(normalize=False).index(HAND_DOCS).search("mèo đen", 5)
+    assert [r for r, _ in raw] == [r for r, _ in HAND_RAW]
+    assert np.allclose([s for _, s in raw], [s for _, s in HAND_RAW], atol=2e-6)
+    nrm = BM25Index(normalize=True).index(HAND_DOCS)
+    assert abs(nrm.avgscore - 1.4806078) < 2e-6 and abs(nrm.avgdl - 2.6) < 1e-6
+    got = nrm.search("mèo đen", 5)
+    assert [r for r, _ in got] == [r for r, _ in HAND_NORM]
+    assert np.allclose([s for _, s in got], [s for _, s in HAND_NORM], atol=2e-6)
+
+
+def test_hybrid_merge_against_hand_computed_scores():
+    sparse = BM25Index(normalize=True).index(HAND_DOCS).search("mèo đen", 30)
+    got = combine([(0, 0.8), (2, 0.6)], sparse, 3, 0.5, True)
+    assert [u for u, _ in got] == [u for u, _ in HAND_HYBRID]
+    assert np.allclose([s for _, s in got], [s for _, s in HAND_HYBRID], atol=2e-6)

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 #include "vqa_common.h"
@@ -52,6 +53,16 @@ struct vqa_index {
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
     size_t ev_used = 0;
+    std::atomic_flag busy = ATOMIC_FLAG_INIT;  // one search at a time per handle (the workspace is shared)
+};
+
+struct HandleBusy {  // a second concurrent call on one handle is refused instead of corrupting the shared workspace
+    std::atomic_flag& f;
+    bool ok;
+    explicit HandleBusy(std::atomic_flag& flag) : f(flag), ok(!flag.test_and_set(std::memory_order_acquire)) {}
+    ~HandleBusy() {
+        if (ok) f.clear(std::memory_order_release);
+    }
 };
 
 struct DeviceGuard {
@@ -309,7 +320,7 @@ extern "C" int vqa_index_launch_info(const vqa_index* ix, int32_t B, int32_t k, 
     out->bytes_per_launch = out->rows_per_launch * (int64_t)ix->d * elem_bytes(ix->dtype);
     out->flops_per_launch = 2 * (int64_t)VQA_QUERY_TILE * out->rows_per_launch * (int64_t)ix->d;
     out->seed_grid = p.grid0;
-    out->reserved = 0;
+    out->seed_tiles = p.seed_tiles;
     return VQA_OK;
 }
 
@@ -355,6 +366,8 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
     VQA_REQUIRE(k >= 1 && k <= VQA_MAX_K_TOTAL, "vqa_index_search: k=%d outside [1, %d]", k, VQA_MAX_K_TOTAL);
     VQA_REQUIRE(q_dtype == VQA_F32 || q_dtype == VQA_F16, "vqa_index_search: q_dtype %d is not f32/f16", q_dtype);
     hipStream_t stream = (hipStream_t)hip_stream;
+    HandleBusy busy(ix->busy);
+    VQA_REQUIRE(busy.ok, "vqa_index_search: this index handle is in use by another host thread (one call at a time per handle)");
     DeviceGuard guard(ix->device);
     const int qeb = q_dtype == VQA_F32 ? 4 : 2;
     const LaunchPlan p = plan_launch(ix);

@@ -12,6 +12,7 @@
 //   attention       per (sequence, head): softmax(q k^T / sqrt(dh) + mask) v, K/V in LDS, wavefront-shuffle softmax
 //   add_ln          residual add + LayerNorm                                             (one wave per token)
 //   pool_normalize  CLS row or masked mean -> fp32 -> x / ||x||                          (one wave per sequence)
+#include <atomic>
 #include <new>
 #include <vector>
 
@@ -76,15 +77,20 @@ __device__ __forceinline__ void row_layer_norm(float (&x)[kChunks][8], int H, in
     }
 }
 
-__global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ ids, int T, int L, int H, int pad_id,
-                                                       const float* __restrict__ word, const float* __restrict__ pos,
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ ids, int T, int L, int H, int pad_id, int vocab,
+                                                       int* __restrict__ bad_ids, const float* __restrict__ word,
+                                                       const float* __restrict__ pos,
                                                        const float* __restrict__ type0, const float* __restrict__ g,
                                                        const float* __restrict__ b, float eps, _Float16* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
     const int seq = t / L, l = t - seq * L;
-    const int id = ids[t];
+    // a token id outside the embedding table (tokenizer / vocabulary mismatch) must not become an out-of-bounds read:
+    // it is embedded as the pad token and reported through the host-visible flag (checked by the next forward call)
+    const int id_raw = ids[t];
+    const int id = (unsigned)id_raw < (unsigned)vocab ? id_raw : pad_id;
+    if (id != id_raw && lane == 0) __hip_atomic_store(bad_ids, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // RoBERTa position id: pad + (number of non-pad tokens up to and including this one), pad tokens keep pad
     int cnt = 0;
     for (int j = lane; j <= l; j += 64) cnt += ids[seq * L + j] != pad_id;
@@ -733,6 +739,9 @@ struct vqa_encoder {
     hipStream_t cap_stream = nullptr;  // capture happens on a stream of our own (the caller's may be the null stream, which
                                        // cannot be captured); the instantiated graph is launched on the caller's stream
     bool use_graphs = true;
+    int* bad_ids_host = nullptr;  // pinned, device-mapped: set by embed_ln when a token id lies outside [0, vocab_size)
+    int* bad_ids_dev = nullptr;
+    std::atomic_flag busy = ATOMIC_FLAG_INIT;  // one forward at a time per handle (staging buffers and graphs are shared)
 };
 
 namespace {
@@ -812,20 +821,19 @@ int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, _Float1
         return VQA_OK;
     }
     if (M >= 1024 && N % kBigBN == 0 && K % 64 == 0 && !force_small) {
-        static bool attr_set_dev[64] = {};
+        static VqaPerDeviceOnce once;
+        static int num_cu[64] = {};  // written inside the once, read after it
         int dev = 0;
         VQA_HIP_CHECK(hipGetDevice(&dev));
-        if (!attr_set_dev[dev & 63]) {
+        int rc = once.run([&](int d) -> int {
             VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<EPI>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
-            attr_set_dev[dev & 63] = true;
-        }
-        static int num_cu[64] = {};
-        if (!num_cu[dev & 63]) {
             hipDeviceProp_t prop;
-            VQA_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-            num_cu[dev & 63] = prop.multiProcessorCount;
-        }
+            VQA_HIP_CHECK(hipGetDeviceProperties(&prop, d));
+            num_cu[d & 63] = prop.multiProcessorCount;
+            return VQA_OK;
+        });
+        if (rc != VQA_OK) return rc;
         const int tiles_n = N / kBigBN, tiles = tiles_n * ((M + kBigBM - 1) / kBigBM);
         const int grid = tiles < num_cu[dev & 63] ? tiles : num_cu[dev & 63];
         hipLaunchKernelGGL(gemm_big_kernel<EPI>, dim3(grid), dim3(512), kBigLds, s, A, W, bias, C, M, N, K, tiles_n, tiles);
@@ -850,6 +858,7 @@ extern "C" void vqa_encoder_destroy(vqa_encoder* e) {
     for (auto& gr : e->graphs)
         if (gr.exec) (void)hipGraphExecDestroy(gr.exec);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+    if (e->bad_ids_host) (void)hipHostFree(e->bad_ids_host);
     delete e;
 }
 
@@ -931,6 +940,13 @@ extern "C" int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encod
         if ((rc = dev_alloc(e, (void**)&e->g_ids, (size_t)max_tokens * 4)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->g_mask, (size_t)max_tokens * 4)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->g_out, (size_t)max_tokens * H * 4)) != VQA_OK) break;
+        if (hipHostMalloc((void**)&e->bad_ids_host, sizeof(int), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&e->bad_ids_dev, e->bad_ids_host, 0) != hipSuccess) {
+            vqa_set_error("vqa_encoder_create: allocating the token-id flag failed");
+            rc = VQA_ENOMEM;
+            break;
+        }
+        *e->bad_ids_host = 0;
         {
             const char* gv = getenv("VQA_ENCODER_GRAPH");
             e->use_graphs = !(gv && gv[0] == '0');
@@ -961,8 +977,8 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
     const int T = B * L, H = e->cfg.hidden, F = e->cfg.ffn, heads = e->cfg.heads, dh = H / heads;
     const float eps = e->cfg.ln_eps;
     const int row_blocks = (T + 3) / 4;
-    hipLaunchKernelGGL(embed_ln_kernel, dim3(row_blocks), dim3(256), 0, s, input_ids, T, L, H, e->cfg.pad_id, e->word, e->pos,
-                       e->type0, e->emb_g, e->emb_b, eps, e->x);
+    hipLaunchKernelGGL(embed_ln_kernel, dim3(row_blocks), dim3(256), 0, s, input_ids, T, L, H, e->cfg.pad_id, e->cfg.vocab_size,
+                       e->bad_ids_dev, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x);
     VQA_HIP_CHECK(hipGetLastError());
     const size_t attn_lds = ((size_t)2 * L * (dh + 1) + 4 * L + 4 * dh) * sizeof(float);
     VQA_REQUIRE(attn_lds <= 160 * 1024, "vqa_encoder_forward: L=%d with head size %d needs %zu bytes of LDS", L, dh, attn_lds);
@@ -1012,6 +1028,21 @@ extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, con
                 L + e->cfg.pad_id, e->cfg.max_pos);
     VQA_REQUIRE(pooling == VQA_POOL_CLS || pooling == VQA_POOL_MEAN, "vqa_encoder_forward: pooling %d", pooling);
     hipStream_t s = (hipStream_t)hip_stream;
+    struct Busy {  // the handle's staging buffers, activations and graphs are shared: a second concurrent call is refused
+        std::atomic_flag& f;
+        bool ok;
+        explicit Busy(std::atomic_flag& flag) : f(flag), ok(!flag.test_and_set(std::memory_order_acquire)) {}
+        ~Busy() {
+            if (ok) f.clear(std::memory_order_release);
+        }
+    } busy(e->busy);
+    VQA_REQUIRE(busy.ok, "vqa_encoder_forward: this encoder handle is in use by another host thread (one forward at a time per handle)");
+    if (__atomic_load_n(e->bad_ids_host, __ATOMIC_RELAXED)) {
+        __atomic_store_n(e->bad_ids_host, 0, __ATOMIC_RELAXED);
+        vqa_set_error("vqa_encoder_forward: an earlier forward on this handle saw token ids outside [0, %d); they were embedded as the "
+                      "pad token (tokenizer / vocabulary mismatch?)", e->cfg.vocab_size);
+        return VQA_EINVAL;
+    }
     DevGuard guard(e->device);
     const int T = B * L;
     // Launch-bound sizes replay a captured graph (unless the caller's stream is itself being captured: then the kernels

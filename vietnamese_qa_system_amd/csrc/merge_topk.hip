@@ -214,14 +214,13 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
     const size_t lds = ((size_t)parts * list_len + 4) * sizeof(vqa_key);
     VQA_REQUIRE(lds <= 160 * 1024, "merge_partials: %d lists x %d keys do not fit in LDS", parts, list_len);
     if (lds > 64 * 1024) {
-        static bool attr_set_dev[64] = {};
-        int dev = 0;
-        VQA_HIP_CHECK(hipGetDevice(&dev));
-        if (!attr_set_dev[dev & 63]) {
+        static VqaPerDeviceOnce once;
+        int rc = once.run([&](int) -> int {
             VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(merge_partials_kernel),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr_set_dev[dev & 63] = true;
-        }
+            return VQA_OK;
+        });
+        if (rc != VQA_OK) return rc;
     }
     if (k > 32) {  // sort instead of k selection rounds
         int m_pow2 = 1;
@@ -258,7 +257,16 @@ extern "C" int vqa_merge_topk(const float* scores, const int64_t* ids, int64_t s
     VQA_REQUIRE(score_rank_stride >= (int64_t)B * k && id_rank_stride >= (int64_t)B * k,
                 "vqa_merge_topk: rank strides %lld / %lld are smaller than one [B, k] block", (long long)score_rank_stride,
                 (long long)id_rank_stride);
-    const size_t lds = ((size_t)R * k + 4) * sizeof(vqa_key);
+    const size_t lds = ((size_t)R * k + 4) * sizeof(vqa_key);  // 65 568 B at the R * k = 8192 limit: above the 64 KiB default
+    if (lds > 64 * 1024) {
+        static VqaPerDeviceOnce once;
+        int rc = once.run([&](int) -> int {
+            VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(merge_shards_kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+            return VQA_OK;
+        });
+        if (rc != VQA_OK) return rc;
+    }
     hipLaunchKernelGGL(merge_shards_kernel, dim3(B), dim3(kMergeThreads), lds, (hipStream_t)hip_stream, scores,
                        reinterpret_cast<const long long*>(ids), (long long)score_rank_stride, (long long)id_rank_stride, R, B, k,
                        k_out, out_scores,

@@ -700,6 +700,9 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     }
     };
 
+#ifndef VQA_SLOT_EARLY
+#define VQA_SLOT_EARLY 0
+#endif
 #ifndef VQA_SLOT
 #define VQA_SLOT 1  // fp16: 1 = anti-phase slot loop below, 0 = tile_loop (one barrier per K-step; measured 4 % slower)
 #endif
@@ -719,6 +722,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     auto slot_loop = [&](auto loader_q_tag) __attribute__((always_inline)) {
         constexpr bool kQ0 = decltype(loader_q_tag)::value;  // group 0: Q loader, multiplies in slot 2
         constexpr int SX = 5, SQ = 3;
+        constexpr int kEarly = VQA_SLOT_EARLY;  // row groups (of 8) a group multiplies right after its memory phase, before the barrier
         static_assert((SX + SQ) * kOperandBytes == kPipeBytes, "slot loop rings fill the pipe area");
         const uint32_t ring_lds = kQ0 ? smem_lds + SX * kOperandBytes : smem_lds;
         constexpr int kRing = (kQ0 ? SQ : SX) * kOperandBytes;
@@ -762,14 +766,14 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
 #define VQA_SLOT_PRIO(P) (void)0
 #endif
 // the MFMAs are register-only: these pins keep hipcc from moving them across the slot's barriers
-#define VQA_SLOT_MMA()                                                                                             \
+#define VQA_SLOT_MMA(M0, M1)                                                                                       \
     do {                                                                                                           \
         asm volatile("" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fa[2]), "+v"(fa[3]), "+v"(fa[4]), "+v"(fa[5]), "+v"(fa[6]), \
                      "+v"(fa[7]));                                                                                 \
         VQA_SB();                                                                                                  \
         VQA_SLOT_PRIO(1);                                                                                          \
-        mma_block<DT, 0, 8>(acc, fa, fb);                                                                          \
-        _Pragma("unroll") for (int mi_ = 0; mi_ < 8; ++mi_)                                                        \
+        mma_block<DT, (M0), (M1)>(acc, fa, fb);                                                                    \
+        _Pragma("unroll") for (int mi_ = (M0); mi_ < (M1); ++mi_)                                                  \
             asm volatile("" ::"v"(acc[mi_][0]), "v"(acc[mi_][1]), "v"(acc[mi_][2]), "v"(acc[mi_][3]));             \
         VQA_SLOT_PRIO(0);                                                                                          \
         VQA_SB();                                                                                                  \
@@ -801,48 +805,57 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
             unsigned long long stamp_t[kStampSlots] = {};
 #endif
             int ext_stage = 0;
-            for (int kt = 0; kt < KT; ++kt) {
-                VQA_STAMP(0);
-                // ---- slot 1
-                if constexpr (kQ0) {
-                    VQA_SLOT_READ();
-                    VQA_STAMP(1);
-                    issue();
-                    VQA_STAMP(2);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    wait_vmcnt<4>();
-                } else {
-                    VQA_SLOT_MMA();
-                    VQA_STAMP(1);
-                    if (owe) wait_vmcnt<8>();
-                    else wait_vmcnt<12>();
-                    VQA_STAMP(2);
-                }
-                VQA_STAMP(3);
-                block_barrier();
-                VQA_STAMP(4);
-                // ---- slot 2
-                if constexpr (kQ0) {
-                    VQA_SLOT_MMA();
-                    VQA_STAMP(5);
-                    VQA_STAMP(6);
-                } else {
-                    if (kt == KT - 1) ext_stage = rx == 0 ? SX - 1 : rx - 1;  // stage of this tile's last K-step
-                    VQA_SLOT_READ();
-                    VQA_STAMP(5);
-                    if (owe) {
-                        issue();
-                        owe = false;
-                    }
-                    if (MODE == 1 && kt == KT - 1) owe = true;
-                    else issue();
-                    VQA_STAMP(6);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                }
-                block_barrier();
-                VQA_STAMP(7);
-                VQA_STAMP_FLUSH(kt);
-            }
+// One K-step; FIRST / LAST = the tile's first / last K-step (compile-time: a run-time choice between MFMA ranges makes hipcc
+// spill the accumulators).  Group 1 multiplies the first kEarly row groups of a K-step in the slot before it -- except
+// across a tile boundary, where the accumulators still belong to the finished tile.
+#define VQA_SLOT_KSTEP(FIRST, LAST, KT_IDX)                                                                          \
+    do {                                                                                                             \
+        VQA_STAMP(0);                                                                                                \
+        if constexpr (kQ0) {                                                                                         \
+            VQA_SLOT_READ();                                                                                         \
+            VQA_STAMP(1);                                                                                            \
+            issue();                                                                                                 \
+            VQA_STAMP(2);                                                                                            \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+            VQA_SLOT_MMA(0, kEarly); /* starts before the other group's block has drained (registers only) */        \
+            wait_vmcnt<4>();                                                                                         \
+        } else {                                                                                                     \
+            if constexpr (FIRST) VQA_SLOT_MMA(0, 8);                                                                 \
+            else VQA_SLOT_MMA(kEarly, 8);                                                                            \
+            VQA_STAMP(1);                                                                                            \
+            if (FIRST && owe) wait_vmcnt<8>();                                                                       \
+            else wait_vmcnt<12>();                                                                                   \
+            VQA_STAMP(2);                                                                                            \
+        }                                                                                                            \
+        VQA_STAMP(3);                                                                                                \
+        block_barrier();                                                                                             \
+        VQA_STAMP(4);                                                                                                \
+        if constexpr (kQ0) {                                                                                         \
+            VQA_SLOT_MMA(kEarly, 8);                                                                                 \
+            VQA_STAMP(5);                                                                                            \
+            VQA_STAMP(6);                                                                                            \
+        } else {                                                                                                     \
+            if constexpr (LAST) ext_stage = rx == 0 ? SX - 1 : rx - 1; /* stage of this tile's last K-step */        \
+            VQA_SLOT_READ();                                                                                         \
+            VQA_STAMP(5);                                                                                            \
+            if (FIRST && owe) {                                                                                      \
+                issue();                                                                                             \
+                owe = false;                                                                                         \
+            }                                                                                                        \
+            if (MODE == 1 && LAST) owe = true;                                                                       \
+            else issue();                                                                                            \
+            VQA_STAMP(6);                                                                                            \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
+            if constexpr (!LAST) VQA_SLOT_MMA(0, kEarly);                                                            \
+        }                                                                                                            \
+        block_barrier();                                                                                             \
+        VQA_STAMP(7);                                                                                                \
+        VQA_STAMP_FLUSH(KT_IDX);                                                                                     \
+    } while (0)
+            VQA_SLOT_KSTEP(true, false, 0);
+            for (int kt = 1; kt < KT - 1; ++kt) VQA_SLOT_KSTEP(false, false, kt);
+            VQA_SLOT_KSTEP(false, true, KT - 1);
+#undef VQA_SLOT_KSTEP
             if constexpr (kQ0) ext_stage = rx == 0 ? SX - 1 : rx - 1;  // group 0 read this tile's last K-step last
             finish_tile(acc, ti, ext_stage);
         }
@@ -933,6 +946,11 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         for (int ti = 0; ti < ntile; ++ti) {
             for (int jj = 0; jj < P; ++jj, ++j) {
                 // ---- R slot: fragments of pair j
+#ifdef VQA_STAMPS
+                const bool stamp_on = blockIdx.x == kStampWg && ti == kStampTile;
+                unsigned long long stamp_t[kStampSlots] = {};
+#endif
+                VQA_STAMP(0);
                 if (MODE == 1 && jj == 0 && ti > 0) compact_pass(L, wave, lane, k, k + (kCap - k + 1) / 2, kCap);
                 bool xi = false;
 #if !(VQA_ABLATE & 33)
@@ -945,16 +963,21 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
 #if !(VQA_ABLATE & 1)
                 if (j >= 1) xi = issue_x2();  // into pair j - 1's stages: both groups have read them
 #endif
+                VQA_STAMP(1);
 #if VQA_ABLATE & 2
                 sx = sx + 2 >= kSx ? sx + 2 - kSx : sx + 2;
 #else
                 VQA_READ_HALVES(a2, b2, 0);
                 VQA_READ_HALVES(a2, b2, 1);
 #endif
+                VQA_STAMP(2);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                VQA_STAMP(3);
                 if (xi) wait_vmcnt<4>();
                 else wait_vmcnt<0>();
+                VQA_STAMP(4);
                 block_barrier();
+                VQA_STAMP(5);
                 if (MODE == 1 && kEarly && jj == 0 && ti > 0) repair(false, fq_other);  // group B's E slot just ended
                 // ---- M slot: nothing but the 32 MFMAs
                 if (jj == 0) {
@@ -974,7 +997,10 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi)
                     asm volatile("" ::"v"(acc[mi][0]), "v"(acc[mi][1]), "v"(acc[mi][2]), "v"(acc[mi][3]));
+                VQA_STAMP(6);
                 block_barrier();
+                VQA_STAMP(7);
+                VQA_STAMP_FLUSH(jj);
                 if (MODE == 1 && !kEarly && jj == P - 1) repair(false, fq_other);  // group A's E slot just ended
             }
             // ---- E slot
@@ -1038,17 +1064,15 @@ int vqa_score_topk_seeds_per_tile() { return kSeedsPerTile; }
 
 template <int DT>
 static int launch_dt(const ScoreTopkArgs& a, int KT, int lds, hipStream_t stream) {
-    static bool attr_set_dev[64] = {};
-    int dev = 0;
-    VQA_HIP_CHECK(hipGetDevice(&dev));
-    bool& attr_set = attr_set_dev[dev & 63];
-    if (!attr_set) {
+    static VqaPerDeviceOnce once;
+    int rc = once.run([&](int) -> int {
         VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<0, DT>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<1, DT>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
+        return VQA_OK;
+    });
+    if (rc != VQA_OK) return rc;
     auto kern = a.seed_only ? score_topk_kernel<0, DT> : score_topk_kernel<1, DT>;
     hipLaunchKernelGGL(kern, dim3(a.grid), dim3(kThreads), lds, stream, a.x, a.q, a.thr_init, a.upper, a.partial, (long long)a.n,
                        KT, a.nq, a.k, a.tile_begin, a.tile_end, a.gate);
@@ -1064,6 +1088,8 @@ int vqa_launch_score_topk(int dtype, const ScoreTopkArgs& a, hipStream_t stream)
     VQA_REQUIRE(a.k >= 1 && a.k <= kMaxK, "score_topk: k=%d outside [1, %d]", a.k, kMaxK);
     VQA_REQUIRE(a.nq >= 1 && a.nq <= kQ, "score_topk: nq=%d outside [1, %d]", a.nq, kQ);
     VQA_REQUIRE(a.grid >= 1 && a.tile_end > a.tile_begin, "score_topk: empty launch");
+    VQA_REQUIRE(a.grid <= a.tile_end - a.tile_begin, "score_topk: %d workgroups for %d tiles (every workgroup needs a tile)", a.grid,
+                a.tile_end - a.tile_begin);
     const int lds = vqa_score_topk_lds_bytes(dtype, a.k);
     const int KT = a.d_pad * esize / kRowBytes;  // even
     if (dtype == VQA_F16) return launch_dt<VQA_F16>(a, KT, lds, stream);

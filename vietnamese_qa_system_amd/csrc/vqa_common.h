@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 
 #include "vqa_retrieval.h"
@@ -24,6 +25,25 @@ void vqa_set_error(const char* fmt, ...);
             return VQA_EINVAL;       \
         }                            \
     } while (0)
+
+// ---- one-time setup per device (hipFuncSetAttribute, device queries), callable from several host threads at once:
+// different handles may be used from different threads (include/vqa_retrieval.h), and every launch path comes through here.
+struct VqaPerDeviceOnce {
+    std::once_flag flag[64];
+    int rc[64] = {};
+    template <typename F>
+    int run(F&& fn) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) {
+            vqa_set_error("hipGetDevice failed");
+            return VQA_EHIP;
+        }
+        const int slot = dev & 63;
+        std::call_once(flag[slot], [&] { rc[slot] = fn(dev); });
+        if (rc[slot] != VQA_OK) vqa_set_error("one-time kernel setup failed on device %d", dev);
+        return rc[slot];
+    }
+};
 
 // ---- candidate keys -----------------------------------------------------------------------------------------
 // A candidate (score, row position) is one u64 whose unsigned order is the result order

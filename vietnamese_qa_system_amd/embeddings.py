@@ -19,8 +19,11 @@ half of txtai's hybrid score is out of scope); a warning
 """
 from __future__ import annotations
 
+import ctypes
 import json
 import os
+import shutil
+import time
 import warnings
 from typing import Callable, Iterable, List, Optional, Sequence, Union
 
@@ -28,6 +31,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+from . import _native as N
 from . import docstore
 from .index import DeviceIndex, resolve_dtype
 from .sharded import ShardedSearcher, shard_bounds
@@ -81,7 +85,10 @@ class Embeddings:
         self._searcher: Optional[ShardedSearcher] = None
         self._host_ids: Optional[list] = None  # non-integer external ids, by row position
         self._docs_db: Optional[str] = None
-        self._docs_mem: Optional[dict] = None
+        self._docs_mem: Optional[dict] = None   # device-level id -> document (lookup at search time)
+        self._docs_rows: Optional[list] = None  # [(global row position, document)] of the rows this rank was given
+        self._lo = 0                            # first global row of this rank's shard
+        self.load_stats: Optional[dict] = None  # filled by load(): bytes, seconds, GB/s of the file -> HBM stream
         self.n = 0
         self.d = 0
 
@@ -125,16 +132,54 @@ class Embeddings:
         if self.hybrid:  # every rank indexes the whole corpus' text (host side, small next to the vectors)
             self._sparse = BM25Index().index(str(d.get("text", "")) for d in docs)
 
-    def index_vectors(self, ids: Optional[Sequence], vectors, documents: Optional[List[dict]] = None) -> None:
-        """Index precomputed embeddings [n, d] (float32, or float16 values already normalised).  With
-        ``torch.distributed`` initialised every rank passes the SAME full arrays and keeps its contiguous row shard."""
-        v = torch.from_numpy(np.ascontiguousarray(vectors)) if isinstance(vectors, np.ndarray) else vectors
-        if v.dim() != 2:
-            raise ValueError("vectors must be [n, d]")
-        n, d = int(v.shape[0]), int(v.shape[1])
-        if ids is not None and len(ids) != n:
-            raise ValueError(f"{len(ids)} ids for {n} vectors")
-        lo, hi = shard_bounds(n, self.world, self.rank)
+    def index_vectors(self, ids: Optional[Sequence], vectors, documents: Optional[List[dict]] = None, *, local: bool = False,
+                      total: Optional[int] = None, chunk_rows: int = 1 << 18) -> None:
+        """Index precomputed embeddings (float32, or float16 values already normalised).
+
+        * default: ``vectors`` [n, d] is the WHOLE corpus; with ``torch.distributed`` initialised every rank passes the same
+          arrays and keeps its contiguous row shard (``shard_bounds``).
+        * ``local=True``: ``vectors`` (and ``ids``, ``documents``) are only THIS rank's rows [lo, hi) of a corpus of ``total``
+          rows -- no rank ever holds the whole corpus (80M x 768 fp16 = 123 GB).  ``total`` defaults to the sum over ranks.
+        * ``vectors`` may also be a callable ``rows(lo, hi) -> [hi - lo, d] array`` (needs ``total``); it is asked for this
+          rank's rows in chunks of ``chunk_rows`` and the shard is filled chunk by chunk without a second copy.
+        """
+        self._host_ids = None  # ids of an earlier index() on this object must not leak into the new one
+        producer = vectors if callable(vectors) else None
+        if producer is not None:
+            if total is None:
+                raise ValueError("a row producer needs total= (rows of the whole corpus)")
+            n = int(total)
+            lo, hi = shard_bounds(n, self.world, self.rank)
+            first = producer(lo, min(hi, lo + 1)) if hi > lo else producer(0, 1)
+            first = torch.from_numpy(np.ascontiguousarray(first)) if isinstance(first, np.ndarray) else first
+            d, v = int(first.shape[1]), None
+            vdtype = first.dtype
+        else:
+            v = torch.from_numpy(np.ascontiguousarray(vectors)) if isinstance(vectors, np.ndarray) else vectors
+            if v.dim() != 2:
+                raise ValueError("vectors must be [n, d]")
+            d, vdtype = int(v.shape[1]), v.dtype
+            if local:
+                mine = int(v.shape[0])
+                if total is None:
+                    if self.world > 1:
+                        t = torch.tensor([mine], dtype=torch.int64)
+                        if dist.get_backend(self.group) == "nccl":
+                            t = t.cuda(self.device)
+                        dist.all_reduce(t, group=self.group)
+                        total = int(t.item())
+                    else:
+                        total = mine
+                n = int(total)
+                lo, hi = shard_bounds(n, self.world, self.rank)
+                if hi - lo != mine:
+                    raise ValueError(f"rank {self.rank} holds rows [{lo}, {hi}) of {n} but was given {mine} vectors")
+            else:
+                n = int(v.shape[0])
+                lo, hi = shard_bounds(n, self.world, self.rank)
+        part = local or producer is not None  # ids / documents cover only this rank's rows
+        if ids is not None and len(ids) != (hi - lo if part else n):
+            raise ValueError(f"{len(ids)} ids for {(hi - lo) if part else n} vectors")
         int_ids = ids is None or all(isinstance(i, (int, np.integer)) for i in ids)
         dev_ids = None
         id_base = 0
@@ -142,15 +187,19 @@ class Embeddings:
             id_base = lo
         elif int_ids:
             arr = np.asarray(ids, dtype=np.int64)
-            if n and np.array_equal(arr, np.arange(arr[0], arr[0] + n)):
+            if not part and n and np.array_equal(arr, np.arange(arr[0], arr[0] + n)):
                 id_base = int(arr[0]) + lo  # contiguous ids (sqlite rowids): no id vector needed
             else:
-                dev_ids = arr[lo:hi]
+                dev_ids = arr if part else arr[lo:hi]
         else:
+            if part:
+                raise ValueError("non-integer ids need the whole id list on every rank: pass the full arrays (local=False)")
             self._host_ids = list(ids)
             id_base = lo  # the device returns global row positions, mapped through _host_ids on the host
         # what the dense path reports for global row position p (the sparse half speaks row positions)
-        if not int_ids:
+        if part:
+            self._row_ids = None  # hybrid search needs the whole corpus' ids on every rank
+        elif not int_ids:
             self._row_ids = np.arange(n, dtype=np.int64)
         elif dev_ids is None:
             self._row_ids = np.arange(n, dtype=np.int64) + (id_base - lo)
@@ -159,13 +208,26 @@ class Embeddings:
         self._sparse = None
         if self._index is not None:
             self._index.close()
-        normalize = self.normalize and v.dtype == torch.float32
-        self._index = DeviceIndex(v[lo:hi], ids=dev_ids, id_base=id_base, dtype=self.dtype, device=self.device,
-                                  normalize=normalize)
+        normalize = self.normalize and vdtype == torch.float32
+        if producer is None:
+            rows = v if part else v[lo:hi]
+            self._index = DeviceIndex(rows, ids=dev_ids, id_base=id_base, dtype=self.dtype, device=self.device, normalize=normalize)
+        else:
+            self._index = DeviceIndex.empty(hi - lo, d, id_base=id_base, dtype=self.dtype, device=self.device,
+                                            with_ids=dev_ids is not None)
+            for c0 in range(lo, hi, chunk_rows):
+                c1 = min(hi, c0 + chunk_rows)
+                rows = first if (c0 == lo and c1 == lo + 1) else producer(c0, c1)
+                self._index.set_rows(c0 - lo, rows, dev_ids[c0 - lo:c1 - lo] if dev_ids is not None else None, normalize=normalize)
         self._searcher = ShardedSearcher(self._local_search, None, self.group)
-        self.n, self.d = n, d
+        self.n, self.d, self._lo = n, d, lo
         self._docs_db = None
-        self._docs_mem = {d_["id"]: d_ for d_ in documents} if documents is not None else None
+        self._docs_rows = self._docs_mem = None
+        if documents is not None:
+            base = lo if part else 0
+            self._docs_rows = [(base + i, d_) for i, d_ in enumerate(documents)]
+            # lookup key = what the device reports for the row: the row position (string ids) or the integer id
+            self._docs_mem = {(pos if self._host_ids is not None else int(d_["id"])): d_ for pos, d_ in self._docs_rows}
 
     def _local_search(self, q: torch.Tensor, k: int, out_s: torch.Tensor, out_i: torch.Tensor) -> None:
         self._index.search(q, k, out=(out_s, out_i))
@@ -187,9 +249,15 @@ class Embeddings:
             v = v[None, :]
         if v.dtype not in (torch.float32, torch.float16):
             v = v.float()
-        v = v.to(torch.device("cuda", self.device))
-        if self.normalize and v.dtype == torch.float32:
-            v = v / v.norm(dim=1, keepdim=True).clamp_min(torch.finfo(torch.float32).tiny)
+        dev = torch.device("cuda", self.device)
+        v = v.to(dev).contiguous()
+        if self.normalize and v.dtype == torch.float32 and v.shape[0]:
+            # x / ||x|| by the library's HIP kernel (zero rows stay zero): no torch arithmetic on the query path
+            out = torch.empty_like(v)
+            with torch.cuda.device(dev):
+                N.check(N.load().vqa_normalize_convert(v.data_ptr(), int(v.shape[0]), int(v.shape[1]), 1, N.VQA_F32, out.data_ptr(),
+                                                       torch.cuda.current_stream(dev).cuda_stream), "vqa_normalize_convert")
+            v = out
         return v
 
     def batchsearch(self, queries, limit: int = 3) -> List[list]:
@@ -244,7 +312,7 @@ class Embeddings:
             if self._docs_db is not None:
                 texts = docstore.fetch_docs(self._docs_db, wanted)
             elif self._docs_mem is not None:
-                texts = {i: self._docs_mem[self._ext_id(i)].get("text") for i in set(wanted) if self._ext_id(i) in self._docs_mem}
+                texts = {i: self._docs_mem[i].get("text") for i in set(wanted) if i in self._docs_mem}
         # plain Python lists first: per-element numpy indexing costs more than the GPU search of a 256-query batch
         il, sl, kl = ids.tolist(), scores.tolist(), keep.tolist()
         ext = (lambda i: self._host_ids[i]) if self._host_ids is not None else (lambda i: i)
@@ -259,43 +327,78 @@ class Embeddings:
     # ---- persistence -----------------------------------------------------------------------
     def save(self, path: str) -> None:
         """``heavy_ranker.py:87``: ``<path>/meta.json`` + ``vectors.f16`` / ``vectors.f32`` (row-major, mmap-able, shardable by byte range)
-        + ``ids.i64`` (+ ``documents.db`` with the reference's table schema when ``content=True``)."""
+        + ``ids.i64`` (+ ``documents.db`` with the reference's table schema when ``content=True``).  With
+        ``torch.distributed`` initialised every rank writes the byte range of its own row shard into the same files
+        (rank 0 creates them at full size first); rank 0 writes the metadata and the documents."""
         if self._index is None:
             raise RuntimeError("nothing to save: the index is empty")
-        if self.world != 1:
-            raise NotImplementedError("save() from a sharded Embeddings: gather on one rank first")
         os.makedirs(path, exist_ok=True)
-        rows, ids = self._index.get_rows()
-        if rows.dtype == np.uint8:
-            # fp8 index: codes of 16 * x -> x as fp16 (3 mantissa bits, exponents down to 2^-13: exact), so that
-            # load() re-encodes to the very same codes
-            from .index import FP8_SCALE
-            rows = (_e4m3_decode_table()[rows] / FP8_SCALE).astype(np.float16)
-        vec_dtype = "float32" if rows.dtype == np.float32 else "float16"
-        rows.tofile(os.path.join(path, VECTOR_FILES[vec_dtype]))
-        if ids is not None:
-            ids.tofile(os.path.join(path, IDS_FILE))
-        meta = {"format": FORMAT_VERSION, "n": self.n, "d": self.d, "dtype": self.dtype, "normalize": self.normalize,
-                "pooling": self.pooling, "path": self.path, "content": self.content, "hybrid": self.hybrid,
-                "id_base": self._index.id_base, "has_ids": ids is not None, "host_ids": self._host_ids,
-                "vector_dtype": vec_dtype}
-        meta["weights"] = self.weights
-        with open(os.path.join(path, META_FILE), "w") as f:
-            json.dump(meta, f)
-        if self._sparse is not None:
-            self._sparse.save(path)
-        if self.content and self._docs_mem is not None:
-            db = os.path.join(path, DOCS_FILE)
-            if os.path.exists(db):
-                os.remove(db)
-            docs = []
-            for pos, (ext, doc) in enumerate(self._docs_mem.items()):
-                key = pos if self._host_ids is not None else int(ext)
-                docs.append({"id": key, "text": doc.get("text"), "source": doc.get("source")})
-            docstore.write_documents(db, docs)
+        has_ids = self._index.has_ids
+        vec_dtype = "float32" if self._index.dtype == N.VQA_F32 else "float16"
+        itemsize = np.dtype(vec_dtype).itemsize
+        vec_path, ids_path = os.path.join(path, VECTOR_FILES[vec_dtype]), os.path.join(path, IDS_FILE)
+        lo, hi = shard_bounds(self.n, self.world, self.rank)
+        if self.rank == 0:  # files at their final size, so that every rank can write its own range
+            with open(vec_path, "wb") as f:
+                f.truncate(self.n * self.d * itemsize)
+            if has_ids:
+                with open(ids_path, "wb") as f:
+                    f.truncate(self.n * 8)
+        if self.world > 1:
+            dist.barrier(group=self.group)
+        step = 1 << 18
+        with open(vec_path, "r+b") as fv:
+            fi = open(ids_path, "r+b") if has_ids else None
+            try:
+                for c0 in range(0, hi - lo, step):
+                    c = min(step, hi - lo - c0)
+                    rows, ids = self._index.get_rows(c0, c)
+                    if rows.dtype == np.uint8:
+                        # fp8 index: codes of 16 * x -> x as fp16 (3 mantissa bits, exponents down to 2^-13: exact), so that
+                        # load() re-encodes to the very same codes
+                        from .index import FP8_SCALE
+                        rows = (_e4m3_decode_table()[rows] / FP8_SCALE).astype(np.float16)
+                    fv.seek((lo + c0) * self.d * itemsize)
+                    fv.write(rows.tobytes())
+                    if fi is not None:
+                        fi.seek((lo + c0) * 8)
+                        fi.write(ids.tobytes())
+            finally:
+                if fi is not None:
+                    fi.close()
+        docs_rows = self._docs_rows
+        if self.content and docs_rows is not None and self.world > 1 and len(docs_rows) != self.n:
+            # every rank holds the documents of its own rows only (index_vectors(local=True)): rank 0 collects them
+            gathered = [None] * self.world if self.rank == 0 else None
+            dist.gather_object(docs_rows, gathered, dst=0, group=self.group)
+            if self.rank == 0:
+                docs_rows = [pd for part in gathered for pd in part]
+        if self.rank == 0:
+            meta = {"format": FORMAT_VERSION, "n": self.n, "d": self.d, "dtype": self.dtype, "normalize": self.normalize,
+                    "pooling": self.pooling, "path": self.path, "content": self.content, "hybrid": self.hybrid,
+                    "id_base": self._index.id_base - self._lo, "has_ids": has_ids, "host_ids": self._host_ids,
+                    "vector_dtype": vec_dtype, "weights": self.weights}
+            with open(os.path.join(path, META_FILE), "w") as f:
+                json.dump(meta, f)
+            if self._sparse is not None:
+                self._sparse.save(path)
+            if self.content:
+                db = os.path.join(path, DOCS_FILE)
+                if docs_rows is not None:
+                    if os.path.exists(db):
+                        os.remove(db)
+                    # one row per corpus row, keyed by what the device reports for it (row position for string ids)
+                    docstore.write_documents(db, [{"id": pos if self._host_ids is not None else int(doc["id"]),
+                                                   "text": doc.get("text"), "source": doc.get("source")} for pos, doc in docs_rows])
+                elif self._docs_db is not None and os.path.abspath(self._docs_db) != os.path.abspath(db):
+                    shutil.copyfile(self._docs_db, db)  # a loaded index keeps its documents on re-save
+        if self.world > 1:
+            dist.barrier(group=self.group)
 
     def load(self, path: str) -> "Embeddings":
-        """``heavy_ranker.py:92,94``: ``Embeddings().load(dir)``; returns ``self``."""
+        """``heavy_ranker.py:92,94``: ``Embeddings().load(dir)``; returns ``self``.  Every rank reads only the byte range of
+        its row shard; the rows stream file -> pinned host buffers -> HBM with the next chunk's file read overlapping the
+        previous chunk's copy (``load_stats`` reports the rate)."""
         meta_path = os.path.join(path, META_FILE)
         if not os.path.isfile(meta_path):
             raise FileNotFoundError(f"{meta_path} not found: {path!r} is not a saved index")
@@ -314,30 +417,73 @@ class Embeddings:
         expected = n * d * np_dtype.itemsize
         if os.path.getsize(vec_path) != expected:
             raise ValueError(f"{vec_path}: {os.path.getsize(vec_path)} bytes, expected {expected}")
-        rows = np.memmap(vec_path, dtype=np_dtype, mode="r", shape=(n, d)) if n else np.zeros((0, d), np_dtype)
         ids = None
         if meta["has_ids"]:
-            ids = np.fromfile(os.path.join(path, IDS_FILE), dtype=np.int64)[lo:hi]
+            ids = np.fromfile(os.path.join(path, IDS_FILE), dtype=np.int64, count=hi - lo, offset=lo * 8)
         if self._index is not None:
             self._index.close()
         self._index = DeviceIndex.empty(hi - lo, d, id_base=int(meta["id_base"]) + lo, dtype=self.dtype, device=self.device,
                                         with_ids=ids is not None)
-        step = 1 << 18  # rows stream file -> pinned-size chunks -> HBM; the whole shard is never resident on the host
-        for c0 in range(lo, hi, step):
-            c1 = min(hi, c0 + step)
-            self._index.set_rows(c0 - lo, np.ascontiguousarray(rows[c0:c1]),
-                                 ids[c0 - lo:c1 - lo] if ids is not None else None)
+        self.load_stats = self._stream_rows(vec_path, np_dtype, lo, hi, d, ids)
         self._searcher = ShardedSearcher(self._local_search, None, self.group)
-        self.n, self.d = n, d
+        self.n, self.d, self._lo = n, d, lo
         db = os.path.join(path, DOCS_FILE)
         self._docs_db = db if os.path.isfile(db) else None
-        self._docs_mem = None
+        self._docs_mem = self._docs_rows = None
         self.weights = float(meta.get("weights", 0.5))
         self._sparse = BM25Index.load(path) if self.hybrid else None
         if self._host_ids is not None:
             self._row_ids = np.arange(n, dtype=np.int64)
         elif meta["has_ids"]:
-            self._row_ids = np.fromfile(os.path.join(path, IDS_FILE), dtype=np.int64)
+            self._row_ids = np.fromfile(os.path.join(path, IDS_FILE), dtype=np.int64) if self.hybrid else None
         else:
             self._row_ids = np.arange(n, dtype=np.int64) + int(meta["id_base"])
         return self
+
+    def _stream_rows(self, vec_path: str, np_dtype, lo: int, hi: int, d: int, ids, chunk_rows: int = 1 << 18) -> dict:
+        """File rows [lo, hi) -> the shard, double buffered: while chunk i travels pinned host -> device (async copy on a side
+        stream) and is transposed into the tiled layout, chunk i + 1 is read from the file into the other pinned buffer."""
+        dev = torch.device("cuda", self.device)
+        tdt = torch.float32 if np_dtype == np.float32 else torch.float16
+        rows_total = hi - lo
+        t0 = time.perf_counter()
+        if rows_total == 0:
+            return {"bytes": 0, "seconds": 0.0, "gb_per_s": 0.0}
+        chunk_rows = min(chunk_rows, rows_total)
+        with torch.cuda.device(dev):
+            pinned = [torch.empty((chunk_rows, d), dtype=tdt, pin_memory=True) for _ in range(2)]
+            staged = [torch.empty((chunk_rows, d), dtype=tdt, device=dev) for _ in range(2)]
+            copy_stream = torch.cuda.Stream(device=dev)
+            done = [None, None]  # event: the copy out of pinned[b] has finished
+            pending = None       # (buffer, first row, count) copied but not yet written into the index
+            row_bytes = d * np_dtype.itemsize
+            with open(vec_path, "rb", buffering=0) as f:
+                f.seek(lo * row_bytes)
+                for i, c0 in enumerate(range(0, rows_total, chunk_rows)):
+                    b = i & 1
+                    c = min(chunk_rows, rows_total - c0)
+                    if done[b] is not None:
+                        done[b].synchronize()
+                    view = memoryview(pinned[b].numpy()).cast("B")[:c * row_bytes]
+                    got = 0
+                    while got < len(view):
+                        r = f.readinto(view[got:])
+                        if not r:
+                            raise ValueError(f"{vec_path}: unexpected end of file")
+                        got += r
+                    if pending is not None:  # the previous chunk: copy done? then transpose it into the shard
+                        pb, p0, pc = pending
+                        done[pb].synchronize()
+                        self._index.set_rows(p0, staged[pb][:pc], ids[p0:p0 + pc] if ids is not None else None)
+                    with torch.cuda.stream(copy_stream):
+                        staged[b][:c].copy_(pinned[b][:c], non_blocking=True)
+                        done[b] = torch.cuda.Event()
+                        done[b].record(copy_stream)
+                    pending = (b, c0, c)
+            pb, p0, pc = pending
+            done[pb].synchronize()
+            self._index.set_rows(p0, staged[pb][:pc], ids[p0:p0 + pc] if ids is not None else None)
+            torch.cuda.synchronize(dev)
+        sec = time.perf_counter() - t0
+        nbytes = rows_total * d * np_dtype.itemsize
+        return {"bytes": nbytes, "seconds": sec, "gb_per_s": nbytes / sec / 1e9}

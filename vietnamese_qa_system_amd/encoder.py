@@ -113,6 +113,13 @@ class QuestionEncoder:
         mask = torch.as_tensor(np.asarray(attention_mask) if not isinstance(attention_mask, torch.Tensor) else attention_mask)
         if ids.dim() != 2 or mask.shape != ids.shape:
             raise ValueError("input_ids and attention_mask must both be [B, L]")
+        if not ids.is_cuda and ids.numel():
+            # host-side ids (what a tokenizer returns) are range-checked here, before anything is launched; device-resident
+            # ids are clamped by the kernel and reported by the next forward call (include/vqa_retrieval.h)
+            lo, hi = int(ids.min()), int(ids.max())
+            if lo < 0 or hi >= int(self.config["vocab_size"]):
+                raise ValueError(f"token ids span [{lo}, {hi}] but the embedding table has {self.config['vocab_size']} rows "
+                                 "(tokenizer / vocabulary mismatch?)")
         ids = ids.to(dev, dtype=torch.int32).contiguous()
         mask = mask.to(dev, dtype=torch.int32).contiguous()
         b, l = int(ids.shape[0]), int(ids.shape[1])
@@ -142,5 +149,19 @@ class TextEncoder:
         outs = []
         for c0 in range(0, len(texts), self.batch_size):
             ids, mask = self.tokenizer(list(texts[c0:c0 + self.batch_size]))
-            outs.append(self.encoder.forward(ids, mask, pooling=self.pooling, normalize=self.normalize))
+            ids = np.asarray(ids) if not isinstance(ids, torch.Tensor) else ids
+            mask = np.asarray(mask) if not isinstance(mask, torch.Tensor) else mask
+            if ids.ndim != 2:
+                raise ValueError("the tokenizer must return [B, L] input_ids")
+            b, l = int(ids.shape[0]), int(ids.shape[1])
+            # a tokenised batch of B x L tokens goes through the encoder in slices of at most max_tokens tokens
+            rows = max(1, self.encoder.max_tokens // max(l, 1))
+            if l > self.encoder.max_tokens:
+                raise ValueError(f"sequence length {l} exceeds the encoder workspace of {self.encoder.max_tokens} tokens")
+            for r0 in range(0, b, rows):
+                outs.append(self.encoder.forward(ids[r0:r0 + rows], mask[r0:r0 + rows], pooling=self.pooling,
+                                                 normalize=self.normalize))
+        if not outs:
+            return torch.zeros((0, int(self.encoder.config["hidden"])), dtype=torch.float32,
+                               device=torch.device("cuda", self.encoder.device))
         return torch.cat(outs) if len(outs) != 1 else outs[0]

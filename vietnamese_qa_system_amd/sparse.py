@@ -9,8 +9,9 @@ follows restates txtai's BM25 scoring FROM MEMORY and is therefore *parity unpin
 * idf(t) = ln(1 + (N - df + 0.5) / (df + 0.5));  score(tf) = idf * tf * (k1 + 1) / (tf + k1 * (1 - b + b * dl / avgdl)),
   k1 = 1.2, b = 0.75;
 * ``normalize=True`` (what ``hybrid=True`` configures): scores are divided by
-  ``min(best + avgscore, 6 * avgscore)`` and clipped to 1, where ``avgscore`` is the score of an average term in an average
-  document -- so that they can be mixed with cosine scores by a convex combination (weights 0.5 / 0.5).
+  ``min(best + avgscore, 6 * avgscore)`` and clipped to 1, where ``avgscore`` is the score of an average term (frequency
+  = total tokens / vocabulary size, idf = mean idf) in an average document -- so that they can be mixed with cosine scores by
+  a convex combination (weights 0.5 / 0.5).
 
 Host-side numpy: the sparse half is a few postings lists per query and is not on the MI355X hot path (the dense scan is).
 """
@@ -78,8 +79,9 @@ class BM25Index:
         self.indptr = np.concatenate([[0], np.cumsum(df)]).astype(np.int64)
         self.idf = np.log(1.0 + (n - df + 0.5) / (df + 0.5)).astype(np.float32)
         self.avgdl = float(self.doclen.mean()) if n else 0.0
-        # the score of an average term (mean tf over postings, mean idf over terms) in an average document
-        avgfreq = float(self.tf.mean()) if self.tf.size else 0.0
+        # the score of an average term in an average document; txtai: avgfreq = total tokens / vocabulary size (the mean
+        # CORPUS frequency of a term), avgidf = mean idf over the vocabulary [recalled]
+        avgfreq = float(self.doclen.sum()) / v if v else 0.0
         avgidf = float(self.idf.mean()) if v else 0.0
         self.avgscore = self._score(avgfreq, avgidf, self.avgdl) if n else 0.0
         return self
