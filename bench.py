@@ -103,6 +103,20 @@ def cpu_model() -> str:
     return "unknown"
 
 
+def usable_cpus() -> int:
+    """Host threads this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU box reports 256
+    logical CPUs but grants a quota of 16: 256 BLAS threads on it run 50x slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def percentiles(np, xs):
     a = np.asarray(xs, dtype=np.float64)
     return {"median": round(float(np.median(a)), 4), "p10": round(float(np.percentile(a, 10)), 4),
@@ -115,7 +129,7 @@ def cpu_baseline(np, torch, shard, q_host, k, dtype, n, sample_rows, budget_s=25
     workload, host-resident fp32 rows (the device->host copy is outside the timing).  B = 256 and B = 1 (the
     reference's own calling pattern, heavy_ranker.py:97-98) at 1k / 100k / sample rows."""
     from oracle import retrieval as R
-    cores = os.cpu_count()
+    cores = usable_cpus()
     torch.set_num_threads(cores)
     rows = min(sample_rows, n)
     x = shard[:rows].cpu()
@@ -140,9 +154,9 @@ def cpu_baseline(np, torch, shard, q_host, k, dtype, n, sample_rows, budget_s=25
     full = next(p for p in points if p["rows"] == rows and p["batch"] == q32.shape[0])
     one = next(p for p in points if p["rows"] == rows and p["batch"] == 1)
     return {"value": round(q32.shape[0] / (full["seconds"] * (n / rows)), 3), "unit": "queries/s", "cores": cores, "kind": "port",
-            "cpu_model": cpu_model(),
+            "cpu_model": cpu_model(), "logical_cpus": os.cpu_count(),
             "sample": (f"oracle/retrieval.py:search_blocked (fp32 torch.mm on the host BLAS + exact top-k per 16384-row block) on "
-                       f"{q32.shape[0]} queries x the first {rows} rows of the shard, host-resident fp32, best of {5} runs "
+                       f"{q32.shape[0]} queries x the first {rows} rows of the shard, host-resident fp32, {cores} threads (cgroup quota), best of 5 runs "
                        f"{full['seconds']:.3f} s; value = {q32.shape[0]} / (t * {n}/{rows}); whole leg {spent:.1f} s of CPU work"),
             "value_batch1": round(1.0 / (one["seconds"] * (n / rows)), 3),
             "points": points}

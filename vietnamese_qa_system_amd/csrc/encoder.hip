@@ -10,10 +10,11 @@
 //   gemm_nt<EPI>    C[M,N] = A[M,K] . W[N,K]^T + bias (+ erf GELU); v_mfma_f32_16x16x32_f16, 128x128x32 tiles,
 //                   register-staged double-buffered LDS image, XOR-swizzled for conflict-free ds_read_b128
 //   attention       per (sequence, head): softmax(q k^T / sqrt(dh) + mask) v, K/V in LDS, wavefront-shuffle softmax
-//   add_ln          residual add + LayerNorm                                             (one wave per token)
+//   ln              LayerNorm (the residual add is fused into the producing GEMM's epilogue) (one wave per token)
 //   pool_normalize  CLS row or masked mean -> fp32 -> x / ||x||                          (one wave per sequence)
 #include <atomic>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 #include "vqa_common.h"
@@ -115,9 +116,10 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ i
     row_layer_norm(x, H, lane, g, b, eps, out + (size_t)t * H);
 }
 
-__global__ __launch_bounds__(256) void add_ln_kernel(const _Float16* __restrict__ a, const _Float16* __restrict__ res, int T,
-                                                     int H, const float* __restrict__ g, const float* __restrict__ b,
-                                                     float eps, _Float16* __restrict__ out) {
+// LayerNorm alone: the residual add is fused into the epilogue of the GEMM that produced `a` (EPI 2).  (Two or four rows per
+// wave, all loaded before the first reduction, measured 1-2 % slower on the whole forward than one row per wave.)
+__global__ __launch_bounds__(256) void ln_kernel(const _Float16* __restrict__ a, int T, int H, const float* __restrict__ g,
+                                                 const float* __restrict__ b, float eps, _Float16* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
@@ -125,13 +127,10 @@ __global__ __launch_bounds__(256) void add_ln_kernel(const _Float16* __restrict_
 #pragma unroll
     for (int i = 0; i < kChunks; ++i) {
         const int j0 = (lane + 64 * i) * 8;
-        half8 va = half8{0, 0, 0, 0, 0, 0, 0, 0}, vr = va;
-        if (j0 < H) {
-            va = *reinterpret_cast<const half8*>(a + (size_t)t * H + j0);
-            vr = *reinterpret_cast<const half8*>(res + (size_t)t * H + j0);
-        }
+        half8 va = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (j0 < H) va = *reinterpret_cast<const half8*>(a + (size_t)t * H + j0);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[i][e] = (float)va[e] + (float)vr[e];
+        for (int e = 0; e < 8; ++e) x[i][e] = (float)va[e];
     }
     row_layer_norm(x, H, lane, g, b, eps, out + (size_t)t * H);
 }
@@ -165,8 +164,8 @@ __device__ __forceinline__ int swz_off(int row, int slot) {
 
 template <int EPI, int BK>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
-                                                      const float* __restrict__ bias, _Float16* __restrict__ C, int M, int N,
-                                                      int K) {
+                                                      const float* __restrict__ bias, const _Float16* __restrict__ R,
+                                                      _Float16* __restrict__ C, int M, int N, int K) {
     constexpr int kTileBytes = kGemmBM * BK * 2;   // per operand per stage
     constexpr int kSlots = BK / 8;                 // 16-byte slots per row
     constexpr int kLoads = 128 * kSlots / 256;     // staging loads per thread per operand (2 or 4)
@@ -253,6 +252,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const _Float16* __restrict
                 if (m >= M) continue;
                 float v = acc[mi][ni][j] + bv;
                 if (EPI == 1) v = gelu_erf(v);
+                if (EPI == 2) v += (float)R[(size_t)m * N + n];
                 C[(size_t)m * N + n] = (_Float16)v;
             }
     }
@@ -311,8 +311,9 @@ __device__ __forceinline__ void big_dma(const char* base, size_t piece_stride, u
 
 template <int EPI>
 __global__ __launch_bounds__(512) void gemm_big_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
-                                                       const float* __restrict__ bias, _Float16* __restrict__ C, int M, int N,
-                                                       int K, int tiles_n, int tiles_total) {
+                                                       const float* __restrict__ bias, const _Float16* __restrict__ R,
+                                                       _Float16* __restrict__ C, int M, int N, int K, int tiles_n,
+                                                       int tiles_total) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     typedef __attribute__((address_space(3))) char* lds_ptr;
     const uint32_t lds_base = (uint32_t)(size_t)(lds_ptr)lds;
@@ -410,17 +411,219 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const _Float16* __restric
             for (int mi = 0; mi < 4; ++mi) {
                 const int m = bm + wr * 64 + mi * 16 + c;
                 if (m >= M) continue;
+                half4 res = half4{0, 0, 0, 0};
+                if (EPI == 2) res = *reinterpret_cast<const half4*>(R + (size_t)m * N + n0);
                 half4 o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v = acc[ni][mi][j] + bv[j];
                     if (EPI == 1) v = gelu_erf(v);
+                    if (EPI == 2) v += (float)res[j];
                     o[j] = (_Float16)v;
                 }
                 *reinterpret_cast<half4*>(C + (size_t)m * N + n0) = o;
             }
         }
     }
+}
+
+// ---- the same GEMM with the K loop in ANTI-PHASE SLOTS (the structure of the scoring kernel's slot loop, score_topk.hip):
+// two barriers per K tile; in every slot one wave group only multiplies (32 MFMAs) while the other only moves data (reads
+// the fragments of its next K tile, issues its 6 LDS-DMA pieces), so the two waves of a SIMD -- one of each group -- never
+// share the matrix pipe and never leave it idle behind each other's memory phases.  One fragment set per wave.
+//     K tile kappa, slot 1:  group 0: read fragments(kappa), issue pieces of kappa + 2, vmcnt(6)   | group 1: MFMAs of kappa, vmcnt(0)
+//                  slot 2:  group 0: MFMAs of kappa                                             | group 1: read fragments(kappa + 1), issue kappa + 2
+// Stage kappa + 2 reuses the stage of kappa - 1 (3 stages): last read in slot 1 (kappa - 1) / slot 2 (kappa - 2).  Pieces are
+// always issued (past the end of the stream: the last K tile again, into a stage nobody reads any more): constant vmcnt.
+// EPI 0: + bias; 1: + bias, erf GELU; 2: + bias + residual row (the residual add of the post-LN block, fused here).
+#ifndef VQA_GEMM_ABLATE
+#define VQA_GEMM_ABLATE 0  // dev-only timing ablations (wrong results): 1 no epilogue stores, 2 no GELU, 4 no MFMAs in the K loop
+#endif
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_slot_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+                                                        const float* __restrict__ bias, const _Float16* __restrict__ R,
+                                                        _Float16* __restrict__ C, int M, int N, int K, int tiles_n,
+                                                        int tiles_total) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    typedef __attribute__((address_space(3))) char* lds_ptr;
+    const uint32_t lds_base = (uint32_t)(size_t)(lds_ptr)lds;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;  // token rows [64 wr, +64) x output features [64 wc, +64) of the tile
+    const int grp = wave >> 2;                // group 0: token rows 0-127, group 1: rows 128-255 (partners w, w + 4 share a SIMD)
+    const int c = lane & 15, g = lane >> 4;
+    const int G = gridDim.x, wg = blockIdx.x;
+    const bool swz = (tiles_total % 8 == 0) && (G % 8 == 0);
+    const int per = swz ? G >> 3 : G, first = swz ? wg >> 3 : wg, span = swz ? tiles_total >> 3 : tiles_total;
+    const int tile0 = swz ? (wg & 7) * span : 0;
+    const int my_tiles = first < span ? (span - first + per - 1) / per : 0;
+    const int KT = K / 64, total = my_tiles * KT;
+    if (total == 0) return;
+
+    const size_t row_bytes = (size_t)K * 2;
+    const uint32_t voff = (uint32_t)((lane >> 3) * row_bytes + (((lane & 7) ^ (lane >> 3)) << 4));
+    const uint32_t a_dst = lds_base + 32 * wave * kBigRowBytes, w_dst = lds_base + kBigAStage + 16 * wave * kBigRowBytes;
+    int is_tile = 0, is_kt = 0, is_stage = 0, is_n = 0;  // issue cursor: tile, K tile inside it, ring stage, K tiles issued
+    const char* a_src = nullptr;
+    const char* w_src = nullptr;
+    auto issue_next = [&]() __attribute__((always_inline)) {
+        if (is_kt == 0 && is_n < total) {
+            const int t = tile0 + first + is_tile * per;
+            a_src = reinterpret_cast<const char*>(A) + (size_t)((t / tiles_n) * kBigBM + 32 * wave) * row_bytes;  // 4 pieces
+            w_src = reinterpret_cast<const char*>(W) + (size_t)((t % tiles_n) * kBigBN + 16 * wave) * row_bytes;  // 2 pieces
+        }
+        big_dma<4>(a_src + (size_t)is_kt * kBigRowBytes, 8 * row_bytes, voff, a_dst + is_stage * kBigStage);
+        big_dma<2>(w_src + (size_t)is_kt * kBigRowBytes, 8 * row_bytes, voff, w_dst + is_stage * kBigStage);
+        ++is_n;
+        if (is_n < total) {  // past the end the cursor stays on the last K tile
+            if (++is_kt == KT) {
+                is_kt = 0;
+                ++is_tile;
+            }
+        }
+        if (++is_stage == kBigStages) is_stage = 0;
+    };
+    const int f0 = c * kBigRowBytes + ((g ^ (c & 7)) << 4), f1 = c * kBigRowBytes + (((4 + g) ^ (c & 7)) << 4);
+    const int a_row0 = wr * 64 * kBigRowBytes, w_row0 = kBigAStage + wc * 64 * kBigRowBytes;
+    int rstage = 0;  // stage of the K tile this group reads next
+    half8 w0[4], x0[4], w1[4], x1[4];
+#define VQA_G_READ()                                                                                  \
+    do {                                                                                              \
+        const char* st = lds + rstage * kBigStage;                                                    \
+        if (++rstage == kBigStages) rstage = 0;                                                       \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+            w0[j] = *reinterpret_cast<const half8*>(st + w_row0 + j * 16 * kBigRowBytes + f0);        \
+            x0[j] = *reinterpret_cast<const half8*>(st + a_row0 + j * 16 * kBigRowBytes + f0);        \
+        }                                                                                             \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
+            w1[j] = *reinterpret_cast<const half8*>(st + w_row0 + j * 16 * kBigRowBytes + f1);        \
+            x1[j] = *reinterpret_cast<const half8*>(st + a_row0 + j * 16 * kBigRowBytes + f1);        \
+        }                                                                                             \
+    } while (0)
+// the MFMAs are register-only: the pins keep hipcc from moving them across the slot's barriers
+#define VQA_G_MMA()                                                                                               \
+    do {                                                                                                          \
+        asm volatile("" : "+v"(w0[0]), "+v"(w0[1]), "+v"(w0[2]), "+v"(w0[3]), "+v"(x0[0]), "+v"(x0[1]), "+v"(x0[2]), \
+                     "+v"(x0[3]));                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        if (!(VQA_GEMM_ABLATE & 4)) {                                                                             \
+        _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                          \
+            _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                      \
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[ni], x0[mi], acc[ni][mi], 0, 0, 0);       \
+        _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                          \
+            _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                      \
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[ni], x1[mi], acc[ni][mi], 0, 0, 0);       \
+        }                                                                                                         \
+        _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                          \
+            asm volatile("" ::"v"(acc[ni][0]), "v"(acc[ni][1]), "v"(acc[ni][2]), "v"(acc[ni][3]));                \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+    } while (0)
+#define VQA_G_BARRIER()                         \
+    do {                                        \
+        __builtin_amdgcn_sched_barrier(0);      \
+        __builtin_amdgcn_s_barrier();           \
+        __builtin_amdgcn_sched_barrier(0);      \
+    } while (0)
+    // prologue: K tiles 0 and 1 issued, 0 landed; group 1 holds fragments(0)
+    issue_next();
+    issue_next();
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    VQA_G_BARRIER();
+    // the tile loop exists once per group, the wave-uniform branch sits outside it (no diamond around the MFMA blocks)
+    auto run = [&](auto first_group_tag) __attribute__((always_inline)) {
+    constexpr bool kG0 = decltype(first_group_tag)::value;
+    if constexpr (!kG0) {
+        VQA_G_READ();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    VQA_G_BARRIER();
+    for (int i = 0; i < my_tiles; ++i) {
+        f32x4 acc[4][4];  // [feature tile ni][token tile mi]
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < KT; ++kt) {
+            // ---- slot 1
+            if constexpr (kG0) {
+                VQA_G_READ();
+                issue_next();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else {
+                VQA_G_MMA();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            VQA_G_BARRIER();
+            // ---- slot 2
+            if constexpr (kG0) {
+                VQA_G_MMA();
+            } else {
+                VQA_G_READ();
+                issue_next();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            VQA_G_BARRIER();
+        }
+        // epilogue: acc[ni][mi][j] = C[token bm + 64 wr + 16 mi + c][feature bn + 64 wc + 16 ni + 4 g + j].  A lane's 4
+        // features of one tile are 8 bytes of fp16: v_permlane16_swap between the registers of feature tiles ni and ni + 1
+        // (lanes g = 1 <-> g = 0, g = 3 <-> g = 2 of the same token) leaves every lane with 8 CONSECUTIVE features --
+        // tile ni + (g & 1), features 8 (g >> 1) .. + 7 -- so the tile goes out as 8 sixteen-byte stores per wave instead of 16
+        // eight-byte ones (a wave instruction then covers 16 token rows x 64 contiguous bytes); bias, GELU and the residual
+        // row are applied in that layout.
+        const int t = tile0 + first + i * per;
+        const int bm = (t / tiles_n) * kBigBM, bn = (t % tiles_n) * kBigBN;
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int n0 = bn + wc * 64 + (2 * pr + (g & 1)) * 16 + (g >> 1) * 8;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + n0), b1 = *reinterpret_cast<const f32x4*>(bias + n0 + 4);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                // (cast the whole vector first: __builtin_bit_cast of a single vector ELEMENT reads element 0 for every index)
+                u32x4 ulo = __builtin_bit_cast(u32x4, acc[2 * pr][mi]), uhi = __builtin_bit_cast(u32x4, acc[2 * pr + 1][mi]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const auto r = __builtin_amdgcn_permlane16_swap(ulo[j], uhi[j], false, false);
+                    ulo[j] = r[0];
+                    uhi[j] = r[1];
+                }
+                const f32x4 lo = __builtin_bit_cast(f32x4, ulo), hi = __builtin_bit_cast(f32x4, uhi);
+                const int m = bm + wr * 64 + mi * 16 + c;
+                if (m >= M) continue;  // after the swaps: every lane takes part in them
+                half8 res = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                if (EPI == 2) res = *reinterpret_cast<const half8*>(R + (size_t)m * N + n0);
+                half8 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v0 = lo[j] + b0[j], v1 = hi[j] + b1[j];
+#if !(VQA_GEMM_ABLATE & 2)
+                    if (EPI == 1) {
+                        v0 = gelu_erf(v0);
+                        v1 = gelu_erf(v1);
+                    }
+#endif
+                    if (EPI == 2) {
+                        v0 += (float)res[j];
+                        v1 += (float)res[4 + j];
+                    }
+                    o[j] = (_Float16)v0;
+                    o[4 + j] = (_Float16)v1;
+                }
+#if VQA_GEMM_ABLATE & 1
+                asm volatile("" ::"v"(o));
+#else
+                *reinterpret_cast<half8*>(C + (size_t)m * N + n0) = o;
+#endif
+            }
+        }
+    }
+    };
+    if (grp) run(std::false_type{});
+    else run(std::true_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pieces issued past the end of the stream land before the LDS is released
+#undef VQA_G_READ
+#undef VQA_G_MMA
+#undef VQA_G_BARRIER
 }
 
 // ---- GEMM for a handful of tokens (M <= 64: single queries, the reference's own calling pattern heavy_ranker.py:97-98):
@@ -430,8 +633,8 @@ __global__ __launch_bounds__(512) void gemm_big_kernel(const _Float16* __restric
 // the four partial tiles are summed through LDS and wave 0 applies bias / GELU and stores 8 bytes per lane.
 template <int EPI, int MT>  // MT token tiles of 16
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
-                                                          const float* __restrict__ bias, _Float16* __restrict__ C, int M,
-                                                          int N, int K) {
+                                                          const float* __restrict__ bias, const _Float16* __restrict__ R,
+                                                          _Float16* __restrict__ C, int M, int N, int K) {
     __shared__ f32x4 red[3][MT][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
@@ -497,11 +700,14 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const _Float16* __rest
         const int m = m0 + mi * 16 + c;
         if (m >= M) continue;
         const f32x4 sum = acc[mi] + red[0][mi][lane] + red[1][mi][lane] + red[2][mi][lane];
+        half4 res = half4{0, 0, 0, 0};
+        if (EPI == 2) res = *reinterpret_cast<const half4*>(R + (size_t)m * N + n0 + 4 * g);
         half4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float v = sum[j] + bv[j];
             if (EPI == 1) v = gelu_erf(v);
+            if (EPI == 2) v += (float)res[j];
             o[j] = (_Float16)v;
         }
         *reinterpret_cast<half4*>(C + (size_t)m * N + n0 + 4 * g) = o;
@@ -803,15 +1009,17 @@ int upload_f16(vqa_encoder* e, const float* src, size_t n, _Float16* dst) {
 }
 
 template <int EPI>
-int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, _Float16* C, int M, int N, int K, hipStream_t s) {
+int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, const _Float16* R, _Float16* C, int M, int N, int K,
+                hipStream_t s) {
     static const bool force_small = getenv("VQA_GEMM_SMALL") != nullptr;  // dev override, read once
+    static const bool force_v1 = getenv("VQA_GEMM_V1") != nullptr;        // dev override: the one-barrier 256 x 128 kernel
     static const int skinny_max = getenv("VQA_SKINNY_MAX") ? atoi(getenv("VQA_SKINNY_MAX")) : 512;  // dev override; measured crossover with the 128 x 128 kernel ~ 700 tokens
     if (M <= skinny_max && N % 16 == 0 && K % 256 == 0 && !force_small) {
         const int mt = M >= 64 ? 4 : (M + 15) / 16;
         const int chunks = (M + 16 * mt - 1) / (16 * mt);
 #define VQA_SKINNY(MT)                                                                                                          \
     case MT:                                                                                                                    \
-        hipLaunchKernelGGL((gemm_skinny_kernel<EPI, MT>), dim3(N / 16, chunks), dim3(256), 0, s, A, W, bias, C, M, N, K);        \
+        hipLaunchKernelGGL((gemm_skinny_kernel<EPI, MT>), dim3(N / 16, chunks), dim3(256), 0, s, A, W, bias, R, C, M, N, K);     \
         break;
         switch (mt) {
             VQA_SKINNY(1) VQA_SKINNY(2) VQA_SKINNY(3) VQA_SKINNY(4)
@@ -828,6 +1036,8 @@ int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, _Float1
         int rc = once.run([&](int d) -> int {
             VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<EPI>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
+            VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_slot_kernel<EPI>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
             hipDeviceProp_t prop;
             VQA_HIP_CHECK(hipGetDeviceProperties(&prop, d));
             num_cu[d & 63] = prop.multiProcessorCount;
@@ -836,15 +1046,18 @@ int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, _Float1
         if (rc != VQA_OK) return rc;
         const int tiles_n = N / kBigBN, tiles = tiles_n * ((M + kBigBM - 1) / kBigBM);
         const int grid = tiles < num_cu[dev & 63] ? tiles : num_cu[dev & 63];
-        hipLaunchKernelGGL(gemm_big_kernel<EPI>, dim3(grid), dim3(512), kBigLds, s, A, W, bias, C, M, N, K, tiles_n, tiles);
+        if (force_v1)
+            hipLaunchKernelGGL(gemm_big_kernel<EPI>, dim3(grid), dim3(512), kBigLds, s, A, W, bias, R, C, M, N, K, tiles_n, tiles);
+        else
+            hipLaunchKernelGGL(gemm_slot_kernel<EPI>, dim3(grid), dim3(512), kBigLds, s, A, W, bias, R, C, M, N, K, tiles_n, tiles);
         VQA_HIP_CHECK(hipGetLastError());
         return VQA_OK;
     }
     dim3 grid((N + kGemmBN - 1) / kGemmBN, (M + kGemmBM - 1) / kGemmBM);
     if (K % 64 == 0)
-        hipLaunchKernelGGL((gemm_nt_kernel<EPI, 64>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K);
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI, 64>), grid, dim3(256), 0, s, A, W, bias, R, C, M, N, K);
     else
-        hipLaunchKernelGGL((gemm_nt_kernel<EPI, 32>), grid, dim3(256), 0, s, A, W, bias, C, M, N, K);
+        hipLaunchKernelGGL((gemm_nt_kernel<EPI, 32>), grid, dim3(256), 0, s, A, W, bias, R, C, M, N, K);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }
@@ -971,6 +1184,10 @@ extern "C" int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encod
     return VQA_OK;
 }
 
+static void launch_ln(const _Float16* a, int T, int H, const float* g, const float* b, float eps, _Float16* out, hipStream_t s) {
+    hipLaunchKernelGGL(ln_kernel, dim3((T + 3) / 4), dim3(256), 0, s, a, T, H, g, b, eps, out);
+}
+
 // the launch sequence of one forward pass (no validation, no allocation, no synchronisation: capturable)
 static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L,
                           int32_t pooling, int32_t normalize, float* out, hipStream_t s) {
@@ -986,7 +1203,7 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
         VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds));
     for (const vqa_encoder::Layer& Ly : e->layers) {
-        int rc = launch_gemm<0>(e->x, Ly.wqkv, Ly.bqkv, e->qkv, T, 3 * H, H, s);
+        int rc = launch_gemm<0>(e->x, Ly.wqkv, Ly.bqkv, nullptr, e->qkv, T, 3 * H, H, s);
         if (rc != VQA_OK) return rc;
         if (dh == kAttDh && L <= 32 * kAttMaxBlocks) {
             const int nqb = (L + 31) / 32;
@@ -1004,12 +1221,13 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
             hipLaunchKernelGGL(attention_kernel, dim3(B * heads), dim3(256), attn_lds, s, e->qkv, attn_mask, L, H, heads, e->ctx);
         }
         VQA_HIP_CHECK(hipGetLastError());
-        if ((rc = launch_gemm<0>(e->ctx, Ly.wo, Ly.bo, e->tmp, T, H, H, s)) != VQA_OK) return rc;
-        hipLaunchKernelGGL(add_ln_kernel, dim3(row_blocks), dim3(256), 0, s, e->tmp, e->x, T, H, Ly.ln1_g, Ly.ln1_b, eps, e->x);
+        // out-projection / FFN2 add the residual row in their epilogue (EPI 2); the LayerNorm then reads one array
+        if ((rc = launch_gemm<2>(e->ctx, Ly.wo, Ly.bo, e->x, e->tmp, T, H, H, s)) != VQA_OK) return rc;
+        launch_ln(e->tmp, T, H, Ly.ln1_g, Ly.ln1_b, eps, e->x, s);
         VQA_HIP_CHECK(hipGetLastError());
-        if ((rc = launch_gemm<1>(e->x, Ly.w1, Ly.b1, e->ffn, T, F, H, s)) != VQA_OK) return rc;
-        if ((rc = launch_gemm<0>(e->ffn, Ly.w2, Ly.b2, e->tmp, T, H, F, s)) != VQA_OK) return rc;
-        hipLaunchKernelGGL(add_ln_kernel, dim3(row_blocks), dim3(256), 0, s, e->tmp, e->x, T, H, Ly.ln2_g, Ly.ln2_b, eps, e->x);
+        if ((rc = launch_gemm<1>(e->x, Ly.w1, Ly.b1, nullptr, e->ffn, T, F, H, s)) != VQA_OK) return rc;
+        if ((rc = launch_gemm<2>(e->ffn, Ly.w2, Ly.b2, e->x, e->tmp, T, H, F, s)) != VQA_OK) return rc;
+        launch_ln(e->tmp, T, H, Ly.ln2_g, Ly.ln2_b, eps, e->x, s);
         VQA_HIP_CHECK(hipGetLastError());
     }
     hipLaunchKernelGGL(pool_normalize_kernel, dim3((B + 3) / 4), dim3(256), 0, s, e->x, attn_mask, B, L, H, pooling, normalize, out);
