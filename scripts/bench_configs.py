@@ -101,7 +101,11 @@ def config1(n=1_000_000, b=256, l=32):
     tokens = int(mask.sum())
     flops = b * l * 12 * (2 * (768 * 2304 + 768 * 768 + 2 * 768 * 3072) + 4 * l * 768)
     return {"config": f"PhoBERT-base-shaped encoder (random weights, B={b}, L={l}, {tokens} real tokens) + {n} x 768 fp32 index, top-10",
-            "encoder_ms": round(enc_ms, 3), "encoder_tflops": round(flops / enc_ms / 1e9, 1), "scoring_kernel_ms": round(k_ms, 3),
+            "encoder_ms": round(enc_ms, 3), "encoder_tflops": round(flops / enc_ms / 1e9, 1),
+            "encoder_roofline": {"bound": "mfma", "achieved": round(flops / enc_ms / 1e9, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                                 "frac": round(flops / enc_ms / 1e9 / 2500.0, 4),
+                                 "note": "whole forward over its wall time; flops = B L 12 (2 (H 3H + H H + 2 H F) + 4 L H)"},
+            "scoring_kernel_ms": round(k_ms, 3),
             "scoring_fp32_mfma_tflops": round(2 * 256 * n * 768 / k_ms / 1e9, 1), "end_to_end_ms": round(e2e_ms, 3),
             "queries_per_s_end_to_end": round(b / e2e_ms * 1e3, 1), "encoder_min_cosine_vs_fp64_oracle": cos,
             "recall_at_10_vs_cpu_oracle_200k_prefix": R.recall_at_k(pp.cpu().numpy(), ref_p)}
@@ -135,14 +139,85 @@ def config4(n=12_500_000, b=256):
             "recall_at_10_vs_cpu_oracle_same_codes_200k_prefix": R.recall_at_k(p8.cpu().numpy(), ref8)}
 
 
+def index_build(n_docs=65536, l_max=128):
+    """f3: Embeddings.index(list[dict]) (heavy_ranker.py:86) through a host tokenizer stand-in + the HIP encoder: docs/s."""
+    import zlib
+    from vietnamese_qa_system_amd.encoder import TextEncoder
+    cfg = dict(E.PHOBERT_BASE, vocab_size=8000)
+    w = E.synthetic_weights(cfg, seed=3)
+    enc = QuestionEncoder(w, cfg, max_tokens=256 * l_max)
+    rng = np.random.default_rng(77)
+    words = [f"từ{j}" for j in range(3000)]
+    lens = rng.integers(20, 120, size=n_docs)
+    docs = [{"id": i + 1, "text": " ".join(words[j] for j in rng.integers(0, 3000, size=lens[i]))} for i in range(n_docs)]
+
+    def tok(texts):
+        rows = [[0] + [3 + (zlib.crc32(t.encode()) % 7997) for t in x.split()][:l_max - 2] + [2] for x in texts]
+        width = max(len(r) for r in rows)
+        ids = np.full((len(rows), width), cfg["pad_id"], dtype=np.int32)
+        mask = np.zeros_like(ids)
+        for i, r in enumerate(rows):
+            ids[i, :len(r)] = r
+            mask[i, :len(r)] = 1
+        return ids, mask
+
+    t0 = time.perf_counter()
+    toks = [tok([d["text"] for d in docs[c:c + 256]]) for c in range(0, n_docs, 256)]
+    tok_s = time.perf_counter() - t0
+    it = iter(toks)
+    emb = Embeddings(encoder=TextEncoder(lambda texts: next(it), enc, pooling="mean", batch_size=256), dtype="fp16")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    emb.index(docs, batch_size=256)
+    torch.cuda.synchronize()
+    enc_s = time.perf_counter() - t0
+    tokens = int(sum(m.sum() for _, m in toks))
+    padded = int(sum(m.size for _, m in toks))
+    return {"config": f"Embeddings.index of {n_docs} synthetic documents (20-120 words, L <= {l_max}) through the HIP encoder, mean pooling",
+            "docs": n_docs, "real_tokens": tokens, "padded_tokens": padded, "host_tokenizer_seconds": round(tok_s, 2),
+            "encode_and_index_seconds": round(enc_s, 3), "docs_per_s_encode_and_index": round(n_docs / enc_s, 1),
+            "docs_per_s_with_host_tokenizer": round(n_docs / (enc_s + tok_s), 1), "padded_tokens_per_s": round(padded / enc_s, 1)}
+
+
+def load_rate(n=10_000_000, d=768):
+    """f1: save a fp16 shard, load it back (file -> pinned host buffers -> HBM, double buffered): GB/s.  The files were just
+    written, so they come from the page cache: this prices the host -> device path, not the disk."""
+    import shutil
+    import tempfile
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 2.5 * n * d * 2 else tempfile.gettempdir()
+    free = shutil.disk_usage(base).free
+    while n * d * 2 * 1.2 > free and n > 1_000_000:
+        n //= 2
+    path = tempfile.mkdtemp(prefix="vqa_load_", dir=base)
+    try:
+        rows = unit_rows(n, d, 5, dtype=torch.float16)
+        emb = Embeddings(dtype="fp16", min_score=None)
+        emb.index_vectors(None, rows)
+        q = unit_rows(16, d, 6)
+        before = emb.batchsearch(q, 5)
+        t0 = time.perf_counter()
+        emb.save(path)
+        save_s = time.perf_counter() - t0
+        del emb, rows
+        torch.cuda.empty_cache()
+        back = Embeddings(min_score=None).load(path)
+        same = back.batchsearch(q, 5) == before
+        st = back.load_stats
+        return {"config": f"save + load of a {n} x {d} fp16 shard ({n * d * 2 / 1e9:.2f} GB) under {base}", "save_seconds": round(save_s, 2),
+                "save_gb_per_s": round(n * d * 2 / save_s / 1e9, 2), "load_seconds": round(st["seconds"], 2),
+                "load_gb_per_s": round(st["gb_per_s"], 2), "results_identical_after_load": bool(same)}
+    finally:
+        shutil.rmtree(path, ignore_errors=True)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tag", default="r01")
-    ap.add_argument("--only", default="0,1,4")
+    ap.add_argument("--tag", default="r02")
+    ap.add_argument("--only", default="0,1,4,build,load")
     args = ap.parse_args()
     out = {}
     for c in args.only.split(","):
-        out[f"configs[{c}]"] = {"0": config0, "1": config1, "4": config4}[c]()
+        out[f"configs[{c}]"] = {"0": config0, "1": config1, "4": config4, "build": index_build, "load": load_rate}[c]()
         torch.cuda.empty_cache()
         print(json.dumps({f"configs[{c}]": out[f"configs[{c}]"]}), flush=True)
     path = os.path.join(ROOT, "gpurun_out", f"{args.tag}_configs.json")

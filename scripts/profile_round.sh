@@ -11,8 +11,8 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$TAG
 rm -rf $O; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 timeout 600 python3 $R/bench.py "$@" > $O/bench.json 2> $O/bench.err
-PROF_ARGS="--steps 12 --warmup 3 --no-cpu"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 60 --warmup 5 --no-cpu "$@" > $O/stats.log 2>&1
+PROF_ARGS="--steps 12 --warmup 3 --no-cpu --no-e2e"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 60 --warmup 5 --no-cpu --no-e2e "$@" > $O/stats.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py $PROF_ARGS "$@" > $O/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python3 $R/bench.py $PROF_ARGS "$@" > $O/pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmc_sq -- python3 $R/bench.py $PROF_ARGS "$@" > $O/pmc_sq.log 2>&1
