@@ -27,5 +27,32 @@ def test_bench_prints_one_json_line_with_the_contract_keys(native_lib):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["launches"] == 3
     cb = r["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["cpu_model"]
+    assert {(p["rows"], p["batch"]) for p in cb["points"]} >= {(1000, 256), (1000, 1), (100000, 256), (100000, 1)}
     assert r["recall_at_10"] == 1.0
+    sm = r["step_ms"]
+    assert sm["p10"] <= sm["median"] <= sm["p90"]
+    e2e = r["end_to_end"]
+    assert e2e["value"] > 0 and e2e["encoder_roofline"]["bound"] == "mfma" and 0 < e2e["encoder_roofline"]["frac"] < 1
+
+
+def test_bench_two_ranks_sharing_the_device(native_lib):
+    """bench.py's N > 1 path as the driver launches it (torch.distributed.run, one JSON line from rank 0), on the 1-GPU box:
+    VQA_BENCH_SHARE_GPU=1 puts both ranks on cuda:0 over gloo.  The row-sharded searcher, the all-gather, the merge, the
+    max-over-ranks timing and the end-to-end leg on every rank all run."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, VQA_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--docs-per-gpu",
+                          "200000", "--steps", "4", "--warmup", "2", "--verify-queries", "4", "--e2e-steps", "3"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["docs_total"] == 400000 and r["scaling"] == "weak"
+    assert r["recall_at_10"] == 1.0 and "cpu_baseline" not in r  # the CPU baseline is an N = 1 leg
+    assert r["roofline"]["launches"] == 4 and r["end_to_end"]["value"] > 0

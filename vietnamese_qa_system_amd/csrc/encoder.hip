@@ -7,8 +7,10 @@
 //
 // Kernels (all hand-written, fp16 storage, fp32 accumulation / statistics):
 //   embed_ln        word + position + type embeddings -> LayerNorm                      (one wave per token)
-//   gemm_nt<EPI>    C[M,N] = A[M,K] . W[N,K]^T + bias (+ erf GELU); v_mfma_f32_16x16x32_f16, 128x128x32 tiles,
-//                   register-staged double-buffered LDS image, XOR-swizzled for conflict-free ds_read_b128
+//   gemm_tile<..>   C[M,N] = A[M,K] . W[N,K]^T + bias (+ erf GELU | + residual row) for >= 1024 tokens: persistent, LDS-DMA ring,
+//                   anti-phase slot K loop, tile shape picked per problem (256x288 / 256x192 / 256x128 / 128x192), 16-byte stores
+//   gemm_skinny     <= 512 tokens (single queries, small batches): weights streamed once, fragments straight from global memory
+//   gemm_nt<EPI>    the shapes in between: v_mfma_f32_16x16x32_f16, 128x128 tiles, register-staged double-buffered LDS image
 //   attention       per (sequence, head): softmax(q k^T / sqrt(dh) + mask) v, K/V in LDS, wavefront-shuffle softmax
 //   ln              LayerNorm (the residual add is fused into the producing GEMM's epilogue) (one wave per token)
 //   pool_normalize  CLS row or masked mean -> fp32 -> x / ||x||                          (one wave per sequence)
@@ -258,372 +260,312 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const _Float16* __restrict
     }
 }
 
-// ---- GEMM for the large shapes (M >= 1024 tokens, N % 128 == 0, K % 64 == 0): 256 x 128 tiles, 8 waves, operands go
-// global -> LDS by LDS-DMA into a 3-stage ring (K tile kt + 2 is issued while kt is multiplied; counted vmcnt, one barrier
-// per K tile).  The DMA writes 64 lanes x 16 B contiguously, so the XOR swizzle of the LDS image is applied on the GLOBAL
-// side: lane i of a piece (8 rows x 128 B) fetches row i >> 3, logical 16-byte slot (i & 7) ^ (i >> 3).  MFMA operand
-// roles are swapped against the small kernel (A operand = weight rows, B operand = token rows), so a lane's 4 accumulator
-// values are 4 consecutive output features of one token: 8-byte stores instead of 2-byte ones.
-// Token rows past M are read (and their results dropped): the caller's activation buffers are padded to 256 rows.
-constexpr int kBigBM = 256, kBigBN = 128, kBigRowBytes = 128;  // K tile = 64 halves
-constexpr int kBigAStage = kBigBM * kBigRowBytes, kBigWStage = kBigBN * kBigRowBytes;
-constexpr int kBigStage = kBigAStage + kBigWStage;  // 48 KiB
-constexpr int kBigStages = 3;
-constexpr int kBigLds = kBigStages * kBigStage;     // 144 KiB
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// N_PIECES pieces of 1 KiB: piece p reads base + p * piece_stride + voff (per lane) and lands at lds_dst + p * 1024
-template <int N_PIECES>
-__device__ __forceinline__ void big_dma(const char* base, size_t piece_stride, uint32_t voff, uint32_t lds_dst) {
-    // the instruction offset moves the global AND the LDS address, so piece p's scalar base is pre-decremented by p * 1024
-    const char* b0 = base;
-    const char* b1 = base + piece_stride - 1024;
-    uint32_t keep;
-    if constexpr (N_PIECES == 4) {
-        const char* b2 = base + 2 * piece_stride - 2048;
-        const char* b3 = base + 3 * piece_stride - 3072;
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %6\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %2\n\t"
-            "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
-            "global_load_lds_dwordx4 %1, %4 offset:2048\n\t"
-            "global_load_lds_dwordx4 %1, %5 offset:3072\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(voff), "s"(b0), "s"(b1), "s"(b2), "s"(b3), "s"(lds_dst)
-            : "memory");
-    } else {
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %4\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, %2\n\t"
-            "global_load_lds_dwordx4 %1, %3 offset:1024\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(voff), "s"(b0), "s"(b1), "s"(lds_dst)
-            : "memory");
-    }
-}
-
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_big_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
-                                                       const float* __restrict__ bias, const _Float16* __restrict__ R,
-                                                       _Float16* __restrict__ C, int M, int N, int K, int tiles_n,
-                                                       int tiles_total) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    typedef __attribute__((address_space(3))) char* lds_ptr;
-    const uint32_t lds_base = (uint32_t)(size_t)(lds_ptr)lds;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;  // token rows [64 wr, +64) x output features [64 wc, +64) of the tile
-    const int c = lane & 15, g = lane >> 4;
-    // Persistent workgroups (one per CU): the K-tile stream runs on across output tiles, so the next tile's first two K
-    // tiles are in flight under this tile's epilogue.  XCD-aware tile order: consecutive workgroups go to different XCDs
-    // (8 of them, private L2 each); every XCD works through a contiguous run of tiles (feature tile fastest), so its
-    // workgroups share token rows and the weight matrix in L2.
-    const int G = gridDim.x, wg = blockIdx.x;
-    const bool swz = (tiles_total % 8 == 0) && (G % 8 == 0);
-    const int per = swz ? G >> 3 : G, first = swz ? wg >> 3 : wg, span = swz ? tiles_total >> 3 : tiles_total;
-    const int tile0 = swz ? (wg & 7) * span : 0;
-    const int my_tiles = first < span ? (span - first + per - 1) / per : 0;
-    const int KT = K / 64, total = my_tiles * KT;
-
-    // LDS-DMA geometry (constant per lane): row i >> 3 of the piece, logical slot (i & 7) ^ (i >> 3)
-    const size_t row_bytes = (size_t)K * 2;
-    const uint32_t voff = (uint32_t)((lane >> 3) * row_bytes + (((lane & 7) ^ (lane >> 3)) << 4));
-    const uint32_t a_dst = lds_base + 32 * wave * kBigRowBytes, w_dst = lds_base + kBigAStage + 16 * wave * kBigRowBytes;
-    int is_tile = 0, is_kt = 0, is_stage = 0;  // issue cursor: tile, K tile inside it, ring stage
-    const char* a_src = nullptr;
-    const char* w_src = nullptr;
-    auto issue_next = [&]() {
-        if (is_kt == 0) {
-            const int t = tile0 + first + is_tile * per;
-            a_src = reinterpret_cast<const char*>(A) + (size_t)((t / tiles_n) * kBigBM + 32 * wave) * row_bytes;  // 4 pieces
-            w_src = reinterpret_cast<const char*>(W) + (size_t)((t % tiles_n) * kBigBN + 16 * wave) * row_bytes;  // 2 pieces
-        }
-        big_dma<4>(a_src + (size_t)is_kt * kBigRowBytes, 8 * row_bytes, voff, a_dst + is_stage * kBigStage);
-        big_dma<2>(w_src + (size_t)is_kt * kBigRowBytes, 8 * row_bytes, voff, w_dst + is_stage * kBigStage);
-        if (++is_kt == KT) {
-            is_kt = 0;
-            ++is_tile;
-        }
-        if (++is_stage == kBigStages) is_stage = 0;
-    };
-    // fragment geometry: row (.. + c), logical slot 4 ks + g stored at position (4 ks + g) ^ (row & 7), row & 7 == c & 7
-    const int f0 = c * kBigRowBytes + ((g ^ (c & 7)) << 4), f1 = c * kBigRowBytes + (((4 + g) ^ (c & 7)) << 4);
-    const int a_row0 = wr * 64 * kBigRowBytes, w_row0 = kBigAStage + wc * 64 * kBigRowBytes;
-
-    if (total > 0) issue_next();
-    if (total > 1) issue_next();
-    if (total > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int kappa = 0, stage = 0;
-    for (int i = 0; i < my_tiles; ++i) {
-        f32x4 acc[4][4];  // [feature tile ni][token tile mi]
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < KT; ++kt, ++kappa) {
-            if (kappa + 2 < total) issue_next();  // into the stage of kappa - 1: every wave passed the barrier behind its reads
-            const char* st = lds + stage * kBigStage;
-            if (++stage == kBigStages) stage = 0;
-            half8 w0[4], x0[4], w1[4], x1[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                w0[j] = *reinterpret_cast<const half8*>(st + w_row0 + j * 16 * kBigRowBytes + f0);
-                x0[j] = *reinterpret_cast<const half8*>(st + a_row0 + j * 16 * kBigRowBytes + f0);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                w1[j] = *reinterpret_cast<const half8*>(st + w_row0 + j * 16 * kBigRowBytes + f1);
-                x1[j] = *reinterpret_cast<const half8*>(st + a_row0 + j * 16 * kBigRowBytes + f1);
-            }
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[ni], x0[mi], acc[ni][mi], 0, 0, 0);
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[ni], x1[mi], acc[ni][mi], 0, 0, 0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the stage are done before its refill
-            if (kappa + 2 < total) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // own pieces of kappa + 1 landed
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        // epilogue: acc[ni][mi][j] = C[token bm + 64 wr + 16 mi + c][feature bn + 64 wc + 16 ni + 4 g + j]
-        const int t = tile0 + first + i * per;
-        const int bm = (t / tiles_n) * kBigBM, bn = (t % tiles_n) * kBigBN;
-        typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            const int n0 = bn + wc * 64 + ni * 16 + g * 4;
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0);
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int m = bm + wr * 64 + mi * 16 + c;
-                if (m >= M) continue;
-                half4 res = half4{0, 0, 0, 0};
-                if (EPI == 2) res = *reinterpret_cast<const half4*>(R + (size_t)m * N + n0);
-                half4 o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v = acc[ni][mi][j] + bv[j];
-                    if (EPI == 1) v = gelu_erf(v);
-                    if (EPI == 2) v += (float)res[j];
-                    o[j] = (_Float16)v;
-                }
-                *reinterpret_cast<half4*>(C + (size_t)m * N + n0) = o;
-            }
-        }
-    }
-}
-
-// ---- the same GEMM with the K loop in ANTI-PHASE SLOTS (the structure of the scoring kernel's slot loop, score_topk.hip):
-// two barriers per K tile; in every slot one wave group only multiplies (32 MFMAs) while the other only moves data (reads
-// the fragments of its next K tile, issues its 6 LDS-DMA pieces), so the two waves of a SIMD -- one of each group -- never
-// share the matrix pipe and never leave it idle behind each other's memory phases.  One fragment set per wave.
-//     K tile kappa, slot 1:  group 0: read fragments(kappa), issue pieces of kappa + 2, vmcnt(6)   | group 1: MFMAs of kappa, vmcnt(0)
-//                  slot 2:  group 0: MFMAs of kappa                                             | group 1: read fragments(kappa + 1), issue kappa + 2
-// Stage kappa + 2 reuses the stage of kappa - 1 (3 stages): last read in slot 1 (kappa - 1) / slot 2 (kappa - 2).  Pieces are
-// always issued (past the end of the stream: the last K tile again, into a stage nobody reads any more): constant vmcnt.
+// ---- GEMM for the large shapes (M >= 1024 tokens): persistent workgroups (one per CU, 8 waves), BM x BN output tiles, operands
+// go global -> LDS by LDS-DMA in K-steps of 32 halves (64-byte rows, 1 KiB pieces of 16 rows) into a ring of S stages, and the
+// K loop runs in ANTI-PHASE SLOTS -- the structure of the scoring kernel's slot loop (score_topk.hip): two barriers per
+// K-step; in every slot one wave group only multiplies while the other only moves data (reads the fragments of its next
+// K-step, issues its LDS-DMA pieces), so the two waves of a SIMD -- one of each group -- never share the matrix pipe and
+// never leave it idle behind each other's memory phases.  One fragment set per wave.
+//     K-step kappa, slot 1:  group 0: read fragments(kappa), issue pieces of kappa + D   | group 1: MFMAs of kappa
+//                  slot 2:  group 0: MFMAs of kappa                                     | group 1: read fragments(kappa + 1), issue kappa + D
+// with D = S - 1: stage kappa + D reuses the stage of kappa - 1 (last read in slot 1 (kappa - 1) / slot 2 (kappa - 2)).
+// Pieces are always issued (past the end of the stream: the last K-step again, into a stage nobody reads any more), so every
+// wait is a constant vmcnt.  The K-step stream runs on across output tiles (the next tile's first K-steps land under this
+// tile's epilogue); XCD-aware tile order.
+//
+// What bounds it (ablation builds, profiles/r02_encoder_gemm_ablation.txt): with the MFMAs AND the stores removed a 256 x 128
+// tile kernel ran at 60 GB/s of L2 -> LDS traffic per CU -- the per-CU LDS-DMA rate (~26 B/clk), not the matrix pipe -- so the
+// lever is bytes per flop, (BM + BN) / (BM BN), and tile quantisation on 256 CUs.  The launcher picks, per (M, N), the shape
+// with the fewest LDS-DMA bytes per CU: at 8192 tokens 256 x 288 for QKV (N = 2304: 256 tiles, one round), 256 x 192 for FFN1
+// (N = 3072: 512 tiles, two rounds), 128 x 192 for the N = 768 projections (256 tiles).
+//
+// The DMA writes 64 lanes x 16 B contiguously, so the XOR swizzle of the LDS image is applied on the GLOBAL side: lane i of a
+// piece fetches row i >> 2, logical 16-byte slot (i & 3) ^ 3 bit3(row); fragment reads use the same involution.  MFMA operand
+// roles: A operand = weight rows, B operand = token rows, so a lane's 4 accumulator values are 4 consecutive output features
+// of one token.  Token rows past M are read (and their results dropped): the caller's activation buffers are padded to 256 rows.
 // EPI 0: + bias; 1: + bias, erf GELU; 2: + bias + residual row (the residual add of the post-LN block, fused here).
 #ifndef VQA_GEMM_ABLATE
 #define VQA_GEMM_ABLATE 0  // dev-only timing ablations (wrong results): 1 no epilogue stores, 2 no GELU, 4 no MFMAs in the K loop
 #endif
-template <int EPI>
-__global__ __launch_bounds__(512) void gemm_slot_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+template <int BM, int BN, int BK>
+struct TileGeom {
+    static constexpr int kRowB = 2 * BK;  // bytes of every operand row per K-step (BK = 32 or 64 halves)
+    static constexpr int kStageB = (BM + BN) * kRowB;
+    static constexpr int kStages = (160 * 1024 / kStageB) < 8 ? (160 * 1024 / kStageB) : 8;
+    static constexpr int kLds = kStages * kStageB;
+    static constexpr int kPieceRows = 1024 / kRowB;               // rows of one 1 KiB piece: 16 or 8
+    static constexpr int kPieces = (BM + BN) / kPieceRows;
+    static constexpr int kPerWave = (kPieces + 7) / 8;
+    static_assert(BK == 32 || BK == 64, "K-steps of 32 or 64 halves");
+    static_assert(kStages >= 3, "the anti-phase ring needs three stages");
+};
+
+// one LDS-DMA piece: 64 lanes x 16 B from `base + voff` (per lane) to LDS `lds_dst + lane * 16`
+__device__ __forceinline__ void tile_dma_piece(const char* base, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(base), "s"(lds_dst)
+        : "memory");
+}
+
+template <int N>
+__device__ __forceinline__ void tile_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int EPI, int BM, int BN, int WM, int WN, int BK>
+__global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                                                         const float* __restrict__ bias, const _Float16* __restrict__ R,
                                                         _Float16* __restrict__ C, int M, int N, int K, int tiles_n,
-                                                        int tiles_total) {
+                                                        int tiles_total, int nb) {
+    using G = TileGeom<BM, BN, BK>;
+    static_assert(WM * WN == 8 && BM % (16 * WM) == 0 && BN % (16 * WN) == 0, "8 waves, whole MFMA tiles per wave");
+    constexpr int MT = BM / WM / 16, NT = BN / WN / 16;  // token / feature MFMA tiles per wave
+    constexpr int S = G::kStages, D = S - 1, PR = G::kPieceRows, PA = BM / PR, NJ = G::kPerWave;
+    constexpr int kTileRowB = G::kRowB, KSUB = BK / 32, SP = kTileRowB / 16;  // 16-byte slots per row: 4 or 8
     extern __shared__ __attribute__((aligned(16))) char lds[];
     typedef __attribute__((address_space(3))) char* lds_ptr;
     const uint32_t lds_base = (uint32_t)(size_t)(lds_ptr)lds;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;  // token rows [64 wr, +64) x output features [64 wc, +64) of the tile
-    const int grp = wave >> 2;                // group 0: token rows 0-127, group 1: rows 128-255 (partners w, w + 4 share a SIMD)
+    const int wr = wave / WN, wc = wave % WN;  // token rows [wr BM/WM, +BM/WM) x output features [wc BN/WN, +BN/WN) of the tile
+    const int grp = wave >> 2;                 // partners w, w + 4 share a SIMD: one of each group
     const int c = lane & 15, g = lane >> 4;
-    const int G = gridDim.x, wg = blockIdx.x;
-    const bool swz = (tiles_total % 8 == 0) && (G % 8 == 0);
-    const int per = swz ? G >> 3 : G, first = swz ? wg >> 3 : wg, span = swz ? tiles_total >> 3 : tiles_total;
+    const int Gd = gridDim.x, wg = blockIdx.x;
+    const bool swz = (tiles_total % 8 == 0) && (Gd % 8 == 0);
+    const int per = swz ? Gd >> 3 : Gd, first = swz ? wg >> 3 : wg, span = swz ? tiles_total >> 3 : tiles_total;
     const int tile0 = swz ? (wg & 7) * span : 0;
     const int my_tiles = first < span ? (span - first + per - 1) / per : 0;
-    const int KT = K / 64, total = my_tiles * KT;
+    const int KT = K / BK, total = my_tiles * KT;
     if (total == 0) return;
+    // Tile of this workgroup's i-th iteration.  nb > 0 (the launcher checked the divisibilities): the `per` workgroups of an
+    // XCD work on a block of (per / nb) token tiles x nb feature tiles at the same time, blocks advance along the features
+    // first -- so what the XCD's L2 holds at any moment is (per / nb) activation row panels + nb weight panels (a whole
+    // feature-fastest run of `per` tiles spans every weight panel: FFN1's 4.7 MB of weights did not fit the 4 MiB L2).
+    auto tile_of = [&](int i) __attribute__((always_inline)) -> int {
+        if (nb <= 0) return tile0 + first + i * per;
+        const int mb = per / nb, nbn = tiles_n / nb;
+        const int m = (tile0 / tiles_n) + (i / nbn) * mb + first / nb;
+        return m * tiles_n + (i % nbn) * nb + first % nb;
+    };
 
+    // ---- issue side: this wave's pieces p = wave + 8 j of every K-step; piece p < PA holds token rows PR p .., the others weight
+    // rows.  Lane i of a piece: row i / SP, physical slot i % SP, which holds logical slot phys ^ f(row) -- f = 3 bit3(row) for
+    // 64-byte rows, row & 7 for 128-byte rows (both conflict-free for ds_read_b128)
     const size_t row_bytes = (size_t)K * 2;
-    const uint32_t voff = (uint32_t)((lane >> 3) * row_bytes + (((lane & 7) ^ (lane >> 3)) << 4));
-    const uint32_t a_dst = lds_base + 32 * wave * kBigRowBytes, w_dst = lds_base + kBigAStage + 16 * wave * kBigRowBytes;
-    int is_tile = 0, is_kt = 0, is_stage = 0, is_n = 0;  // issue cursor: tile, K tile inside it, ring stage, K tiles issued
-    const char* a_src = nullptr;
-    const char* w_src = nullptr;
+    const int prow = lane / SP, pslot = lane % SP;
+    const uint32_t voff = (uint32_t)(prow * row_bytes + ((pslot ^ (BK == 32 ? 3 * ((prow >> 3) & 1) : (prow & 7))) << 4));
+    const int n_mine = (G::kPieces - wave + 7) / 8;  // NJ or NJ - 1
+    int is_tile = 0, is_kt = 0, is_stage = 0, is_n = 0;  // issue cursor: tile, K-step inside it, ring stage, K-steps issued
+    const char* src[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) src[j] = nullptr;
     auto issue_next = [&]() __attribute__((always_inline)) {
         if (is_kt == 0 && is_n < total) {
-            const int t = tile0 + first + is_tile * per;
-            a_src = reinterpret_cast<const char*>(A) + (size_t)((t / tiles_n) * kBigBM + 32 * wave) * row_bytes;  // 4 pieces
-            w_src = reinterpret_cast<const char*>(W) + (size_t)((t % tiles_n) * kBigBN + 16 * wave) * row_bytes;  // 2 pieces
+            const int t = tile_of(is_tile);
+            const size_t bm = (size_t)(t / tiles_n) * BM, bn = (size_t)(t % tiles_n) * BN;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int p = wave + 8 * j;
+                src[j] = p < PA ? reinterpret_cast<const char*>(A) + (bm + PR * p) * row_bytes
+                                : reinterpret_cast<const char*>(W) + (bn + PR * (p - PA)) * row_bytes;
+            }
         }
-        big_dma<4>(a_src + (size_t)is_kt * kBigRowBytes, 8 * row_bytes, voff, a_dst + is_stage * kBigStage);
-        big_dma<2>(w_src + (size_t)is_kt * kBigRowBytes, 8 * row_bytes, voff, w_dst + is_stage * kBigStage);
+        const uint32_t dst = lds_base + is_stage * G::kStageB + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            if (j < n_mine) tile_dma_piece(src[j] + (size_t)is_kt * kTileRowB, voff, dst + j * 8192);
         ++is_n;
-        if (is_n < total) {  // past the end the cursor stays on the last K tile
+        if (is_n < total) {  // past the end the cursor stays on the last K-step
             if (++is_kt == KT) {
                 is_kt = 0;
                 ++is_tile;
             }
         }
-        if (++is_stage == kBigStages) is_stage = 0;
+        if (++is_stage == S) is_stage = 0;
     };
-    const int f0 = c * kBigRowBytes + ((g ^ (c & 7)) << 4), f1 = c * kBigRowBytes + (((4 + g) ^ (c & 7)) << 4);
-    const int a_row0 = wr * 64 * kBigRowBytes, w_row0 = kBigAStage + wc * 64 * kBigRowBytes;
-    int rstage = 0;  // stage of the K tile this group reads next
-    half8 w0[4], x0[4], w1[4], x1[4];
-#define VQA_G_READ()                                                                                  \
-    do {                                                                                              \
-        const char* st = lds + rstage * kBigStage;                                                    \
-        if (++rstage == kBigStages) rstage = 0;                                                       \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
-            w0[j] = *reinterpret_cast<const half8*>(st + w_row0 + j * 16 * kBigRowBytes + f0);        \
-            x0[j] = *reinterpret_cast<const half8*>(st + a_row0 + j * 16 * kBigRowBytes + f0);        \
-        }                                                                                             \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                               \
-            w1[j] = *reinterpret_cast<const half8*>(st + w_row0 + j * 16 * kBigRowBytes + f1);        \
-            x1[j] = *reinterpret_cast<const half8*>(st + a_row0 + j * 16 * kBigRowBytes + f1);        \
-        }                                                                                             \
+    // all but the youngest `KSTEPS` K-steps of this wave's pieces have landed
+    auto wait_keep = [&](auto ksteps_tag) __attribute__((always_inline)) {
+        constexpr int KS = decltype(ksteps_tag)::value;
+        if (n_mine == NJ) tile_wait_vmcnt<KS * NJ>();
+        else tile_wait_vmcnt<KS * (NJ - 1)>();
+    };
+    // ---- fragment geometry: row (base + c) of a stage, sub-step ks: logical slot 4 ks + g at position slot ^ f(row); row
+    // bases are multiples of 16, so f(row) = f(c)
+    int frag[KSUB];
+#pragma unroll
+    for (int ks = 0; ks < KSUB; ++ks)
+        frag[ks] = c * kTileRowB + (((4 * ks + g) ^ (BK == 32 ? 3 * ((c >> 3) & 1) : (c & 7))) << 4);
+    const int x_off = wr * (BM / WM) * kTileRowB;
+    const int w_off = BM * kTileRowB + wc * (BN / WN) * kTileRowB;
+    int rstage = 0;  // stage of the K-step this group reads next
+    half8 wf[KSUB][NT], xf[KSUB][MT];
+#define VQA_T_READ()                                                                                          \
+    do {                                                                                                      \
+        const char* st = lds + rstage * G::kStageB;                                                           \
+        if (++rstage == S) rstage = 0;                                                                        \
+        _Pragma("unroll") for (int ks = 0; ks < KSUB; ++ks) {                                                 \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                    \
+                wf[ks][j] = *reinterpret_cast<const half8*>(st + w_off + j * 16 * kTileRowB + frag[ks]);      \
+            _Pragma("unroll") for (int j = 0; j < MT; ++j)                                                    \
+                xf[ks][j] = *reinterpret_cast<const half8*>(st + x_off + j * 16 * kTileRowB + frag[ks]);      \
+        }                                                                                                     \
     } while (0)
 // the MFMAs are register-only: the pins keep hipcc from moving them across the slot's barriers
-#define VQA_G_MMA()                                                                                               \
+#define VQA_T_MMA()                                                                                               \
     do {                                                                                                          \
-        asm volatile("" : "+v"(w0[0]), "+v"(w0[1]), "+v"(w0[2]), "+v"(w0[3]), "+v"(x0[0]), "+v"(x0[1]), "+v"(x0[2]), \
-                     "+v"(x0[3]));                                                                                \
+        _Pragma("unroll") for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(xf[0][j]));                         \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
         if (!(VQA_GEMM_ABLATE & 4)) {                                                                             \
-        _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                          \
-            _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                      \
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0[ni], x0[mi], acc[ni][mi], 0, 0, 0);       \
-        _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                          \
-            _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                      \
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w1[ni], x1[mi], acc[ni][mi], 0, 0, 0);       \
+            _Pragma("unroll") for (int ks = 0; ks < KSUB; ++ks)                                                   \
+                _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                                                 \
+                    _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                                             \
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ks][ni], xf[ks][mi], acc[ni][mi], 0, 0, 0); \
         }                                                                                                         \
-        _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                          \
-            asm volatile("" ::"v"(acc[ni][0]), "v"(acc[ni][1]), "v"(acc[ni][2]), "v"(acc[ni][3]));                \
+        _Pragma("unroll") for (int ni = 0; ni < NT; ++ni)                                                         \
+            _Pragma("unroll") for (int mi = 0; mi < MT; ++mi) asm volatile("" ::"v"(acc[ni][mi]));                \
         __builtin_amdgcn_sched_barrier(0);                                                                        \
     } while (0)
-#define VQA_G_BARRIER()                         \
+#define VQA_T_BARRIER()                         \
     do {                                        \
         __builtin_amdgcn_sched_barrier(0);      \
         __builtin_amdgcn_s_barrier();           \
         __builtin_amdgcn_sched_barrier(0);      \
     } while (0)
-    // prologue: K tiles 0 and 1 issued, 0 landed; group 1 holds fragments(0)
-    issue_next();
-    issue_next();
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    VQA_G_BARRIER();
+    // prologue: K-steps 0 .. D - 1 issued, K-step 0 landed; group 1 holds fragments(0)
+    for (int i = 0; i < D; ++i) issue_next();
+    wait_keep(std::integral_constant<int, D - 1>{});
+    VQA_T_BARRIER();
     // the tile loop exists once per group, the wave-uniform branch sits outside it (no diamond around the MFMA blocks)
     auto run = [&](auto first_group_tag) __attribute__((always_inline)) {
-    constexpr bool kG0 = decltype(first_group_tag)::value;
-    if constexpr (!kG0) {
-        VQA_G_READ();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    VQA_G_BARRIER();
-    for (int i = 0; i < my_tiles; ++i) {
-        f32x4 acc[4][4];  // [feature tile ni][token tile mi]
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int kt = 0; kt < KT; ++kt) {
-            // ---- slot 1
-            if constexpr (kG0) {
-                VQA_G_READ();
-                issue_next();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            } else {
-                VQA_G_MMA();
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            VQA_G_BARRIER();
-            // ---- slot 2
-            if constexpr (kG0) {
-                VQA_G_MMA();
-            } else {
-                VQA_G_READ();
-                issue_next();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            }
-            VQA_G_BARRIER();
+        constexpr bool kG0 = decltype(first_group_tag)::value;
+        if constexpr (!kG0) {
+            VQA_T_READ();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        // epilogue: acc[ni][mi][j] = C[token bm + 64 wr + 16 mi + c][feature bn + 64 wc + 16 ni + 4 g + j].  A lane's 4
-        // features of one tile are 8 bytes of fp16: v_permlane16_swap between the registers of feature tiles ni and ni + 1
-        // (lanes g = 1 <-> g = 0, g = 3 <-> g = 2 of the same token) leaves every lane with 8 CONSECUTIVE features --
-        // tile ni + (g & 1), features 8 (g >> 1) .. + 7 -- so the tile goes out as 8 sixteen-byte stores per wave instead of 16
-        // eight-byte ones (a wave instruction then covers 16 token rows x 64 contiguous bytes); bias, GELU and the residual
-        // row are applied in that layout.
-        const int t = tile0 + first + i * per;
-        const int bm = (t / tiles_n) * kBigBM, bn = (t % tiles_n) * kBigBN;
+        VQA_T_BARRIER();
+        for (int i = 0; i < my_tiles; ++i) {
+            f32x4 acc[NT][MT];  // [feature tile ni][token tile mi]
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-            const int n0 = bn + wc * 64 + (2 * pr + (g & 1)) * 16 + (g >> 1) * 8;
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + n0), b1 = *reinterpret_cast<const f32x4*>(bias + n0 + 4);
+            for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                // (cast the whole vector first: __builtin_bit_cast of a single vector ELEMENT reads element 0 for every index)
-                u32x4 ulo = __builtin_bit_cast(u32x4, acc[2 * pr][mi]), uhi = __builtin_bit_cast(u32x4, acc[2 * pr + 1][mi]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const auto r = __builtin_amdgcn_permlane16_swap(ulo[j], uhi[j], false, false);
-                    ulo[j] = r[0];
-                    uhi[j] = r[1];
+                for (int mi = 0; mi < MT; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int kt = 0; kt < KT; ++kt) {
+                // ---- slot 1
+                if constexpr (kG0) {
+                    VQA_T_READ();
+                    issue_next();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    wait_keep(std::integral_constant<int, D - 1>{});  // own pieces of kappa + 1 landed (group 1 reads them in slot 2)
+                } else {
+                    VQA_T_MMA();
+                    wait_keep(std::integral_constant<int, D - 2>{});  // own pieces of kappa + 1 landed
                 }
-                const f32x4 lo = __builtin_bit_cast(f32x4, ulo), hi = __builtin_bit_cast(f32x4, uhi);
-                const int m = bm + wr * 64 + mi * 16 + c;
-                if (m >= M) continue;  // after the swaps: every lane takes part in them
-                half8 res = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (EPI == 2) res = *reinterpret_cast<const half8*>(R + (size_t)m * N + n0);
-                half8 o;
+                VQA_T_BARRIER();
+                // ---- slot 2
+                if constexpr (kG0) {
+                    VQA_T_MMA();
+                } else {
+                    VQA_T_READ();
+                    issue_next();
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                VQA_T_BARRIER();
+            }
+            // ---- epilogue: acc[ni][mi][j] = C[token bm + wr BM/WM + 16 mi + c][feature bn + wc BN/WN + 16 ni + 4 g + j].  A lane's
+            // 4 features of one tile are 8 bytes of fp16: v_permlane16_swap between the registers of feature tiles ni and ni + 1
+            // (lanes g = 1 <-> g = 0, g = 3 <-> g = 2 of the same token) leaves every lane with 8 CONSECUTIVE features -- tile
+            // ni + (g & 1), features 8 (g >> 1) .. + 7 -- so a pair of tiles goes out as one 16-byte store per lane (a wave
+            // instruction covers 16 token rows x 64 contiguous bytes); bias, GELU and the residual row are applied in that layout.
+            // An odd last feature tile keeps the 8-byte form.
+            const int t = tile_of(i);
+            const int bm = (t / tiles_n) * BM, bn = (t % tiles_n) * BN;
+            typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float v0 = lo[j] + b0[j], v1 = hi[j] + b1[j];
+            for (int pr = 0; pr < NT / 2; ++pr) {
+                const int n0 = bn + wc * (BN / WN) + (2 * pr + (g & 1)) * 16 + (g >> 1) * 8;
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + n0), b1 = *reinterpret_cast<const f32x4*>(bias + n0 + 4);
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    // (cast the whole vector first: __builtin_bit_cast of a single vector ELEMENT reads element 0 for every index)
+                    u32x4 ulo = __builtin_bit_cast(u32x4, acc[2 * pr][mi]), uhi = __builtin_bit_cast(u32x4, acc[2 * pr + 1][mi]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const auto r = __builtin_amdgcn_permlane16_swap(ulo[j], uhi[j], false, false);
+                        ulo[j] = r[0];
+                        uhi[j] = r[1];
+                    }
+                    const f32x4 lo = __builtin_bit_cast(f32x4, ulo), hi = __builtin_bit_cast(f32x4, uhi);
+                    const int m = bm + wr * (BM / WM) + mi * 16 + c;
+                    if (m >= M) continue;  // after the swaps: every lane takes part in them
+                    half8 res = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                    if (EPI == 2) res = *reinterpret_cast<const half8*>(R + (size_t)m * N + n0);
+                    half8 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v0 = lo[j] + b0[j], v1 = hi[j] + b1[j];
 #if !(VQA_GEMM_ABLATE & 2)
-                    if (EPI == 1) {
-                        v0 = gelu_erf(v0);
-                        v1 = gelu_erf(v1);
-                    }
+                        if (EPI == 1) {
+                            v0 = gelu_erf(v0);
+                            v1 = gelu_erf(v1);
+                        }
 #endif
-                    if (EPI == 2) {
-                        v0 += (float)res[j];
-                        v1 += (float)res[4 + j];
+                        if (EPI == 2) {
+                            v0 += (float)res[j];
+                            v1 += (float)res[4 + j];
+                        }
+                        o[j] = (_Float16)v0;
+                        o[4 + j] = (_Float16)v1;
                     }
-                    o[j] = (_Float16)v0;
-                    o[4 + j] = (_Float16)v1;
-                }
 #if VQA_GEMM_ABLATE & 1
-                asm volatile("" ::"v"(o));
-#else
-                *reinterpret_cast<half8*>(C + (size_t)m * N + n0) = o;
+                    asm volatile("" ::"v"(o));
+#else  // plain stores: sc1 / sc0 sc1 (write-through, dropped from the XCD's L2) measured the same, nt 6 % slower on the forward
+                    *reinterpret_cast<half8*>(C + (size_t)m * N + n0) = o;
 #endif
+                }
+            }
+            if constexpr (NT & 1) {
+                const int n0 = bn + wc * (BN / WN) + (NT - 1) * 16 + g * 4;
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0);
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    const int m = bm + wr * (BM / WM) + mi * 16 + c;
+                    if (m >= M) continue;
+                    half4 res = half4{0, 0, 0, 0};
+                    if (EPI == 2) res = *reinterpret_cast<const half4*>(R + (size_t)m * N + n0);
+                    half4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = acc[NT - 1][mi][j] + bv[j];
+#if !(VQA_GEMM_ABLATE & 2)
+                        if (EPI == 1) v = gelu_erf(v);
+#endif
+                        if (EPI == 2) v += (float)res[j];
+                        o[j] = (_Float16)v;
+                    }
+#if VQA_GEMM_ABLATE & 1
+                    asm volatile("" ::"v"(o));
+#else
+                    *reinterpret_cast<half4*>(C + (size_t)m * N + n0) = o;
+#endif
+                }
             }
         }
-    }
     };
     if (grp) run(std::false_type{});
     else run(std::true_type{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the pieces issued past the end of the stream land before the LDS is released
-#undef VQA_G_READ
-#undef VQA_G_MMA
-#undef VQA_G_BARRIER
+    tile_wait_vmcnt<0>();  // the pieces issued past the end of the stream land before the LDS is released
+#undef VQA_T_READ
+#undef VQA_T_MMA
+#undef VQA_T_BARRIER
 }
 
 // ---- GEMM for a handful of tokens (M <= 64: single queries, the reference's own calling pattern heavy_ranker.py:97-98):
@@ -1008,11 +950,50 @@ int upload_f16(vqa_encoder* e, const float* src, size_t n, _Float16* dst) {
     return VQA_OK;
 }
 
+constexpr int kTokenPad = 256;  // activation buffers are padded to this many rows (the tallest tile)
+
+template <int EPI, int BM, int BN, int WM, int WN, int BK>
+int launch_tile(const _Float16* A, const _Float16* W, const float* bias, const _Float16* R, _Float16* C, int M, int N, int K,
+                int num_cu, hipStream_t s) {
+    using G = TileGeom<BM, BN, BK>;
+    static VqaPerDeviceOnce once;
+    int rc = once.run([&](int) -> int {
+        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<EPI, BM, BN, WM, WN, BK>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, G::kLds));
+        return VQA_OK;
+    });
+    if (rc != VQA_OK) return rc;
+    const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM, tiles = tiles_n * tiles_m;
+    const int grid = tiles < num_cu ? tiles : num_cu;
+    // blocked tile order inside an XCD (see tile_of in the kernel): needs the XCD split itself (tiles, grid multiples of 8),
+    // whole token-tile rows per XCD, and a block of per = grid / 8 tiles that divides them
+    static const int nb_force = getenv("VQA_GEMM_NB") ? atoi(getenv("VQA_GEMM_NB")) : -1;  // dev override; 0 = feature-fastest order
+    int nb = 0;
+    if (tiles % 8 == 0 && grid % 8 == 0 && tiles_m % 8 == 0) {
+        const int per = grid / 8, rows = tiles_m / 8;
+        for (int cand = 8; cand >= 1 && nb == 0; --cand)
+            if (tiles_n % cand == 0 && per % cand == 0 && rows % (per / cand) == 0) nb = cand;
+        if (nb_force >= 0 && (nb_force == 0 || (tiles_n % nb_force == 0 && per % nb_force == 0 && rows % (per / nb_force) == 0)))
+            nb = nb_force;
+    }
+    hipLaunchKernelGGL((gemm_tile_kernel<EPI, BM, BN, WM, WN, BK>), dim3(grid), dim3(512), G::kLds, s, A, W, bias, R, C, M, N, K,
+                       tiles_n, tiles, nb);
+    VQA_HIP_CHECK(hipGetLastError());
+    return VQA_OK;
+}
+
+// LDS-DMA bytes per CU (in units of 64 KT bytes) of a tile shape on this problem: rounds of tiles x (BM + BN)
+static long tile_cost(int M, int N, int BM, int BN, int num_cu) {
+    if (N % BN) return -1;
+    const long tiles = (long)(N / BN) * ((M + BM - 1) / BM);
+    return (tiles + num_cu - 1) / num_cu * (BM + BN);
+}
+
 template <int EPI>
 int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, const _Float16* R, _Float16* C, int M, int N, int K,
                 hipStream_t s) {
     static const bool force_small = getenv("VQA_GEMM_SMALL") != nullptr;  // dev override, read once
-    static const bool force_v1 = getenv("VQA_GEMM_V1") != nullptr;        // dev override: the one-barrier 256 x 128 kernel
+    static const int force_tile = getenv("VQA_GEMM_TILE") ? atoi(getenv("VQA_GEMM_TILE")) : -1;  // dev override: shape index 0..4
     static const int skinny_max = getenv("VQA_SKINNY_MAX") ? atoi(getenv("VQA_SKINNY_MAX")) : 512;  // dev override; measured crossover with the 128 x 128 kernel ~ 700 tokens
     if (M <= skinny_max && N % 16 == 0 && K % 256 == 0 && !force_small) {
         const int mt = M >= 64 ? 4 : (M + 15) / 16;
@@ -1028,30 +1009,43 @@ int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, const _
         VQA_HIP_CHECK(hipGetLastError());
         return VQA_OK;
     }
-    if (M >= 1024 && N % kBigBN == 0 && K % 64 == 0 && !force_small) {
+    if (M >= 1024 && N % 64 == 0 && K % 32 == 0 && !force_small) {
         static VqaPerDeviceOnce once;
         static int num_cu[64] = {};  // written inside the once, read after it
         int dev = 0;
         VQA_HIP_CHECK(hipGetDevice(&dev));
         int rc = once.run([&](int d) -> int {
-            VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel<EPI>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
-            VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_slot_kernel<EPI>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds));
             hipDeviceProp_t prop;
             VQA_HIP_CHECK(hipGetDeviceProperties(&prop, d));
             num_cu[d & 63] = prop.multiProcessorCount;
             return VQA_OK;
         });
         if (rc != VQA_OK) return rc;
-        const int tiles_n = N / kBigBN, tiles = tiles_n * ((M + kBigBM - 1) / kBigBM);
-        const int grid = tiles < num_cu[dev & 63] ? tiles : num_cu[dev & 63];
-        if (force_v1)
-            hipLaunchKernelGGL(gemm_big_kernel<EPI>, dim3(grid), dim3(512), kBigLds, s, A, W, bias, R, C, M, N, K, tiles_n, tiles);
-        else
-            hipLaunchKernelGGL(gemm_slot_kernel<EPI>, dim3(grid), dim3(512), kBigLds, s, A, W, bias, R, C, M, N, K, tiles_n, tiles);
-        VQA_HIP_CHECK(hipGetLastError());
-        return VQA_OK;
+        const int cu = num_cu[dev & 63];
+        // Tile shapes: {BM, BN, BK}.  The cost model is LDS-DMA bytes per CU (rounds of tiles x (BM + BN)): what the K loop is
+        // bound by; K-steps of 32 halves pay two barriers per 32-deep step, so a 64-deep shape wins a near tie (x 0.85).
+        static const int shapes[5][3] = {{256, 288, 32}, {256, 192, 32}, {256, 128, 64}, {128, 192, 64}, {256, 128, 32}};
+        int best = -1;
+        double best_cost = 0;
+        for (int i = 0; i < 4; ++i) {
+            const long cst = K % shapes[i][2] ? -1 : tile_cost(M, N, shapes[i][0], shapes[i][1], cu);
+            const double w = cst * (shapes[i][2] == 64 ? 0.85 : 1.0);
+            if (cst >= 0 && (best < 0 || w < best_cost)) {
+                best = i;
+                best_cost = w;
+            }
+        }
+        if (force_tile >= 0 && force_tile < 5 && K % shapes[force_tile][2] == 0 &&
+            tile_cost(M, N, shapes[force_tile][0], shapes[force_tile][1], cu) >= 0)
+            best = force_tile;
+        switch (best) {
+            case 0: return launch_tile<EPI, 256, 288, 4, 2, 32>(A, W, bias, R, C, M, N, K, cu, s);
+            case 1: return launch_tile<EPI, 256, 192, 4, 2, 32>(A, W, bias, R, C, M, N, K, cu, s);
+            case 2: return launch_tile<EPI, 256, 128, 4, 2, 64>(A, W, bias, R, C, M, N, K, cu, s);
+            case 3: return launch_tile<EPI, 128, 192, 2, 4, 64>(A, W, bias, R, C, M, N, K, cu, s);
+            case 4: return launch_tile<EPI, 256, 128, 4, 2, 32>(A, W, bias, R, C, M, N, K, cu, s);
+            default: break;  // no shape divides N / K: the register-staged kernel below
+        }
     }
     dim3 grid((N + kGemmBN - 1) / kGemmBN, (M + kGemmBM - 1) / kGemmBM);
     if (K % 64 == 0)
@@ -1144,7 +1138,7 @@ extern "C" int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encod
         }
         if (rc != VQA_OK) break;
         // token rows padded to the large GEMM's 256-row tiles: rows past B * L are read (never written back), so clear them once
-        const size_t T = ((size_t)max_tokens + kBigBM - 1) / kBigBM * kBigBM;
+        const size_t T = ((size_t)max_tokens + kTokenPad - 1) / kTokenPad * kTokenPad;
         if ((rc = dev_alloc(e, (void**)&e->x, T * H * 2)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->qkv, T * 3 * H * 2)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->ctx, T * H * 2)) != VQA_OK) break;
