@@ -16,9 +16,10 @@ DPR algorithm in plain numpy -- it imports nothing from ``transformers``:
 * pooling: CLS row of the last layer (``modeling_dpr.py`` ``DPREncoder.forward``: ``sequence_output[:, 0, :]``, no
   projection when ``projection_dim = 0``) or sentence-transformers masked mean; then ``x / ||x||``.
 
-PARITY STATUS: pinned against outputs of HF ``RobertaModel`` / ``DPRQuestionEncoder`` run in the build container
-(``tests/golden/make_golden_encoder.py`` -> ``enc_tiny.npz``, ``enc_phobert_layer.npz``); the reference itself holds
-no golden vectors for the encoder.
+PARITY STATUS: **parity unpinned by the reference** -- it holds no golden vectors for the encoder.  The oracle is checked
+against outputs of HF ``RobertaModel`` / ``DPRQuestionEncoder`` of transformers 5.15 (what the build container has, NOT the
+reference's pinned 4.33.1) run here (``tests/golden/make_golden_encoder.py`` -> ``enc_tiny.npz``, ``enc_phobert_layer.npz``):
+a third-party stand-in, not a pin to the reference.
 """
 from __future__ import annotations
 
