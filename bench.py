@@ -369,8 +369,9 @@ def end_to_end(torch, np, searcher, device, dev_index, b, k, steps, sync, L=32):
     ids = torch.where(mask.bool(), ids, torch.full_like(ids, cfg["pad_id"]))
     ids[:, 0] = 0
     ids[torch.arange(b, device=device), (lens - 1).to(torch.int64)] = 2
+    real = int(mask.sum())  # the mask is right-padded: the encoder computes only these rows (sequence packing)
     for _ in range(5):
-        qv = enc.forward(ids, mask, pooling="cls", normalize=True)
+        qv = enc.forward(ids, mask, pooling="cls", normalize=True, real_tokens=real)
         searcher.search(qv, k)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(steps)]
@@ -378,7 +379,7 @@ def end_to_end(torch, np, searcher, device, dev_index, b, k, steps, sync, L=32):
     t0 = time.perf_counter()
     for e0, e1, e2 in ev:
         e0.record()
-        qv = enc.forward(ids, mask, pooling="cls", normalize=True)
+        qv = enc.forward(ids, mask, pooling="cls", normalize=True, real_tokens=real)
         e1.record()
         searcher.search(qv, k)
         e2.record()
@@ -387,10 +388,12 @@ def end_to_end(torch, np, searcher, device, dev_index, b, k, steps, sync, L=32):
     enc_ms = [e0.elapsed_time(e1) for e0, e1, _ in ev]
     tot_ms = [e0.elapsed_time(e2) for e0, _, e2 in ev]
     enc.close()
-    tokens = b * L
-    flops = tokens * cfg["layers"] * (2 * (h * 3 * h + h * h + 2 * h * f) + 4 * L * h)
+    # algorithmic flops of the REAL tokens (padding rows are not computed): GEMMs per token + attention over each sequence's own length
+    lens_f = lens.double()
+    flops = int(cfg["layers"] * (real * 2 * (h * 3 * h + h * h + 2 * h * f) + float((lens_f * lens_f).sum()) * 4 * h))
     enc_med = float(np.median(enc_ms))
-    return {"workload": f"PhoBERT-base-shape question encoder (random init, B={b}, L={L}, CLS pooling, L2 norm) + search + merge",
+    return {"workload": f"PhoBERT-base-shape question encoder (random init, B={b}, L={L}, {real} real tokens of {b * L}: lengths uniform "
+                        f"8-{L}, right-padded, packed; CLS pooling, L2 norm) + search + merge",
             "steps": steps, "ms_per_batch": round(el / steps * 1e3, 4), "value": round(b * steps / el, 1), "unit": "queries/s",
             "batch_ms": percentiles(np, tot_ms), "encoder_ms": percentiles(np, enc_ms),
             "encoder_roofline": {"bound": "mfma", "achieved": round(flops / (enc_med * 1e-3) / 1e12, 1), "peak": F16_MFMA_PEAK_TFLOPS,

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VQA_VERSION 100 /* 0.1.0 */
+#define VQA_VERSION 101 /* 0.1.1: vqa_encoder_forward takes real_tokens, vqa_launch_info.seed_tiles */
 
 /* error codes */
 #define VQA_OK 0
@@ -152,11 +152,16 @@ int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encoder_config* 
                        int32_t max_tokens /* B*L capacity of the activation workspace */);
 void vqa_encoder_destroy(vqa_encoder* enc);
 /* input_ids, attn_mask: [B, L] int32 device.  out: [B, hidden] fp32 device.
+ * real_tokens: 0 = unknown (every one of the B * L positions is computed), else the number of set mask entries of a
+ * RIGHT-PADDED mask (mask[b][l] = 1 exactly for l < n_b, n_b >= 1): calls of more than 4096 positions then compute only those
+ * rows (sequence packing; the results of the real tokens are identical, padding keys carry zero attention weight either
+ * way).  A mask that is not right-padded, or holds more set entries than announced, invalidates that call's output and makes
+ * the NEXT vqa_encoder_forward on the handle fail with VQA_EINVAL.
  * Token ids outside [0, vocab_size) never index the embedding table: they are embedded as pad_id and a host-visible flag
  * is raised, which makes the NEXT vqa_encoder_forward on the handle fail with VQA_EINVAL (the call that saw them cannot
  * report it without a synchronisation). */
 int vqa_encoder_forward(vqa_encoder* enc, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L,
-                        int32_t pooling, int32_t normalize, float* out, void* hip_stream);
+                        int32_t real_tokens, int32_t pooling, int32_t normalize, float* out, void* hip_stream);
 
 /* ---- helpers used by the host side when it builds an index from fp32 embeddings ------------------------------
  * rows fp32 [n, d] device -> L2-normalised (optional) -> element type dtype, written to out (device). */

@@ -10,9 +10,14 @@ w = E.synthetic_weights(cfg, seed=0)
 ids, mask = E.synthetic_tokens(cfg, b, l, seed=1)
 enc = QuestionEncoder(w, cfg, max_tokens=b * l)
 ids_t, mask_t = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
-for _ in range(3): enc.forward(ids_t, mask_t)
+packed = os.environ.get("ENC_PACK", "0") == "1"   # ENC_PACK=1: sequence packing (only the real tokens of the ragged batch)
+real = int(mask.sum()) if packed else 0
+for _ in range(3): enc.forward(ids_t, mask_t, real_tokens=real)
 torch.cuda.synchronize(); t0 = time.perf_counter()
-for _ in range(10): enc.forward(ids_t, mask_t)
+for _ in range(10): enc.forward(ids_t, mask_t, real_tokens=real)
 torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 10 * 1e3
-flops = b * l * 12 * (2 * (768 * 2304 + 768 * 768 + 2 * 768 * 3072) + 4 * l * 768)
-print(f"encoder B={b} L={l}: {ms:.3f} ms, {flops / ms / 1e9:.0f} TFLOP/s")
+rows = real if packed else b * l
+lens = mask.sum(1).astype(np.float64)
+att = float((lens * lens).sum()) if packed else float(b * l * l)
+flops = 12 * (rows * 2 * (768 * 2304 + 768 * 768 + 2 * 768 * 3072) + att * 4 * 768)
+print(f"encoder B={b} L={l} ({'packed: ' + str(real) + ' real tokens' if packed else 'padded'}): {ms:.3f} ms, {flops / ms / 1e9:.0f} TFLOP/s of computed rows")

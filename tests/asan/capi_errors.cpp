@@ -90,7 +90,7 @@ int main() {
     EXPECT(rc != VQA_OK && enc == nullptr);
     vqa_encoder_destroy(nullptr);
     int32_t tok[4] = {0, 1, 2, 3};
-    EXPECT(vqa_encoder_forward(nullptr, tok, tok, 1, 4, VQA_POOL_CLS, 1, s, nullptr) == VQA_EINVAL);
+    EXPECT(vqa_encoder_forward(nullptr, tok, tok, 1, 4, 0, VQA_POOL_CLS, 1, s, nullptr) == VQA_EINVAL);
     EXPECT(vqa_normalize_convert(nullptr, 1, 4, 1, VQA_F16, s, nullptr) == VQA_EINVAL);
     EXPECT(vqa_normalize_convert(s, -1, 4, 1, VQA_F16, s, nullptr) == VQA_EINVAL);
     EXPECT(vqa_normalize_convert(s, 1, 4, 1, 9, s, nullptr) == VQA_EINVAL);

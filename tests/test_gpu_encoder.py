@@ -121,3 +121,41 @@ def test_encoder_feeds_retrieval(native_lib):
     _, ref_ids, _ = R.search(R.l2_normalize(ref_q).astype(np.float16).astype(np.float32), x16, 1, dtype=R.DTYPE_F16, id_base=1)
     assert [r[0][0] for r in res] == ref_ids[:, 0].tolist() == list(range(1, 49))
     enc.close()
+
+
+def test_sequence_packing_matches_the_padded_form(native_lib):
+    """Ragged batch (8-32 real tokens of 32): with a right-padded mask only the real tokens are computed (sequence packing,
+    include/vqa_retrieval.h: real_tokens); the pooled vectors equal the padded computation's and the fp64 oracle's."""
+    from vietnamese_qa_system_amd.encoder import QuestionEncoder
+    cfg = dict(E.PHOBERT_BASE, layers=2)
+    w = E.synthetic_weights(cfg, seed=5, layers=2)
+    b, l = 192, 32  # 6144 positions: above the graph threshold, so the packed path runs
+    ids, mask = E.synthetic_tokens(cfg, b, l, seed=21)
+    assert 0.4 < mask.mean() < 0.9 and mask[:, 0].all()
+    enc = QuestionEncoder(w, cfg, max_tokens=b * l)
+    ids_d, mask_d = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+    for pooling in ("cls", "mean"):
+        padded = enc.forward(ids_d, mask_d, pooling=pooling).cpu().numpy()            # device mask, no count: every position
+        packed = enc.forward(ids, mask, pooling=pooling).cpu().numpy()                # host mask: counted and packed
+        explicit = enc.forward(ids_d, mask_d, pooling=pooling, real_tokens=int(mask.sum())).cpu().numpy()
+        assert np.abs(packed - padded).max() < 1e-6 and np.array_equal(packed, explicit)
+        ref = E.encode(w, cfg, ids[:6], mask[:6], pooling=pooling)
+        assert _cos(packed[:6], ref).min() > 0.999
+    # a mask with a hole is not right-padded: host-side masks fall back to the padded form ...
+    holed = mask.copy()
+    holed[3, 2] = 0
+    got = enc.forward(ids, holed, pooling="mean").cpu().numpy()
+    ref = E.encode(w, cfg, ids[3:4], holed[3:4], pooling="mean")
+    assert _cos(got[3:4], ref).min() > 0.999
+    # ... and announcing it as packable is caught on the device and reported by the next call
+    enc.forward(ids_d, torch.from_numpy(holed).cuda(), pooling="mean", real_tokens=int(holed.sum()))
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="right-padded"):
+        enc.forward(ids, mask)
+    enc.forward(ids, mask)  # the flag was consumed
+    # too few tokens announced: also caught
+    enc.forward(ids_d, mask_d, real_tokens=int(mask.sum()) - 5)
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="announced"):
+        enc.forward(ids, mask)
+    enc.close()

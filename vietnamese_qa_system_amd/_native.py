@@ -98,7 +98,7 @@ def load() -> ctypes.CDLL:
                                        c.POINTER(EncoderWeights), c.c_int32]
     lib.vqa_encoder_destroy.argtypes = [c.c_void_p]
     lib.vqa_encoder_destroy.restype = None
-    lib.vqa_encoder_forward.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int32, c.c_int32, c.c_int32, c.c_int32,
+    lib.vqa_encoder_forward.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int32, c.c_int32, c.c_int32, c.c_int32, c.c_int32,
                                         c.c_void_p, c.c_void_p]
     lib.vqa_normalize_convert.argtypes = [c.c_void_p, c.c_int64, c.c_int32, c.c_int32, c.c_int32, c.c_void_p, c.c_void_p]
     for name in EXPORTS:

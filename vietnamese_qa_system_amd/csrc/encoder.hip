@@ -80,18 +80,75 @@ __device__ __forceinline__ void row_layer_norm(float (&x)[kChunks][8], int H, in
     }
 }
 
+// ---- sequence packing (round 2): a ragged batch (questions of 8-32 tokens padded to L) spends a third of every GEMM on padding
+// rows.  With right-padded masks the real tokens of sequence b are l = 0 .. n_b - 1; they are stored at packed rows
+// cu[b] + l and every kernel below takes its per-sequence length from cu (cu == nullptr: the padded [B, L] layout).
+// Padding keys carry exactly zero attention weight in the padded form (HF adds finfo.min), so the real tokens' results are
+// identical.  One workgroup: per-sequence counts -> exclusive scan -> cu[0 .. B], row_seq[packed row] = b.  A mask that is not
+// right-padded, or more real tokens than the caller announced, raises the host-visible flag (the next forward fails).
+__global__ __launch_bounds__(256) void pack_kernel(const int* __restrict__ mask, int B, int L, int announced, int* __restrict__ cu,
+                                                   int* __restrict__ row_seq, int* __restrict__ bad) {
+    __shared__ int part[256];
+    const int tid = threadIdx.x;
+    const int per = (B + 255) / 256, b0 = tid * per, b1 = b0 + per < B ? b0 + per : B;
+    int sum = 0;
+    bool ragged_ok = true;
+    for (int b = b0; b < b1; ++b) {
+        int n = 0;
+        for (int l = 0; l < L; ++l) {
+            const int m = mask[b * L + l] != 0;
+            ragged_ok &= !(m && n != l);  // a real token after a padding one
+            n += m;
+        }
+        ragged_ok &= n >= 1;
+        sum += n;
+    }
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; ++i) {
+            const int v = part[i];
+            part[i] = run;
+            run += v;
+        }
+        cu[B] = run;
+        if (run > announced) __hip_atomic_store(bad, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    if (!ragged_ok) __hip_atomic_store(bad, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    int off = part[tid];
+    for (int b = b0; b < b1; ++b) {
+        cu[b] = off;
+        int n = 0;
+        for (int l = 0; l < L; ++l) n += mask[b * L + l] != 0;
+        for (int l = 0; l < n; ++l)
+            if (off + l < announced) row_seq[off + l] = b;
+        off += n;
+    }
+}
+
 __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ ids, int T, int L, int H, int pad_id, int vocab,
-                                                       int* __restrict__ bad_ids, const float* __restrict__ word,
+                                                       int* __restrict__ bad_ids, const int* __restrict__ cu,
+                                                       const int* __restrict__ row_seq, int B, const float* __restrict__ word,
                                                        const float* __restrict__ pos,
                                                        const float* __restrict__ type0, const float* __restrict__ g,
                                                        const float* __restrict__ b, float eps, _Float16* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
-    const int seq = t / L, l = t - seq * L;
+    int seq, l;
+    if (cu) {  // packed rows: t = cu[seq] + l
+        if (t >= cu[B]) return;
+        seq = row_seq[t];
+        l = t - cu[seq];
+    } else {
+        seq = t / L;
+        l = t - seq * L;
+    }
     // a token id outside the embedding table (tokenizer / vocabulary mismatch) must not become an out-of-bounds read:
     // it is embedded as the pad token and reported through the host-visible flag (checked by the next forward call)
-    const int id_raw = ids[t];
+    const int id_raw = ids[seq * L + l];
     const int id = (unsigned)id_raw < (unsigned)vocab ? id_raw : pad_id;
     if (id != id_raw && lane == 0) __hip_atomic_store(bad_ids, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // RoBERTa position id: pad + (number of non-pad tokens up to and including this one), pad tokens keep pad
@@ -719,7 +776,8 @@ constexpr int kAttMaxBlocks = 8;  // L <= 256
 
 template <int NQB>
 __global__ __launch_bounds__(64 * NQB) void attention_mfma_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ mask,
-                                                                   int L, int H, int heads, _Float16* __restrict__ ctx) {
+                                                                   int Lmax, int H, int heads, const int* __restrict__ cu,
+                                                                   _Float16* __restrict__ ctx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = NQB * 32;
     constexpr int kVtStride = Lp + 8;  // halves per dim row (+16 B so that consecutive dims start on different banks)
@@ -728,7 +786,10 @@ __global__ __launch_bounds__(64 * NQB) void attention_mfma_kernel(const _Float16
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
     const size_t row_stride = (size_t)3 * H;
-    const _Float16* base = qkv + (size_t)seq * L * row_stride + head * kAttDh;
+    // packed rows: the sequence owns rows [cu[seq], cu[seq + 1]) and every one of them is a real token
+    const size_t row0 = cu ? (size_t)cu[seq] : (size_t)seq * Lmax;
+    const int L = cu ? cu[seq + 1] - cu[seq] : Lmax;
+    const _Float16* base = qkv + row0 * row_stride + head * kAttDh;
     // V -> LDS, transposed (keys beyond L are zero)
     for (int i = tid; i < Lp * 8; i += 64 * NQB) {
         const int key = i >> 3, ch = i & 7;
@@ -756,7 +817,7 @@ __global__ __launch_bounds__(64 * NQB) void attention_mfma_kernel(const _Float16
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], acc, 0, 0, 0);
         }
         // key validity of this block as a wave-uniform bit mask (bit = key index inside the block)
-        const int valid = key < L && mask[seq * L + (key < L ? key : 0)] != 0;
+        const int valid = key < L && (cu != nullptr || mask[seq * Lmax + (key < L ? key : 0)] != 0);
         const unsigned long long bal = __ballot(valid);
         const unsigned int kmask = (unsigned int)(bal & 0xFFFFFFFFull);
 #pragma unroll
@@ -806,18 +867,20 @@ __global__ __launch_bounds__(64 * NQB) void attention_mfma_kernel(const _Float16
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int q = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (q < L) ctx[((size_t)seq * L + q) * H + head * kAttDh + db * 32 + li] = (_Float16)o[db][r];
+            if (q < L) ctx[(row0 + q) * H + head * kAttDh + db * 32 + li] = (_Float16)o[db][r];
         }
 }
 
 constexpr int kMaxPer = 32;  // hidden <= 2048 (pooling keeps element j = lane + 64 i per lane)
 
 __global__ __launch_bounds__(256) void pool_normalize_kernel(const _Float16* __restrict__ hidden, const int* __restrict__ mask,
-                                                             int B, int L, int H, int pooling, int normalize,
-                                                             float* __restrict__ out) {
+                                                             int B, int Lmax, int H, int pooling, int normalize,
+                                                             const int* __restrict__ cu, float* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (seq >= B) return;
+    const size_t row0 = cu ? (size_t)cu[seq] : (size_t)seq * Lmax;
+    const int L = cu ? cu[seq + 1] - cu[seq] : Lmax;
     float x[kMaxPer];
 #pragma unroll
     for (int i = 0; i < kMaxPer; ++i) x[i] = 0.f;
@@ -825,17 +888,17 @@ __global__ __launch_bounds__(256) void pool_normalize_kernel(const _Float16* __r
 #pragma unroll
         for (int i = 0; i < kMaxPer; ++i) {
             const int j = lane + 64 * i;
-            if (j < H) x[i] = (float)hidden[(size_t)seq * L * H + j];
+            if (j < H) x[i] = (float)hidden[row0 * H + j];
         }
     } else {
         int cnt = 0;
         for (int l = 0; l < L; ++l) {
-            if (!mask[seq * L + l]) continue;
+            if (!cu && !mask[seq * Lmax + l]) continue;
             ++cnt;
 #pragma unroll
             for (int i = 0; i < kMaxPer; ++i) {
                 const int j = lane + 64 * i;
-                if (j < H) x[i] += (float)hidden[((size_t)seq * L + l) * H + j];
+                if (j < H) x[i] += (float)hidden[(row0 + l) * H + j];
             }
         }
         const float inv = 1.0f / fmaxf((float)cnt, 1e-9f);
@@ -876,6 +939,7 @@ struct vqa_encoder {
     _Float16 *x = nullptr, *qkv = nullptr, *ctx = nullptr, *tmp = nullptr, *ffn = nullptr;
     // small batches are launch-bound (12 layers x 7 kernels of a few microseconds each): their launch sequence is captured
     // once per (B, L, pooling, normalize) into a hipGraph over these fixed staging buffers and replayed
+    int32_t *cu = nullptr, *row_seq = nullptr;    // sequence packing: [max_tokens + 1] row offsets, [max_tokens] packed row -> sequence
     int32_t *g_ids = nullptr, *g_mask = nullptr;  // [max_tokens]
     float* g_out = nullptr;                       // [max_tokens, hidden] (B <= max_tokens)
     struct Graph {
@@ -1144,6 +1208,8 @@ extern "C" int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encod
         if ((rc = dev_alloc(e, (void**)&e->ctx, T * H * 2)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->tmp, T * H * 2)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->ffn, T * F * 2)) != VQA_OK) break;
+        if ((rc = dev_alloc(e, (void**)&e->cu, ((size_t)max_tokens + 1) * 4)) != VQA_OK) break;
+        if ((rc = dev_alloc(e, (void**)&e->row_seq, (size_t)max_tokens * 4)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->g_ids, (size_t)max_tokens * 4)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->g_mask, (size_t)max_tokens * 4)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->g_out, (size_t)max_tokens * H * 4)) != VQA_OK) break;
@@ -1184,12 +1250,20 @@ static void launch_ln(const _Float16* a, int T, int H, const float* g, const flo
 
 // the launch sequence of one forward pass (no validation, no allocation, no synchronisation: capturable)
 static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L,
-                          int32_t pooling, int32_t normalize, float* out, hipStream_t s) {
-    const int T = B * L, H = e->cfg.hidden, F = e->cfg.ffn, heads = e->cfg.heads, dh = H / heads;
+                          int32_t real_tokens, int32_t pooling, int32_t normalize, float* out, hipStream_t s) {
+    const int H = e->cfg.hidden, F = e->cfg.ffn, heads = e->cfg.heads, dh = H / heads;
+    // real_tokens > 0: the caller states how many mask entries are set (right-padded masks): only those rows are computed
+    const bool packed = real_tokens > 0 && real_tokens < B * L && dh == kAttDh && L <= 32 * kAttMaxBlocks;
+    const int T = packed ? real_tokens : B * L;  // activation rows
+    const int* cu = packed ? e->cu : nullptr;
     const float eps = e->cfg.ln_eps;
     const int row_blocks = (T + 3) / 4;
+    if (packed) {
+        hipLaunchKernelGGL(pack_kernel, dim3(1), dim3(256), 0, s, attn_mask, B, L, real_tokens, e->cu, e->row_seq, e->bad_ids_dev);
+        VQA_HIP_CHECK(hipGetLastError());
+    }
     hipLaunchKernelGGL(embed_ln_kernel, dim3(row_blocks), dim3(256), 0, s, input_ids, T, L, H, e->cfg.pad_id, e->cfg.vocab_size,
-                       e->bad_ids_dev, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x);
+                       e->bad_ids_dev, cu, e->row_seq, B, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x);
     VQA_HIP_CHECK(hipGetLastError());
     const size_t attn_lds = ((size_t)2 * L * (dh + 1) + 4 * L + 4 * dh) * sizeof(float);
     VQA_REQUIRE(attn_lds <= 160 * 1024, "vqa_encoder_forward: L=%d with head size %d needs %zu bytes of LDS", L, dh, attn_lds);
@@ -1205,7 +1279,7 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
 #define VQA_ATT(NQB)                                                                                                   \
     case NQB:                                                                                                          \
         hipLaunchKernelGGL(attention_mfma_kernel<NQB>, dim3(B * heads), dim3(64 * NQB), lds, s, e->qkv, attn_mask, L, H, heads, \
-                           e->ctx);                                                                                   \
+                           cu, e->ctx);                                                                               \
         break;
             switch (nqb) {
                 VQA_ATT(1) VQA_ATT(2) VQA_ATT(3) VQA_ATT(4) VQA_ATT(5) VQA_ATT(6) VQA_ATT(7) VQA_ATT(8)
@@ -1224,13 +1298,13 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
         launch_ln(e->tmp, T, H, Ly.ln2_g, Ly.ln2_b, eps, e->x, s);
         VQA_HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(pool_normalize_kernel, dim3((B + 3) / 4), dim3(256), 0, s, e->x, attn_mask, B, L, H, pooling, normalize, out);
+    hipLaunchKernelGGL(pool_normalize_kernel, dim3((B + 3) / 4), dim3(256), 0, s, e->x, attn_mask, B, L, H, pooling, normalize, cu, out);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }
 
 extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L,
-                                   int32_t pooling, int32_t normalize, float* out, void* hip_stream) {
+                                   int32_t real_tokens, int32_t pooling, int32_t normalize, float* out, void* hip_stream) {
     VQA_REQUIRE(e, "vqa_encoder_forward: encoder is null");
     VQA_REQUIRE(input_ids && attn_mask && out, "vqa_encoder_forward: null pointer");
     VQA_REQUIRE(B >= 1 && L >= 1, "vqa_encoder_forward: B=%d L=%d", B, L);
@@ -1239,6 +1313,8 @@ extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, con
     VQA_REQUIRE(L + e->cfg.pad_id + 1 <= e->cfg.max_pos, "vqa_encoder_forward: L=%d needs position %d, the table has %d rows", L,
                 L + e->cfg.pad_id, e->cfg.max_pos);
     VQA_REQUIRE(pooling == VQA_POOL_CLS || pooling == VQA_POOL_MEAN, "vqa_encoder_forward: pooling %d", pooling);
+    VQA_REQUIRE(real_tokens >= 0 && (long long)real_tokens <= (long long)B * L, "vqa_encoder_forward: real_tokens=%d outside [0, B*L=%lld]",
+                real_tokens, (long long)B * L);
     hipStream_t s = (hipStream_t)hip_stream;
     struct Busy {  // the handle's staging buffers, activations and graphs are shared: a second concurrent call is refused
         std::atomic_flag& f;
@@ -1251,8 +1327,9 @@ extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, con
     VQA_REQUIRE(busy.ok, "vqa_encoder_forward: this encoder handle is in use by another host thread (one forward at a time per handle)");
     if (__atomic_load_n(e->bad_ids_host, __ATOMIC_RELAXED)) {
         __atomic_store_n(e->bad_ids_host, 0, __ATOMIC_RELAXED);
-        vqa_set_error("vqa_encoder_forward: an earlier forward on this handle saw token ids outside [0, %d); they were embedded as the "
-                      "pad token (tokenizer / vocabulary mismatch?)", e->cfg.vocab_size);
+        vqa_set_error("vqa_encoder_forward: an earlier forward on this handle saw token ids outside [0, %d) (embedded as the pad token: "
+                      "tokenizer / vocabulary mismatch?) or a packed call whose mask was not right-padded / held more real tokens than "
+                      "announced (its output is invalid)", e->cfg.vocab_size);
         return VQA_EINVAL;
     }
     DevGuard guard(e->device);
@@ -1262,13 +1339,14 @@ extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, con
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);
     if (!e->use_graphs || T > 4096 || cap != hipStreamCaptureStatusNone)
-        return encoder_launch(e, input_ids, attn_mask, B, L, pooling, normalize, out, s);
+        return encoder_launch(e, input_ids, attn_mask, B, L, real_tokens, pooling, normalize, out, s);
+    // (launch-bound sizes replay a graph of the padded form: a graph is keyed by shape, a packed row count is not one)
     vqa_encoder::Graph* gr = nullptr;
     for (auto& c : e->graphs)
         if (c.B == B && c.L == L && c.pooling == pooling && c.normalize == normalize) gr = &c;
     if (!gr) {  // first call of this shape: eager (sets the kernels' attributes), remembered -- up to 64 shapes, then eager only
         if (e->graphs.size() < 64) e->graphs.push_back({B, L, pooling, normalize, nullptr, true});
-        return encoder_launch(e, input_ids, attn_mask, B, L, pooling, normalize, out, s);
+        return encoder_launch(e, input_ids, attn_mask, B, L, 0, pooling, normalize, out, s);
     }
     const size_t H = e->cfg.hidden;
     VQA_HIP_CHECK(hipMemcpyAsync(e->g_ids, input_ids, (size_t)T * 4, hipMemcpyDeviceToDevice, s));
@@ -1276,7 +1354,7 @@ extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, con
     if (!gr->exec) {
         hipGraph_t graph = nullptr;
         VQA_HIP_CHECK(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
-        const int rc = encoder_launch(e, e->g_ids, e->g_mask, B, L, pooling, normalize, e->g_out, e->cap_stream);
+        const int rc = encoder_launch(e, e->g_ids, e->g_mask, B, L, 0, pooling, normalize, e->g_out, e->cap_stream);
         const hipError_t end = hipStreamEndCapture(e->cap_stream, &graph);
         if (rc != VQA_OK) {
             if (graph) (void)hipGraphDestroy(graph);

@@ -102,8 +102,13 @@ class QuestionEncoder:
         except Exception:
             pass
 
-    def forward(self, input_ids, attention_mask, *, pooling: str = "cls", normalize: bool = True) -> torch.Tensor:
-        """``input_ids`` / ``attention_mask`` [B, L] integers -> [B, hidden] fp32 cuda tensor (pooled, L2-normalised)."""
+    def forward(self, input_ids, attention_mask, *, pooling: str = "cls", normalize: bool = True,
+                real_tokens: Optional[int] = None) -> torch.Tensor:
+        """``input_ids`` / ``attention_mask`` [B, L] integers -> [B, hidden] fp32 cuda tensor (pooled, L2-normalised).
+
+        Ragged batches: with a right-padded mask only the real tokens are computed (sequence packing inside the library).
+        Host-side masks (what a tokenizer returns) are checked and counted here; for a device-resident mask pass
+        ``real_tokens`` = its number of set entries (``0`` / ``None``: compute every position)."""
         if not self._handle.value:
             raise RuntimeError("encoder is closed")
         if pooling not in POOLING:
@@ -120,14 +125,21 @@ class QuestionEncoder:
             if lo < 0 or hi >= int(self.config["vocab_size"]):
                 raise ValueError(f"token ids span [{lo}, {hi}] but the embedding table has {self.config['vocab_size']} rows "
                                  "(tokenizer / vocabulary mismatch?)")
+        if real_tokens is None:
+            real_tokens = 0
+            if not mask.is_cuda and mask.numel():
+                m = mask != 0
+                right_padded = bool(m[:, 0].all()) and bool((m[:, :-1] >= m[:, 1:]).all())
+                real_tokens = int(m.sum()) if right_padded else 0
         ids = ids.to(dev, dtype=torch.int32).contiguous()
         mask = mask.to(dev, dtype=torch.int32).contiguous()
         b, l = int(ids.shape[0]), int(ids.shape[1])
         with torch.cuda.device(dev):
             out = torch.empty((b, int(self.config["hidden"])), dtype=torch.float32, device=dev)
             stream = torch.cuda.current_stream(dev).cuda_stream
-            N.check(self._lib.vqa_encoder_forward(self._handle, ids.data_ptr(), mask.data_ptr(), b, l, POOLING[pooling],
-                                                  int(bool(normalize)), out.data_ptr(), stream), "vqa_encoder_forward")
+            N.check(self._lib.vqa_encoder_forward(self._handle, ids.data_ptr(), mask.data_ptr(), b, l, int(real_tokens),
+                                                  POOLING[pooling], int(bool(normalize)), out.data_ptr(), stream),
+                    "vqa_encoder_forward")
         return out
 
     __call__ = forward
