@@ -105,19 +105,18 @@ __global__ __launch_bounds__(256) void pack_kernel(const int* __restrict__ mask,
     }
     part[tid] = sum;
     __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int i = 0; i < 256; ++i) {
-            const int v = part[i];
-            part[i] = run;
-            run += v;
-        }
-        cu[B] = run;
-        if (run > announced) __hip_atomic_store(bad, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int step = 1; step < 256; step <<= 1) {  // inclusive scan of the 256 partial sums
+        const int add = tid >= step ? part[tid - step] : 0;
+        __syncthreads();
+        part[tid] += add;
+        __syncthreads();
     }
-    __syncthreads();
+    if (tid == 255) {
+        cu[B] = part[255];
+        if (part[255] > announced) __hip_atomic_store(bad, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (!ragged_ok) __hip_atomic_store(bad, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    int off = part[tid];
+    int off = part[tid] - sum;  // exclusive
     for (int b = b0; b < b1; ++b) {
         cu[b] = off;
         int n = 0;
