@@ -85,6 +85,13 @@ def main():
     # the txtai-shaped call returns the same thing on every rank
     res = emb.batchsearch(q16[:4].astype(np.float32), 5)
     assert [r[0] for r in res[0][:3]] == dup
+    # 1b. pipelined batches: the all-gather of batch i runs under the scan of batch i + 1; results equal per-batch search
+    batches = [q, q[:5], torch.from_numpy(unit(rng, 64, d)).to(device), q]
+    want = [tuple(t.clone() for t in emb._searcher.search(bq, k)) for bq in batches]
+    got = emb._searcher.search_pipelined(batches, k)
+    torch.cuda.synchronize()
+    assert len(got) == len(want) and all(torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) for g, w in zip(got, want))
+    checks.append("pipelined")
     # 2. k > 12 (one-pass wide search per shard + merge of R * k candidates)
     compare("k=300", emb, q, 300, single(x, ids, q, 300))
     # 3. sharded save (every rank writes its byte range) -> load (every rank reads its byte range)

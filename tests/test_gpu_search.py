@@ -149,13 +149,13 @@ def test_sharded_searcher_packs_one_gather_buffer(native_lib):
     ids = rng.integers(0, 1 << 40, size=(world, b, k)).astype(np.int64)
     s = ShardedSearcher(lambda *a: None, merge_topk)
     s.world = world
-    send_s, send_i, recv_s, recv_i = s._buffers(b, k, torch.device("cuda", 0))
-    assert s._send.numel() % 8 == 0 and s._recv.shape == (world, s._send.numel())
+    send, recv, (send_s, send_i, recv_s, recv_i) = s._buffers(b, k, torch.device("cuda", 0))
+    assert send.numel() % 8 == 0 and recv.shape == (world, send.numel())
     assert not recv_s.is_contiguous() and recv_s.shape == (world, b, k) and recv_i.shape == (world, b, k)
     for r in range(world):  # what all_gather_into_tensor delivers: rank r's send buffer in row r
         send_s.copy_(torch.from_numpy(sc[r]))
         send_i.copy_(torch.from_numpy(ids[r]))
-        s._recv[r].copy_(s._send)
+        recv[r].copy_(send)
     gs, gi = merge_topk(recv_s, recv_i, k)
     es, ei = R.merge_shards(sc, ids, k)
     assert np.array_equal(gs.cpu().numpy(), es) and np.array_equal(gi.cpu().numpy(), ei)
@@ -166,6 +166,8 @@ def test_sharded_searcher_packs_one_gather_buffer(native_lib):
     s1, i1 = one.search(torch.from_numpy(q).cuda(), 10)
     s2, i2, _ = ix.search(torch.from_numpy(q).cuda(), 10)
     assert torch.equal(s1, s2) and torch.equal(i1, i2)
+    piped = one.search_pipelined([torch.from_numpy(q).cuda(), torch.from_numpy(q[:4]).cuda()], 10)
+    assert torch.equal(piped[0][0], s2) and torch.equal(piped[1][1], i2[:4])
     ix.close()
 
 

@@ -15,7 +15,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-EXPECTED = {"id-vector", "k=300", "save-load", "local-slice", "producer", "short-shard", "short-shard-k12", "string-ids", "reindex"}
+EXPECTED = {"id-vector", "pipelined", "k=300", "save-load", "local-slice", "producer", "short-shard", "short-shard-k12", "string-ids", "reindex"}
 
 
 def _free_port() -> int:

@@ -50,6 +50,10 @@ def _worker(rank, world, port, out_dir):
     s, i = searcher.search(torch.from_numpy(q), k)
     s2, i2 = searcher.search(torch.from_numpy(q), k)  # buffers are reused across calls
     assert torch.equal(i, i2) and torch.equal(s, s2)
+    # pipelined batches (asynchronous all-gather of batch n under the shard search of batch n + 1): same results
+    tq = torch.from_numpy(q)
+    piped = searcher.search_pipelined([tq, tq[:3], tq], k)
+    assert len(piped) == 3 and torch.equal(piped[0][1], i) and torch.equal(piped[2][0], s) and torch.equal(piped[1][1], i[:3])
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), s=s.numpy(), i=i.numpy())
     dist.destroy_process_group()
 

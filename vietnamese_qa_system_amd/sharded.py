@@ -45,32 +45,58 @@ class ShardedSearcher:
         self.merge = merge
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self._key = None
-        self._send = self._recv = None
-        self._views = None
+        self._slots = {}  # (B, k, device, slot) -> (send, recv, (send_s, send_i, recv_s, recv_i))
 
-    def _buffers(self, b: int, k: int, device: torch.device):
-        key = (b, k, device)
-        if self._key != key:
+    def _buffers(self, b: int, k: int, device: torch.device, slot: int = 0):
+        key = (b, k, device, slot)
+        if key not in self._slots:
+            if len(self._slots) >= 8:
+                self._slots.clear()
             row = (12 * b * k + 7) // 8 * 8  # bytes per rank: ids [B, k] int64, scores [B, k] float32, pad to 8
-            self._send = torch.zeros((row,), dtype=torch.uint8, device=device)
-            self._recv = torch.zeros((self.world, row), dtype=torch.uint8, device=device)
+            send = torch.zeros((row,), dtype=torch.uint8, device=device)
+            recv = torch.zeros((self.world, row), dtype=torch.uint8, device=device)
             n = b * k
-            send_i = self._send[:8 * n].view(torch.int64).view(b, k)
-            send_s = self._send[8 * n:12 * n].view(torch.float32).view(b, k)
-            recv_i = self._recv[:, :8 * n].view(torch.int64).unflatten(1, (b, k))
-            recv_s = self._recv[:, 8 * n:12 * n].view(torch.float32).unflatten(1, (b, k))
-            self._views = (send_s, send_i, recv_s, recv_i)
-            self._key = key
-        return self._views
+            send_i = send[:8 * n].view(torch.int64).view(b, k)
+            send_s = send[8 * n:12 * n].view(torch.float32).view(b, k)
+            recv_i = recv[:, :8 * n].view(torch.int64).unflatten(1, (b, k))
+            recv_s = recv[:, 8 * n:12 * n].view(torch.float32).unflatten(1, (b, k))
+            self._slots[key] = (send, recv, (send_s, send_i, recv_s, recv_i))
+        return self._slots[key]
 
     def search(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
         b = int(queries.shape[0])
-        send_s, send_i, recv_s, recv_i = self._buffers(b, k, self._device(queries))
+        send, recv, (send_s, send_i, recv_s, recv_i) = self._buffers(b, k, self._device(queries))
         self.local_search(queries, k, send_s, send_i)
         if self.world == 1:
             return send_s.clone(), send_i.clone()
-        dist.all_gather_into_tensor(self._recv.view(-1), self._send, group=self.group)  # the one exchange step
+        dist.all_gather_into_tensor(recv.view(-1), send, group=self.group)  # the one exchange step
+        return self.merge(recv_s, recv_i, k)
+
+    def search_pipelined(self, batches, k: int):
+        """Several query batches back to back with the exchange of batch i hidden under the scan of batch i + 1 (SURVEY.md
+        section 8e): the all-gather is issued asynchronously (RCCL runs it on its own stream behind the scan that produced
+        the send buffer), the next batch's scan is enqueued at once, and only then does the compute stream wait for the
+        gather and merge batch i.  Two buffer slots alternate.  Returns ``[(scores, ids), ...]`` in batch order, identical
+        to calling :meth:`search` per batch."""
+        results, pending = [], None
+        for n, queries in enumerate(batches):
+            b = int(queries.shape[0])
+            send, recv, (send_s, send_i, recv_s, recv_i) = self._buffers(b, k, self._device(queries), slot=n & 1)
+            self.local_search(queries, k, send_s, send_i)
+            work = None
+            if self.world > 1:
+                work = dist.all_gather_into_tensor(recv.view(-1), send, group=self.group, async_op=True)
+            if pending is not None:
+                results.append(self._finish(*pending, k))
+            pending = (work, send_s, send_i, recv_s, recv_i)
+        if pending is not None:
+            results.append(self._finish(*pending, k))
+        return results
+
+    def _finish(self, work, send_s, send_i, recv_s, recv_i, k):
+        if work is None:
+            return send_s.clone(), send_i.clone()
+        work.wait()  # the compute stream waits for the gather; the host does not block on RCCL
         return self.merge(recv_s, recv_i, k)
 
     def _device(self, queries: torch.Tensor) -> torch.device:
