@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VQA_VERSION 101 /* 0.1.1: vqa_encoder_forward takes real_tokens, vqa_launch_info.seed_tiles */
+#define VQA_VERSION 102 /* 0.1.2: vqa_encoder_forward takes real_tokens; vqa_launch_info.seed_tiles, .first_stage_rows */
 
 /* error codes */
 #define VQA_OK 0
@@ -110,12 +110,14 @@ typedef struct vqa_launch_info {
     int32_t block;         /* threads per workgroup */
     int32_t lds_bytes;     /* dynamic LDS per workgroup */
     int32_t rows_per_tile; /* corpus rows scored per workgroup iteration */
-    int64_t rows_per_launch;  /* corpus rows the MAIN scoring kernel covers: every row of the shard (the seeding pass scores
+    int64_t rows_per_launch;  /* corpus rows the MAIN scoring kernel launch covers: n - first_stage_rows (the seeding pass scores
                                * its seed_tiles * rows_per_tile rows once more, in a launch of its own) */
     int64_t bytes_per_launch; /* algorithmic bytes of that launch: rows_per_launch * d * sizeof(element) */
     int64_t flops_per_launch; /* 2 * VQA_QUERY_TILE * rows_per_launch * d */
     int32_t seed_grid;        /* workgroups of the seeding pass (a few tiles each), 0 when the search is single pass */
     int32_t seed_tiles;       /* tiles of rows_per_tile rows the seeding pass scores */
+    int64_t first_stage_rows; /* large shards, k <= VQA_MAX_K: rows scored by the first-stage launch of the same kernel (its exact
+                               * k-th best scores seed the main launch's thresholds); 0 = the main launch covers every row */
 } vqa_launch_info;
 int vqa_index_launch_info(const vqa_index* index, int32_t B, int32_t k, vqa_launch_info* out);
 int vqa_index_set_timing(vqa_index* index, int32_t enabled);

@@ -1,7 +1,7 @@
 """Copy what is to be judged from gpurun_out/<tag>/ (scratch, written by scripts/profile_round.sh on the GPU box) into profiles/:
 <name>_kernel_stats.csv (kernel names cut to 120 characters: torch's templated names run to kilobytes), <name>_pmc_summary.json,
 <name>_bench.json; and refresh the workload's entry of profiles/traffic.json.   usage: collect_profiles.py <tag> <name>"""
-import csv, json, os, sys
+import csv, json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, name = sys.argv[1], sys.argv[2]
 src = os.path.join(ROOT, "gpurun_out", tag)
@@ -15,7 +15,7 @@ with open(os.path.join(dst, f"{name}_kernel_stats.csv"), "w", newline="") as f:
 summ = json.load(open(os.path.join(src, "pmc_summary.json")))
 bench = summ.pop("bench", None)
 if summ.get("kernel") in (None, "", "void "):
-    summ["kernel"] = next((r[0][:120] for r in rows[1:] if "score_topk_kernel<1" in r[0] or "score_topk_kernelILi1E" in r[0]), summ.get("kernel"))
+    summ["kernel"] = next((r[0][:120] for r in rows[1:] if re.search(r"score_topk_kernel<1, \d, 0>|score_topk_kernelILi1ELi\dELi0E", r[0])), summ.get("kernel"))
 json.dump(summ, open(os.path.join(dst, f"{name}_pmc_summary.json"), "w"), indent=1)
 if bench:
     json.dump(bench, open(os.path.join(dst, f"{name}_bench.json"), "w"), indent=1)

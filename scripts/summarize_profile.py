@@ -1,7 +1,7 @@
 """Condense the rocprofv3 output of scripts/profile_round.sh: per-kernel stats CSV + PMC summary of the main scoring kernel.
 HBM bytes follow MI355X_MICROARCH.md (HBM / rocprofv3 section): FETCH_SIZE and WRITE_SIZE in separate passes, KiB units,
 FETCH_SIZE doubled on gfx950 for wide coalesced streaming reads."""
-import collections, csv, glob, json, os, shutil, sys
+import re, collections, csv, glob, json, os, shutil, sys
 
 root = sys.argv[1]
 out = {}
@@ -19,7 +19,8 @@ main_name = None
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
     agg = collections.defaultdict(list)
     for r in rows(sub, "counter_collection.csv"):
-        if "score_topk_kernel" in r["Kernel_Name"] and ("<1," in r["Kernel_Name"] or "ILi1E" in r["Kernel_Name"]):
+        # the main launch: score_topk_kernel<1, DT, 0> (<1, DT, 1> is the first stage of a two-stage search, <0, ..> the seed pass)
+        if re.search(r"score_topk_kernel<1, \d, 0>|score_topk_kernelILi1ELi\dELi0E", r["Kernel_Name"]):
             main_name = r["Kernel_Name"].split("(")[0]
             agg[r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     for name, v in agg.items():

@@ -108,6 +108,32 @@ def test_two_pass_large(native_lib):
     assert R.recall_at_k(i, io) == 1.0
 
 
+@pytest.mark.parametrize("k", [1, 10, 12, 30])
+def test_two_stage_search_equals_one_stage(native_lib, monkeypatch, k):
+    """Shards of at least 40 tiles per workgroup are searched in two stages (the first 10 % of the tiles give the main launch
+    its thresholds; capi.hip plan_launch).  VQA_STAGE_MIN brings the switch-over down to a size the oracle handles: the
+    result must be the oracle's and bit-identical to the one-stage search's (VQA_STAGE_MIN=0)."""
+    from vietnamese_qa_system_amd.index import DeviceIndex
+    n, d, b = 300_001, 64, 41
+    x, q = _mk(n, d, b, seed=11)
+    x[1000:1040] = x[7]  # a run of ties that straddles nothing special in stage one ...
+    x[250_000:250_040] = x[7]  # ... and the same rows again in the main stage
+    s_full = R.full_scores(q.astype(np.float32), x, R.DTYPE_F16)
+    out = []
+    for stage_min in ("2", "0"):
+        monkeypatch.setenv("VQA_STAGE_MIN", stage_min)
+        ix = DeviceIndex(x, id_base=1, dtype="fp16", device=0)
+        info = ix.launch_info(b, k)
+        assert (info.first_stage_rows > 0) == (stage_min == "2" and k <= 12)
+        assert info.rows_per_launch == n - info.first_stage_rows
+        s, i, p = ix.search(torch.from_numpy(q).cuda(), k, return_positions=True)
+        torch.cuda.synchronize()
+        out.append((s.cpu().numpy(), p.cpu().numpy()))
+        ix.close()
+        R.check_topk(out[-1][0], out[-1][1], s_full, k, score_tol=SCORE_TOL, tie_tol=TIE_TOL)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+
+
 def test_argument_errors(native_lib):
     from vietnamese_qa_system_amd.index import DeviceIndex
     x, q = _mk(100, 64, 2, seed=0)

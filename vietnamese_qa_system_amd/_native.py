@@ -38,7 +38,7 @@ class LaunchInfo(ctypes.Structure):
     _fields_ = [("grid", ctypes.c_int32), ("block", ctypes.c_int32), ("lds_bytes", ctypes.c_int32),
                 ("rows_per_tile", ctypes.c_int32), ("rows_per_launch", ctypes.c_int64),
                 ("bytes_per_launch", ctypes.c_int64), ("flops_per_launch", ctypes.c_int64),
-                ("seed_grid", ctypes.c_int32), ("seed_tiles", ctypes.c_int32)]
+                ("seed_grid", ctypes.c_int32), ("seed_tiles", ctypes.c_int32), ("first_stage_rows", ctypes.c_int64)]
 
 
 class EncoderConfig(ctypes.Structure):

@@ -40,6 +40,9 @@ struct vqa_index {
     bool two_pass = true;
     int seed_mult = 2;  // seed pass covers seed_mult * CUs tiles (VQA_SEED_MULT = 1..4)
     int seed_div = 16;  // ... but at most 1 / seed_div of the shard's tiles (VQA_SEED_DIV: dev override, 0 = no cap)
+    int stage_min_tiles = 40;  // two-stage search when the shard has at least this many tiles per workgroup (VQA_STAGE_MIN: dev /
+                               // test override, 0 disables); the first stage takes stage_pct % of the tiles (VQA_STAGE_PCT)
+    int stage_pct = 10;
     // workspace (allocated once; search never allocates)
     void* q_stage = nullptr;     // one 256-row tile in TILED layout
     void* q_rows = nullptr;      // staging for host -> device row chunks in set_rows (lazy)
@@ -182,6 +185,10 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
     ix->wide = !(wk && wk[0] == '0');
     const char* sd = getenv("VQA_SEED_DIV");
     if (sd) ix->seed_div = atoi(sd);
+    const char* sg = getenv("VQA_STAGE_MIN");
+    if (sg) ix->stage_min_tiles = atoi(sg);
+    const char* sp = getenv("VQA_STAGE_PCT");
+    if (sp && atoi(sp) >= 1 && atoi(sp) <= 50) ix->stage_pct = atoi(sp);
     const char* sm = getenv("VQA_SEED_MULT");
     if (sm && sm[0] >= '1' && sm[0] <= '4') ix->seed_mult = sm[0] - '0';
     const int eb = elem_bytes(dtype);
@@ -285,6 +292,7 @@ struct LaunchPlan {
     int seed_tiles = 0;  // tiles of the seed pass, 0 = no seeding
     int grid0 = 0;  // its workgroups (a few tiles each)
     int grid1 = 0;  // workgroups of the main pass
+    int stage_tiles = 0;  // two-stage search (k <= 12, large shards): tiles of the FIRST stage, 0 = one stage
 };
 
 static LaunchPlan plan_launch(const vqa_index* ix) {
@@ -304,6 +312,18 @@ static LaunchPlan plan_launch(const vqa_index* ix) {
         if (div > 0 && want > p.tiles / div) want = p.tiles / div > 0 ? p.tiles / div : 1;
         p.seed_tiles = p.tiles < want ? p.tiles : want;
         p.grid0 = p.seed_tiles < ix->max_grid ? p.seed_tiles : ix->max_grid;
+        // Two stages: a workgroup only knows its own rows and the seeds, so ~5 candidates per tile pass its threshold test
+        // and the epilogue's rare path costs 4.4 % of the scan.  The first stage_pct % of the tiles are
+        // therefore scored by a launch of their own; the exact k-th best of THOSE rows (one list merge) is a 7x tighter
+        // bound than the seeds' for the main launch over the remaining tiles, and the first stage only needs seeds from
+        // half as many tiles.  Both launches flush into one array of 2 x grid lists per query for the final merge.
+        if (ix->stage_min_tiles > 0 && p.grid1 == ix->max_grid && p.tiles >= (long long)ix->stage_min_tiles * p.grid1) {
+            const int per_wg = (int)((long long)p.tiles * ix->stage_pct / 100 / p.grid1);
+            p.stage_tiles = (per_wg > 0 ? per_wg : 1) * p.grid1;
+            const int half = p.seed_tiles / 2 > 0 ? p.seed_tiles / 2 : 1;
+            p.seed_tiles = half;
+            p.grid0 = p.seed_tiles < ix->max_grid ? p.seed_tiles : ix->max_grid;
+        }
     }
     return p;
 }
@@ -316,7 +336,8 @@ extern "C" int vqa_index_launch_info(const vqa_index* ix, int32_t B, int32_t k, 
     out->block = 512;
     out->lds_bytes = vqa_score_topk_lds_bytes(ix->dtype, k);
     out->rows_per_tile = 256;
-    out->rows_per_launch = ix->n;
+    out->first_stage_rows = k <= vqa_score_topk_max_k(ix->dtype) ? (int64_t)p.stage_tiles * 256 : 0;
+    out->rows_per_launch = ix->n - out->first_stage_rows;
     out->bytes_per_launch = out->rows_per_launch * (int64_t)ix->d * elem_bytes(ix->dtype);
     out->flops_per_launch = 2 * (int64_t)VQA_QUERY_TILE * out->rows_per_launch * (int64_t)ix->d;
     out->seed_grid = p.grid0;
@@ -464,11 +485,31 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             a.tile_end = p.tiles;
             a.grid = p.grid1;
             a.seed_only = false;
+            const bool staged = p.stage_tiles > 0 && k <= max_k && p.grid0 > 0;  // one exact pass of a large shard
+            int lists = p.grid1;
+            if (staged) {
+                // first stage: tiles [0, stage_tiles) with the seeds' thresholds -> lists [0, grid) of every query's row of 2 grid
+                // lists; their merge (thresholds only) = the exact k-th best score of those rows, seeds the main launch
+                lists = 2 * p.grid1;
+                a.row_lists = lists;
+                a.list_offset = 0;
+                a.tile_end = p.stage_tiles;
+                a.first_stage = true;
+                rc = vqa_launch_score_topk(ix->dtype, a, stream);
+                if (rc != VQA_OK) return rc;
+                rc = vqa_launch_merge_partials(ix->partial, p.grid1, kk, nq, kk, nullptr, 0, nullptr, nullptr, nullptr, ix->thr0, 1.0f, kk,
+                                               0, nullptr, true, gate, stream, lists);
+                if (rc != VQA_OK) return rc;
+                a.first_stage = false;
+                a.tile_begin = p.stage_tiles;
+                a.tile_end = p.tiles;
+                a.list_offset = p.grid1;
+            }
             if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
             rc = vqa_launch_score_topk(ix->dtype, a, stream);
             if (rc != VQA_OK) return rc;
             if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
-            rc = vqa_launch_merge_partials(ix->partial, p.grid1, kk, nq, kk, ix->ids, ix->id_base, os, oi, op, nullptr,
+            rc = vqa_launch_merge_partials(ix->partial, lists, kk, nq, kk, ix->ids, ix->id_base, os, oi, op, nullptr,
                                            1.0f / (ix->scale * ix->scale), k, done, done + kk < k ? ix->upper : nullptr, true, gate,
                                            stream);
             if (rc != VQA_OK) return rc;

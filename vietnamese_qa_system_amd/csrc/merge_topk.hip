@@ -45,15 +45,15 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
                                                                        float* __restrict__ out_thr, float score_scale,
                                                                        int out_stride, int out_offset,
                                                                        vqa_key* __restrict__ out_last_key, int query_major,
-                                                                       const int* __restrict__ gate) {
+                                                                       const int* __restrict__ gate, int row_lists) {
     if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     vqa_key* keys = reinterpret_cast<vqa_key*>(smem);    // [parts * list_len]
     vqa_key* red = keys + (size_t)parts * list_len;      // [4]
     const int q = blockIdx.x;
     const int m = parts * list_len;
-    if (query_major) {
-        for (int i = threadIdx.x; i < m; i += kMergeThreads) keys[i] = partial[(size_t)q * m + i];
+    if (query_major) {  // a query's row holds row_lists lists; the first `parts` of them are merged
+        for (int i = threadIdx.x; i < m; i += kMergeThreads) keys[i] = partial[(size_t)q * row_lists * list_len + i];
     } else {
         for (int i = threadIdx.x; i < m; i += kMergeThreads) {
             const int p = i / list_len, j = i - p * list_len;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_sort_kernel(cons
                                                                             float* __restrict__ out_thr, float score_scale,
                                                                             int out_stride, int out_offset,
                                                                             vqa_key* __restrict__ out_last_key, int query_major,
-                                                                            const int* __restrict__ gate) {
+                                                                            const int* __restrict__ gate, int row_lists) {
     if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     vqa_key* keys = reinterpret_cast<vqa_key*>(smem);  // [m_pow2]
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_sort_kernel(cons
         vqa_key v = 0ull;
         if (i < m) {
             if (query_major) {
-                v = partial[(size_t)q * m + i];
+                v = partial[(size_t)q * row_lists * list_len + i];
             } else {
                 const int p = i / list_len, j = i - p * list_len;
                 v = partial[((size_t)p * VQA_QUERY_TILE + q) * list_len + j];
@@ -208,7 +208,9 @@ int vqa_launch_verify_wide(const vqa_key* partial, int32_t parts, int32_t list_l
 int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t list_len, int32_t nq, int32_t k,
                               const int64_t* ids, int64_t id_base, float* out_scores, int64_t* out_ids, int64_t* out_pos,
                               float* out_thr, float score_scale, int32_t out_stride, int32_t out_offset,
-                              vqa_key* out_last_key, bool query_major, const int* gate, hipStream_t stream) {
+                              vqa_key* out_last_key, bool query_major, const int* gate, hipStream_t stream, int32_t row_lists) {
+    if (row_lists <= 0) row_lists = parts;
+    VQA_REQUIRE(row_lists >= parts, "merge_partials: %d lists per row but %d to merge", row_lists, parts);
     VQA_REQUIRE(parts >= 1 && list_len >= 1 && nq >= 1 && nq <= VQA_QUERY_TILE && k >= 1,
                 "merge_partials: bad shape parts=%d list_len=%d nq=%d k=%d", parts, list_len, nq, k);
     const size_t lds = ((size_t)parts * list_len + 4) * sizeof(vqa_key);
@@ -230,7 +232,7 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
             hipLaunchKernelGGL(merge_partials_sort_kernel, dim3(nq), dim3(kMergeThreads), lds_sort, stream, partial, parts, list_len,
                                k, m_pow2, reinterpret_cast<const long long*>(ids), (long long)id_base, out_scores,
                                reinterpret_cast<long long*>(out_ids), reinterpret_cast<long long*>(out_pos), out_thr, score_scale,
-                               out_stride, out_offset, out_last_key, query_major ? 1 : 0, gate);
+                               out_stride, out_offset, out_last_key, query_major ? 1 : 0, gate, row_lists);
             VQA_HIP_CHECK(hipGetLastError());
             return VQA_OK;
         }
@@ -238,7 +240,7 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
     hipLaunchKernelGGL(merge_partials_kernel, dim3(nq), dim3(kMergeThreads), lds, stream, partial, parts, list_len, k,
                        reinterpret_cast<const long long*>(ids), (long long)id_base, out_scores,
                        reinterpret_cast<long long*>(out_ids), reinterpret_cast<long long*>(out_pos), out_thr, score_scale,
-                       out_stride, out_offset, out_last_key, query_major ? 1 : 0, gate);
+                       out_stride, out_offset, out_last_key, query_major ? 1 : 0, gate, row_lists);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

@@ -22,6 +22,8 @@
 //   MODE 0 "seed": a few tiles per workgroup; writes, per query and tile, two sub-maxima (valid lower bounds: each is
 //                  the score of a distinct row); K2 turns their k-th largest into starting thresholds.
 //   MODE 1 "main": all tiles, thresholds seeded; flushes per-workgroup sorted top-k lists for K2 to merge.
+//   (STAGE 1 is the same MODE 1 code under a second symbol: the first-stage launch of a two-stage search, capi.hip, so that
+//   a kernel trace keeps it apart from the main launch.)
 #include <type_traits>
 #include <utility>
 
@@ -315,12 +317,13 @@ __device__ unsigned long long g_stamps[8 * 64 * kStampSlots];
 #define VQA_STAMP_FLUSH(KT) (void)0
 #endif
 
-template <int MODE, int DT>
+template <int MODE, int DT, int STAGE = 0>
 __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __restrict__ X, const void* __restrict__ Qs,
                                                               const float* __restrict__ thr_init,
                                                               const vqa_key* __restrict__ upper,
                                                               vqa_key* __restrict__ out, long long N, int KT, int nq, int k,
-                                                              int tile_begin, int tile_end, const int* __restrict__ gate) {
+                                                              int tile_begin, int tile_end, const int* __restrict__ gate,
+                                                              int row_lists, int list_offset) {
     // gated launch (fallback passes of a large-k search, capi.hip): nothing to do when the one-pass result was verified
     if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1043,7 +1046,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     // query-major [query][workgroup][k]: K2 then reads one contiguous run per query
     for (int i = tid; i < kQ * k; i += kThreads) {
         const int q = i / k, j = i - q * k;
-        out[((size_t)q * gridDim.x + blockIdx.x) * k + j] = j < list_count(L, q) ? L.cand[q * kCap + j] : 0ull;
+        out[((size_t)q * row_lists + list_offset + blockIdx.x) * k + j] = j < list_count(L, q) ? L.cand[q * kCap + j] : 0ull;
     }
 }
 
@@ -1070,12 +1073,14 @@ static int launch_dt(const ScoreTopkArgs& a, int KT, int lds, hipStream_t stream
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<1, DT>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<1, DT, 1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         return VQA_OK;
     });
     if (rc != VQA_OK) return rc;
-    auto kern = a.seed_only ? score_topk_kernel<0, DT> : score_topk_kernel<1, DT>;
+    auto kern = a.seed_only ? score_topk_kernel<0, DT> : a.first_stage ? score_topk_kernel<1, DT, 1> : score_topk_kernel<1, DT>;
     hipLaunchKernelGGL(kern, dim3(a.grid), dim3(kThreads), lds, stream, a.x, a.q, a.thr_init, a.upper, a.partial, (long long)a.n,
-                       KT, a.nq, a.k, a.tile_begin, a.tile_end, a.gate);
+                       KT, a.nq, a.k, a.tile_begin, a.tile_end, a.gate, a.row_lists > 0 ? a.row_lists : a.grid, a.list_offset);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

@@ -80,6 +80,10 @@ struct ScoreTopkArgs {
     int32_t tile_end;     // one past the last
     int32_t grid;         // workgroups
     const int* gate = nullptr;  // device flag or nullptr: the kernel returns at once when *gate == 0
+    int32_t row_lists = 0;      // main pass flush: lists per query row of `partial` (0 = grid) ...
+    int32_t list_offset = 0;    // ... and the slot of this launch's workgroup 0 inside the row (two-stage search: the first
+                                // stage fills slots [0, grid), the main launch [grid, 2 grid) of rows of 2 grid lists)
+    bool first_stage = false;   // the first-stage launch of a two-stage search: same code, its own kernel symbol
     bool seed_only = false;  // MODE 0: writes 2 sub-maxima per query and tile to `partial` as [query][tile - tile_begin][2]
 };
 int vqa_launch_score_topk(int dtype, const ScoreTopkArgs& a, hipStream_t stream);
@@ -95,7 +99,9 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
                               int32_t out_stride /* row stride of the out arrays */, int32_t out_offset /* first column */,
                               vqa_key* out_last_key /* [nq] k-th key per query (0 when fewer exist) or nullptr */,
                               bool query_major /* lists are [query][parts][list_len] instead of [parts][256][list_len] */,
-                              const int* gate /* device flag or nullptr: no-op when *gate == 0 */, hipStream_t stream);
+                              const int* gate /* device flag or nullptr: no-op when *gate == 0 */, hipStream_t stream,
+                              int32_t row_lists = 0 /* query-major only: lists per query row in memory (>= parts; 0 = parts):
+                                                       the first `parts` lists of every row are merged */);
 // one-pass large-k check: sets *flag = 1 when some workgroup's list (list_len keys, full) ends ABOVE the query's k-th merged
 // key `kth` -- that list may have dropped a row of the true top-k (capi.hip, vqa_index_search)
 int vqa_launch_verify_wide(const vqa_key* partial, int32_t parts, int32_t list_len, int32_t nq, const vqa_key* kth, int* flag,
