@@ -397,7 +397,9 @@ def end_to_end(torch, np, searcher, device, dev_index, b, k, steps, sync, L=32):
     enc.close()
     # algorithmic flops of the REAL tokens (padding rows are not computed): GEMMs per token + attention over each sequence's own length
     lens_f = lens.double()
-    flops = int(cfg["layers"] * (real * 2 * (h * 3 * h + h * h + 2 * h * f) + float((lens_f * lens_f).sum()) * 4 * h))
+    att = float((lens_f * lens_f).sum()) * 4 * h
+    flops = int(cfg["layers"] * (real * 2 * h * 3 * h + att) + (cfg["layers"] - 1) * real * 2 * (h * h + 2 * h * f)
+                + b * 2 * (h * h + 2 * h * f))  # CLS pooling: the last layer's out-projection + FFN run on the B first rows only
     enc_med = float(np.median(enc_ms))
     return {"workload": f"PhoBERT-base-shape question encoder (random init, B={b}, L={L}, {real} real tokens of {b * L}: lengths uniform "
                         f"8-{L}, right-padded, packed; CLS pooling, L2 norm) + search + merge",

@@ -19,5 +19,5 @@ torch.cuda.synchronize(); ms = (time.perf_counter() - t0) / 10 * 1e3
 rows = real if packed else b * l
 lens = mask.sum(1).astype(np.float64)
 att = float((lens * lens).sum()) if packed else float(b * l * l)
-flops = 12 * (rows * 2 * (768 * 2304 + 768 * 768 + 2 * 768 * 3072) + att * 4 * 768)
+flops = 12 * (rows * 2 * 768 * 2304 + att * 4 * 768) + (11 * rows + b) * 2 * (768 * 768 + 2 * 768 * 3072)  # last layer: b first rows
 print(f"encoder B={b} L={l} ({'packed: ' + str(real) + ' real tokens' if packed else 'padded'}): {ms:.3f} ms, {flops / ms / 1e9:.0f} TFLOP/s of computed rows")

@@ -159,3 +159,27 @@ def test_sequence_packing_matches_the_padded_form(native_lib):
     with pytest.raises(ValueError, match="announced"):
         enc.forward(ids, mask)
     enc.close()
+
+
+def test_cls_pooling_prunes_the_last_layer_to_first_rows(native_lib, monkeypatch):
+    """CLS pooling of a large batch runs the last layer's out-projection / FFN / LayerNorms on the B first-token rows only
+    (encoder.hip encoder_launch).  Same vectors as the unpruned sequence (VQA_ENC_FIRST_ROWS=0 at create) up to the fp16
+    rounding of a different GEMM kernel, padded and packed; mean pooling never prunes (bit-identical either way)."""
+    from vietnamese_qa_system_amd.encoder import QuestionEncoder
+    cfg = dict(E.PHOBERT_BASE, layers=2)
+    w = E.synthetic_weights(cfg, seed=5, layers=2)
+    b, l = 160, 32
+    ids, mask = E.synthetic_tokens(cfg, b, l, seed=33)
+    ids_d, mask_d = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+    out = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("VQA_ENC_FIRST_ROWS", on)
+        enc = QuestionEncoder(w, cfg, max_tokens=b * l)
+        out[on] = {(p, r): enc.forward(ids_d, mask_d, pooling=p, real_tokens=int(mask.sum()) if r else 0).cpu().numpy()
+                   for p in ("cls", "mean") for r in (False, True)}
+        enc.close()
+    ref = E.encode(w, cfg, ids[:8], mask[:8], pooling="cls")
+    for r in (False, True):
+        assert np.abs(out["1"]["cls", r] - out["0"]["cls", r]).max() < 2e-3
+        assert _cos(out["1"]["cls", r][:8], ref).min() > 0.999
+        assert np.array_equal(out["1"]["mean", r], out["0"]["mean", r])

@@ -870,6 +870,22 @@ __global__ __launch_bounds__(64 * NQB) void attention_mfma_kernel(const _Float16
         }
 }
 
+// CLS pooling reads one row per sequence, and after the last layer's attention nothing mixes rows any more: the last layer's
+// out-projection, FFN and LayerNorms then run on the B first-token rows alone.  This gathers those rows of the attention
+// output and of the layer input (the residual) into two dense [B, H] arrays; one wave per sequence, 16 bytes per lane.
+__global__ __launch_bounds__(256) void gather_first_rows_kernel(const _Float16* __restrict__ ctx, const _Float16* __restrict__ x, int B,
+                                                                int Lmax, int H, const int* __restrict__ cu,
+                                                                _Float16* __restrict__ ctx_out, _Float16* __restrict__ x_out) {
+    const int lane = threadIdx.x & 63;
+    const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (seq >= B) return;
+    const size_t row = cu ? (size_t)cu[seq] : (size_t)seq * Lmax;
+    for (int j = lane * 8; j < H; j += 512) {  // H % 8 == 0 (checked at create)
+        *reinterpret_cast<half8*>(ctx_out + (size_t)seq * H + j) = *reinterpret_cast<const half8*>(ctx + row * H + j);
+        *reinterpret_cast<half8*>(x_out + (size_t)seq * H + j) = *reinterpret_cast<const half8*>(x + row * H + j);
+    }
+}
+
 constexpr int kMaxPer = 32;  // hidden <= 2048 (pooling keeps element j = lane + 64 i per lane)
 
 __global__ __launch_bounds__(256) void pool_normalize_kernel(const _Float16* __restrict__ hidden, const int* __restrict__ mask,
@@ -933,6 +949,7 @@ struct vqa_encoder {
         float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
     };
     std::vector<Layer> layers;
+    bool first_rows_on = true;  // CLS pooling: last layer past the attention on the first-token rows only (encoder_launch)
     std::vector<void*> allocs;
     // activations
     _Float16 *x = nullptr, *qkv = nullptr, *ctx = nullptr, *tmp = nullptr, *ffn = nullptr;
@@ -1160,6 +1177,7 @@ extern "C" int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encod
     e->device = device;
     e->cfg = *cfg;
     e->max_tokens = max_tokens;
+    e->first_rows_on = !(getenv("VQA_ENC_FIRST_ROWS") && atoi(getenv("VQA_ENC_FIRST_ROWS")) == 0);
     const size_t H = cfg->hidden, F = cfg->ffn;
     int rc = VQA_OK;
     do {
@@ -1257,6 +1275,10 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
     const int* cu = packed ? e->cu : nullptr;
     const float eps = e->cfg.ln_eps;
     const int row_blocks = (T + 3) / 4;
+    // CLS pooling of a large batch: the last layer's out-projection / FFN / LayerNorms only on the first-token rows (below);
+    // small calls are launch-bound and keep the plain sequence (VQA_ENC_FIRST_ROWS=0 at create: dev / test switch)
+    const bool first_rows_only = e->first_rows_on && pooling == VQA_POOL_CLS && T >= 1024 && T >= 2 * B && H % 8 == 0 && !e->layers.empty() &&
+                                 (size_t)B * (3 * H + F) <= (size_t)e->max_tokens * F;  // the scratch fits the FFN array
     if (packed) {
         hipLaunchKernelGGL(pack_kernel, dim3(1), dim3(256), 0, s, attn_mask, B, L, real_tokens, e->cu, e->row_seq, e->bad_ids_dev);
         VQA_HIP_CHECK(hipGetLastError());
@@ -1288,6 +1310,26 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
             hipLaunchKernelGGL(attention_kernel, dim3(B * heads), dim3(256), attn_lds, s, e->qkv, attn_mask, L, H, heads, e->ctx);
         }
         VQA_HIP_CHECK(hipGetLastError());
+        if (first_rows_only && &Ly == &e->layers.back()) {
+            // the last layer past its attention, on the B first-token rows only (scratch: the FFN intermediate array, idle here)
+            _Float16* c_ctx = e->ffn;
+            _Float16* c_x = c_ctx + (size_t)B * H;
+            _Float16* c_tmp = c_x + (size_t)B * H;
+            _Float16* c_ffn = c_tmp + (size_t)B * H;
+            hipLaunchKernelGGL(gather_first_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, s, e->ctx, e->x, B, L, H, cu, c_ctx, c_x);
+            VQA_HIP_CHECK(hipGetLastError());
+            if ((rc = launch_gemm<2>(c_ctx, Ly.wo, Ly.bo, c_x, c_tmp, B, H, H, s)) != VQA_OK) return rc;
+            launch_ln(c_tmp, B, H, Ly.ln1_g, Ly.ln1_b, eps, c_x, s);
+            VQA_HIP_CHECK(hipGetLastError());
+            if ((rc = launch_gemm<1>(c_x, Ly.w1, Ly.b1, nullptr, c_ffn, B, F, H, s)) != VQA_OK) return rc;
+            if ((rc = launch_gemm<2>(c_ffn, Ly.w2, Ly.b2, c_x, c_tmp, B, H, F, s)) != VQA_OK) return rc;
+            launch_ln(c_tmp, B, H, Ly.ln2_g, Ly.ln2_b, eps, c_x, s);
+            VQA_HIP_CHECK(hipGetLastError());
+            hipLaunchKernelGGL(pool_normalize_kernel, dim3((B + 3) / 4), dim3(256), 0, s, c_x, attn_mask, B, 1, H, pooling, normalize,
+                               (const int*)nullptr, out);
+            VQA_HIP_CHECK(hipGetLastError());
+            return VQA_OK;
+        }
         // out-projection / FFN2 add the residual row in their epilogue (EPI 2); the LayerNorm then reads one array
         if ((rc = launch_gemm<2>(e->ctx, Ly.wo, Ly.bo, e->x, e->tmp, T, H, H, s)) != VQA_OK) return rc;
         launch_ln(e->tmp, T, H, Ly.ln1_g, Ly.ln1_b, eps, e->x, s);
