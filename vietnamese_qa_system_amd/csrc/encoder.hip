@@ -80,6 +80,46 @@ __device__ __forceinline__ void row_layer_norm(float (&x)[kChunks][8], int H, in
     }
 }
 
+// LayerNorm folded into the GEMMs (FoldArgs further down): a row's statistics are (sum, sum of squares) slots, P of 16 in use.
+// Layout [slot][row] (row stride = the padded row count): the 16 rows a wave instruction covers are 128 contiguous bytes, for
+// the GEMM that writes a slot and for the one that reads it.  ([row][slot], 8-byte pieces of a row's line written by 16 waves
+// of 4 workgroups, cost 4 us per producing GEMM and 2 us per consuming one.)
+constexpr int kRowStatSlots = 16;
+
+// mean and 1 / std of a row from its slots; the whole wave calls (lanes < P load one slot each)
+__device__ __forceinline__ void row_stats(const float2* __restrict__ stats, size_t stride, size_t row, int p, int lane, float inv_h,
+                                          float eps, float& mean, float& rstd) {
+    float2 v = make_float2(0.f, 0.f);
+    if (lane < p) v = stats[lane * stride + row];
+    const float sm = wave_sum(v.x), sq = wave_sum(v.y);
+    mean = sm * inv_h;
+    rstd = rsqrtf(fmaxf(sq * inv_h - mean * mean, 0.f) + eps);
+}
+
+// the raw row (fp16) and its statistics, of the values as stored, in slot 0 (slots 1 .. 3 cleared: P = 4)
+__device__ __forceinline__ void row_raw_stats(float (&x)[kChunks][8], int H, int lane, _Float16* __restrict__ out,
+                                              float2* __restrict__ stats, size_t stride, size_t row) {
+    float sm = 0.f, sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < kChunks; ++i) {
+        const int j0 = (lane + 64 * i) * 8;
+        if (j0 < H) {
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[e] = (_Float16)x[i][e];
+                const float q = (float)o[e];
+                sm += q;
+                sq += q * q;
+            }
+            *reinterpret_cast<half8*>(out + j0) = o;
+        }
+    }
+    sm = wave_sum(sm);
+    sq = wave_sum(sq);
+    if (lane < 4) stats[lane * stride + row] = lane == 0 ? make_float2(sm, sq) : make_float2(0.f, 0.f);
+}
+
 // ---- sequence packing (round 2): a ragged batch (questions of 8-32 tokens padded to L) spends a third of every GEMM on padding
 // rows.  With right-padded masks the real tokens of sequence b are l = 0 .. n_b - 1; they are stored at packed rows
 // cu[b] + l and every kernel below takes its per-sequence length from cu (cu == nullptr: the padded [B, L] layout).
@@ -132,7 +172,8 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ i
                                                        const int* __restrict__ row_seq, int B, const float* __restrict__ word,
                                                        const float* __restrict__ pos,
                                                        const float* __restrict__ type0, const float* __restrict__ g,
-                                                       const float* __restrict__ b, float eps, _Float16* __restrict__ out) {
+                                                       const float* __restrict__ b, float eps, _Float16* __restrict__ out,
+                                                       float2* __restrict__ stats, int st_stride) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (t >= T) return;
@@ -171,7 +212,9 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ i
             for (int e = 0; e < 4; ++e) x[i][4 * hlf + e] = v[e];
         }
     }
-    row_layer_norm(x, H, lane, g, b, eps, out + (size_t)t * H);
+    // stats != nullptr: the LayerNorm is folded into the GEMMs that follow (FoldArgs): raw sum + the row's statistics
+    if (stats) row_raw_stats(x, H, lane, out + (size_t)t * H, stats, (size_t)st_stride, (size_t)t);
+    else row_layer_norm(x, H, lane, g, b, eps, out + (size_t)t * H);
 }
 
 // LayerNorm alone: the residual add is fused into the epilogue of the GEMM that produced `a` (EPI 2).  (Two or four rows per
@@ -377,11 +420,46 @@ __device__ __forceinline__ void tile_wait_vmcnt() {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int EPI, int BM, int BN, int WM, int WN, int BK>
+// ---- LayerNorm folded into the GEMMs around it (FOLD = 1; the forward of >= 1024 tokens, encoder_launch).  The post-LN block
+// h = LN(y) feeds (a) the next GEMM and (b) the next residual add.  Both can start from the RAW sum y and the row's mean /
+// variance:  (a)  LN(y) . W^T = rstd (y . (gamma (.) W)^T) - rstd mean colsum(gamma (.) W) + beta . W^T  -- the GEMM runs on y
+// with the weights scaled by gamma at create time (Wf, cvec = its column sums as stored in fp16, bias' = bias + W beta) and
+// its epilogue applies the two per-row scalars (EPI 0 / 1);  (b)  the EPI 2 epilogue normalises the residual row it reads
+// anyway, (y - mean) rstd gamma + beta, per element.  The statistics come from the GEMM that produced y (EPI 2): every wave
+// adds up sum and sum of squares of its slice of the row (the fp16 values as stored) and writes them to one of 16 slots of
+// the row (slot = feature slice of BN / WN columns: P = N / (BN / WN) slots in use, a multiple of 4); the consumer adds the
+// slots up in a fixed order -- deterministic, no atomics, no LayerNorm kernel and no second pass over the activations.
+// sum over the four lanes c, c + 16, c + 32, c + 48 (the 4 feature groups g of one token row c), in every one of them:
+// v_permlane16_swap / v_permlane32_swap of a register with itself give the two halves of each pair, one VALU op per step
+__device__ __forceinline__ float quad_row_sum(float v) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);  // {rows 0 0 2 2, rows 1 1 3 3}
+    const float h = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+    const unsigned uh = __builtin_bit_cast(unsigned, h);
+    const auto b = __builtin_amdgcn_permlane32_swap(uh, uh, false, false);  // {lower half twice, upper half twice}
+    return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
+
+#ifndef VQA_FOLD_ABLATE
+#define VQA_FOLD_ABLATE 0  // dev-only timing ablations (wrong results): 1 no statistics out, 2 no statistics in, 4 no sums, 8 no extra vectors
+#endif
+struct FoldArgs {
+    const float2* st_in;  // [16][rows] (sum, sum of squares) slots of the rows of A (EPI 0 / 1) or of R (EPI 2)
+    int p_in;             // slots in use (multiple of 4)
+    int st_stride;        // rows per slot of st_in / st_out (the padded row count)
+    float inv_h;          // 1 / LayerNorm width
+    float eps;
+    const float* cvec;    // EPI 0 / 1: column sums of the scaled weights [N]
+    const float* g;       // EPI 2: gamma / beta of the LayerNorm of R [N]
+    const float* b;
+    float2* st_out;       // EPI 2: slots of the rows of C
+};
+
+template <int EPI, int BM, int BN, int WM, int WN, int BK, int FOLD = 0>
 __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                                                         const float* __restrict__ bias, const _Float16* __restrict__ R,
                                                         _Float16* __restrict__ C, int M, int N, int K, int tiles_n,
-                                                        int tiles_total, int nb) {
+                                                        int tiles_total, int nb, FoldArgs fa) {
     using G = TileGeom<BM, BN, BK>;
     static_assert(WM * WN == 8 && BM % (16 * WM) == 0 && BN % (16 * WN) == 0, "8 waves, whole MFMA tiles per wave");
     constexpr int MT = BM / WM / 16, NT = BN / WN / 16;  // token / feature MFMA tiles per wave
@@ -449,10 +527,11 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
         if (++is_stage == S) is_stage = 0;
     };
     // all but the youngest `KSTEPS` K-steps of this wave's pieces have landed
-    auto wait_keep = [&](auto ksteps_tag) __attribute__((always_inline)) {
-        constexpr int KS = decltype(ksteps_tag)::value;
-        if (n_mine == NJ) tile_wait_vmcnt<KS * NJ>();
-        else tile_wait_vmcnt<KS * (NJ - 1)>();
+    // (`extra`: that many plain loads were issued AFTER the pieces being waited for and may stay outstanding as well)
+    auto wait_keep = [&](auto ksteps_tag, auto extra_tag) __attribute__((always_inline)) {
+        constexpr int KS = decltype(ksteps_tag)::value, EX = decltype(extra_tag)::value;
+        if (n_mine == NJ) tile_wait_vmcnt<KS * NJ + EX>();
+        else tile_wait_vmcnt<KS * (NJ - 1) + EX>();
     };
     // ---- fragment geometry: row (base + c) of a stage, sub-step ks: logical slot 4 ks + g at position slot ^ f(row); row
     // bases are multiples of 16, so f(row) = f(c)
@@ -498,7 +577,7 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
     } while (0)
     // prologue: K-steps 0 .. D - 1 issued, K-step 0 landed; group 1 holds fragments(0)
     for (int i = 0; i < D; ++i) issue_next();
-    wait_keep(std::integral_constant<int, D - 1>{});
+    wait_keep(std::integral_constant<int, D - 1>{}, std::integral_constant<int, 0>{});
     VQA_T_BARRIER();
     // the tile loop exists once per group, the wave-uniform branch sits outside it (no diamond around the MFMA blocks)
     auto run = [&](auto first_group_tag) __attribute__((always_inline)) {
@@ -514,16 +593,33 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
             for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-            for (int kt = 0; kt < KT; ++kt) {
+            // FOLD: the statistics slots of this lane's rows (written by the previous kernel: an HBM / Infinity Cache round trip)
+            // are requested two K-steps before the epilogue needs them (plain loads inside the LDS-DMA stream: see the K loop).
+            // The 288-wide tile (and the residual form of the 256-row tiles) has no registers to park them in: loaded in the epilogue.
+            constexpr bool kStatsEarly = FOLD && BN < 288 && !(EPI == 2 && BM == 256);  // (those shapes would spill)
+            f32x4 su[FOLD ? MT : 1], sw[FOLD ? MT : 1];
+            auto load_stats = [&]() __attribute__((always_inline)) {
+                const int t = tile_of(i);
+                const int m0 = (t / tiles_n) * BM + wr * (BM / WM) + c;
+#pragma unroll
+                for (int mi = 0; mi < (FOLD ? MT : 0); ++mi) {
+                    const float2* sp = fa.st_in + (size_t)(4 * g) * fa.st_stride + (m0 + 16 * mi);  // slots 4 g .. 4 g + 3 of the row
+                    const float2 q0 = sp[0], q1 = sp[fa.st_stride], q2 = sp[2 * (size_t)fa.st_stride], q3 = sp[3 * (size_t)fa.st_stride];
+                    su[mi] = f32x4{q0.x, q0.y, q1.x, q1.y};
+                    sw[mi] = f32x4{q2.x, q2.y, q3.x, q3.y};
+                }
+            };
+            // one K-step (two slots); EX: plain loads in flight that are newer than the pieces the counted waits are for
+            auto kstep = [&](auto extra_tag) __attribute__((always_inline)) {
                 // ---- slot 1
                 if constexpr (kG0) {
                     VQA_T_READ();
                     issue_next();
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    wait_keep(std::integral_constant<int, D - 1>{});  // own pieces of kappa + 1 landed (group 1 reads them in slot 2)
+                    wait_keep(std::integral_constant<int, D - 1>{}, extra_tag);  // own pieces of kappa + 1 landed (group 1 reads them in slot 2)
                 } else {
                     VQA_T_MMA();
-                    wait_keep(std::integral_constant<int, D - 2>{});  // own pieces of kappa + 1 landed
+                    wait_keep(std::integral_constant<int, D - 2>{}, extra_tag);  // own pieces of kappa + 1 landed
                 }
                 VQA_T_BARRIER();
                 // ---- slot 2
@@ -535,6 +631,18 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
                 VQA_T_BARRIER();
+            };
+            if constexpr (kStatsEarly && !(VQA_FOLD_ABLATE & 2)) {
+                // the last two K-steps run with the 4 MT statistics loads in flight.  The pieces their waits are for (K-step
+                // kappa + 1, issued D - 1 steps before) are older than those loads when D >= 3 -- the loads stay outstanding
+                // (+4 MT in the counts: without it they would take the places of 4 MT pieces and stall the LDS-DMA stream);
+                // with a two-deep stream the last step's pieces are younger than the loads and the plain count is the right one
+                for (int kt = 0; kt < KT - 2; ++kt) kstep(std::integral_constant<int, 0>{});
+                load_stats();
+                kstep(std::integral_constant<int, 4 * MT>{});
+                kstep(std::integral_constant<int, D >= 3 ? 4 * MT : 0>{});
+            } else {
+                for (int kt = 0; kt < KT; ++kt) kstep(std::integral_constant<int, 0>{});
             }
             // ---- epilogue: acc[ni][mi][j] = C[token bm + wr BM/WM + 16 mi + c][feature bn + wc BN/WN + 16 ni + 4 g + j].  A lane's
             // 4 features of one tile are 8 bytes of fp16: v_permlane16_swap between the registers of feature tiles ni and ni + 1
@@ -542,13 +650,103 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
             // ni + (g & 1), features 8 (g >> 1) .. + 7 -- so a pair of tiles goes out as one 16-byte store per lane (a wave
             // instruction covers 16 token rows x 64 contiguous bytes); bias, GELU and the residual row are applied in that layout.
             // An odd last feature tile keeps the 8-byte form.
+            // Loads and stores share one in-order counter (vmcnt): a wait for a load also waits for every older store, and a
+            // branch makes hipcc wait for everything -- the first form of this epilogue (a row bound check around every store,
+            // the bias / residual loads of a pair issued behind the previous pair's stores) completed every store before the
+            // next one went out (7-13 us per GEMM, profiles/r02_encoder_gemm_ablation.txt).  Hence: straight-line code, rows
+            // past M are computed and stored like any other (they land in the padding rows of C: every activation buffer is
+            // padded to 256 rows), and the loads of pair pr + 1 go out BEFORE the stores of pair pr.
             const int t = tile_of(i);
             const int bm = (t / tiles_n) * BM, bn = (t % tiles_n) * BN;
             typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+            constexpr int NP = NT / 2;
+            const int m_base = bm + wr * (BM / WM) + c;  // this lane's rows: m_base + 16 mi
+            // FOLD: rstd and mean x rstd of this lane's MT token rows (lanes g = 0..3 of a token each add up 4 of the 16 slots)
+            float rs[MT], mrs[MT], ps[MT], pss[MT];
+            if constexpr (FOLD) {
+                if constexpr (!kStatsEarly && !(VQA_FOLD_ABLATE & 2)) load_stats();
+                const bool live = 4 * g < fa.p_in;  // slots past P hold stale values of an earlier call
 #pragma unroll
-            for (int pr = 0; pr < NT / 2; ++pr) {
-                const int n0 = bn + wc * (BN / WN) + (2 * pr + (g & 1)) * 16 + (g >> 1) * 8;
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + n0), b1 = *reinterpret_cast<const f32x4*>(bias + n0 + 4);
+                for (int mi = 0; mi < MT; ++mi) {
+                    float sm = (su[mi][0] + su[mi][2]) + (sw[mi][0] + sw[mi][2]), sq = (su[mi][1] + su[mi][3]) + (sw[mi][1] + sw[mi][3]);
+                    sm = quad_row_sum(live ? sm : 0.f);
+                    sq = quad_row_sum(live ? sq : 0.f);
+#if VQA_FOLD_ABLATE & 2
+                    sm = 0.f;
+                    sq = 768.f;
+#endif
+                    const float mean = sm * fa.inv_h;
+                    const float r = rsqrtf(fmaxf(sq * fa.inv_h - mean * mean, 0.f) + fa.eps);
+                    rs[mi] = r;
+                    mrs[mi] = mean * r;
+                    ps[mi] = 0.f;
+                    pss[mi] = 0.f;
+                }
+            }
+            // per-feature vectors of a pair (two buffers: pair pr + 1 is loaded while pair pr is computed and stored):
+            // v[0], v[1] = bias; v[2], v[3] = FOLD: column sums (EPI 0 / 1) or gamma (EPI 2); v[4], v[5] = FOLD EPI 2: beta
+            constexpr int NV = FOLD ? (EPI == 2 ? 6 : 4) : 2;
+            f32x4 vec[2][NV];
+            half8 res[2][MT];
+            auto pair_n0 = [&](int pr) __attribute__((always_inline)) {
+                return bn + wc * (BN / WN) + (2 * pr + (g & 1)) * 16 + (g >> 1) * 8;
+            };
+            auto load_pair = [&](int pr, int buf) __attribute__((always_inline)) {
+                const int n0 = pair_n0(pr);
+                vec[buf][0] = *reinterpret_cast<const f32x4*>(bias + n0);
+                vec[buf][1] = *reinterpret_cast<const f32x4*>(bias + n0 + 4);
+                if constexpr (FOLD && bool(VQA_FOLD_ABLATE & 8)) {
+                    vec[buf][2] = vec[buf][0];
+                    vec[buf][3] = vec[buf][1];
+                    if constexpr (EPI == 2) {
+                        vec[buf][4] = vec[buf][0];
+                        vec[buf][5] = vec[buf][1];
+                    }
+                } else if constexpr (FOLD) {
+                    const float* cg = EPI == 2 ? fa.g : fa.cvec;
+                    vec[buf][2] = *reinterpret_cast<const f32x4*>(cg + n0);
+                    vec[buf][3] = *reinterpret_cast<const f32x4*>(cg + n0 + 4);
+                    if constexpr (EPI == 2) {
+                        vec[buf][4] = *reinterpret_cast<const f32x4*>(fa.b + n0);
+                        vec[buf][5] = *reinterpret_cast<const f32x4*>(fa.b + n0 + 4);
+                    }
+                }
+                if constexpr (EPI == 2) {
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi)
+                        res[buf][mi] = *reinterpret_cast<const half8*>(R + (size_t)(m_base + 16 * mi) * N + n0);
+                }
+            };
+            // the odd last feature tile's loads (8-byte form)
+            f32x4 tvec[NV / 2 > 0 ? NV / 2 : 1];
+            half4 tres[MT];
+            auto load_tail = [&]() __attribute__((always_inline)) {
+                const int n0 = bn + wc * (BN / WN) + (NT - 1) * 16 + g * 4;
+                tvec[0] = *reinterpret_cast<const f32x4*>(bias + n0);
+                if constexpr (FOLD) {
+                    tvec[1] = *reinterpret_cast<const f32x4*>((EPI == 2 ? fa.g : fa.cvec) + n0);
+                    if constexpr (EPI == 2) tvec[2] = *reinterpret_cast<const f32x4*>(fa.b + n0);
+                }
+                if constexpr (EPI == 2) {
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi)
+                        tres[mi] = *reinterpret_cast<const half4*>(R + (size_t)(m_base + 16 * mi) * N + n0);
+                }
+            };
+            if constexpr (NP > 0) load_pair(0, 0);
+            else if constexpr (NT & 1) load_tail();
+#pragma unroll
+            for (int pr = 0; pr < NP; ++pr) {
+                const int buf = pr & 1;
+                // (the 288-wide tile has no registers for two sets while all its accumulators are live: its pair 1 is loaded
+                // after pair 0 went out -- one wait for stores per tile; from there on the accumulators of stored pairs are free)
+                constexpr bool kTight = BN >= 288;
+                if (kTight && pr == 1) load_pair(1, 1);
+                if (pr + 1 < NP) {
+                    if (!kTight || pr >= 1) load_pair(pr + 1, buf ^ 1);
+                } else if constexpr (NT & 1) load_tail();
+                __builtin_amdgcn_sched_barrier(0);  // hipcc sinks these loads below the stores of pair pr otherwise
+                const int n0 = pair_n0(pr);
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) {
                     // (cast the whole vector first: __builtin_bit_cast of a single vector ELEMENT reads element 0 for every index)
@@ -560,58 +758,84 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
                         uhi[j] = r[1];
                     }
                     const f32x4 lo = __builtin_bit_cast(f32x4, ulo), hi = __builtin_bit_cast(f32x4, uhi);
-                    const int m = bm + wr * (BM / WM) + mi * 16 + c;
-                    if (m >= M) continue;  // after the swaps: every lane takes part in them
-                    half8 res = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                    if (EPI == 2) res = *reinterpret_cast<const half8*>(R + (size_t)m * N + n0);
                     half8 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float v0 = lo[j] + b0[j], v1 = hi[j] + b1[j];
+                        float v0, v1;
+                        if constexpr (FOLD && EPI != 2) {  // rstd (y . Wf) - rstd mean colsum + bias'
+                            v0 = lo[j] * rs[mi] - mrs[mi] * vec[buf][2][j] + vec[buf][0][j];
+                            v1 = hi[j] * rs[mi] - mrs[mi] * vec[buf][3][j] + vec[buf][1][j];
+                        } else {
+                            v0 = lo[j] + vec[buf][0][j];
+                            v1 = hi[j] + vec[buf][1][j];
+                        }
 #if !(VQA_GEMM_ABLATE & 2)
                         if (EPI == 1) {
                             v0 = gelu_erf(v0);
                             v1 = gelu_erf(v1);
                         }
 #endif
-                        if (EPI == 2) {
-                            v0 += (float)res[j];
-                            v1 += (float)res[4 + j];
+                        if constexpr (EPI == 2) {
+                            if constexpr (FOLD) {  // the residual is LN(raw row)
+                                v0 += ((float)res[buf][mi][j] * rs[mi] - mrs[mi]) * vec[buf][2][j] + vec[buf][4][j];
+                                v1 += ((float)res[buf][mi][4 + j] * rs[mi] - mrs[mi]) * vec[buf][3][j] + vec[buf][5][j];
+                            } else {
+                                v0 += (float)res[buf][mi][j];
+                                v1 += (float)res[buf][mi][4 + j];
+                            }
                         }
                         o[j] = (_Float16)v0;
                         o[4 + j] = (_Float16)v1;
+                        if constexpr (FOLD && EPI == 2 && !(VQA_FOLD_ABLATE & 4)) {  // statistics of the row AS STORED
+                            const float q0 = (float)o[j], q1 = (float)o[4 + j];
+                            ps[mi] += q0 + q1;
+                            pss[mi] += q0 * q0 + q1 * q1;
+                        }
                     }
 #if VQA_GEMM_ABLATE & 1
                     asm volatile("" ::"v"(o));
 #else  // plain stores: sc1 / sc0 sc1 (write-through, dropped from the XCD's L2) measured the same, nt 6 % slower on the forward
-                    *reinterpret_cast<half8*>(C + (size_t)m * N + n0) = o;
+                    *reinterpret_cast<half8*>(C + (size_t)(m_base + 16 * mi) * N + n0) = o;
 #endif
                 }
             }
             if constexpr (NT & 1) {
                 const int n0 = bn + wc * (BN / WN) + (NT - 1) * 16 + g * 4;
-                const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n0);
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi) {
-                    const int m = bm + wr * (BM / WM) + mi * 16 + c;
-                    if (m >= M) continue;
-                    half4 res = half4{0, 0, 0, 0};
-                    if (EPI == 2) res = *reinterpret_cast<const half4*>(R + (size_t)m * N + n0);
                     half4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float v = acc[NT - 1][mi][j] + bv[j];
+                        float v;
+                        if constexpr (FOLD && EPI != 2) v = acc[NT - 1][mi][j] * rs[mi] - mrs[mi] * tvec[1][j] + tvec[0][j];
+                        else v = acc[NT - 1][mi][j] + tvec[0][j];
 #if !(VQA_GEMM_ABLATE & 2)
                         if (EPI == 1) v = gelu_erf(v);
 #endif
-                        if (EPI == 2) v += (float)res[j];
+                        if constexpr (EPI == 2) {
+                            if constexpr (FOLD) v += ((float)tres[mi][j] * rs[mi] - mrs[mi]) * tvec[1][j] + tvec[2][j];
+                            else v += (float)tres[mi][j];
+                        }
                         o[j] = (_Float16)v;
+                        if constexpr (FOLD && EPI == 2) {
+                            const float q = (float)o[j];
+                            ps[mi] += q;
+                            pss[mi] += q * q;
+                        }
                     }
 #if VQA_GEMM_ABLATE & 1
                     asm volatile("" ::"v"(o));
 #else
-                    *reinterpret_cast<half4*>(C + (size_t)m * N + n0) = o;
+                    *reinterpret_cast<half4*>(C + (size_t)(m_base + 16 * mi) * N + n0) = o;
 #endif
+                }
+            }
+            if constexpr (FOLD && EPI == 2 && !(VQA_FOLD_ABLATE & 1)) {  // this wave's slice of every row: one (sum, sum of squares) slot
+                const int slot = (bn + wc * (BN / WN)) / (BN / WN);
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi) {
+                    const float sm = quad_row_sum(ps[mi]), sq = quad_row_sum(pss[mi]);
+                    if (g == 0) fa.st_out[(size_t)slot * fa.st_stride + (m_base + 16 * mi)] = make_float2(sm, sq);  // rows past M: padding
                 }
             }
         }
@@ -873,16 +1097,52 @@ __global__ __launch_bounds__(64 * NQB) void attention_mfma_kernel(const _Float16
 // CLS pooling reads one row per sequence, and after the last layer's attention nothing mixes rows any more: the last layer's
 // out-projection, FFN and LayerNorms then run on the B first-token rows alone.  This gathers those rows of the attention
 // output and of the layer input (the residual) into two dense [B, H] arrays; one wave per sequence, 16 bytes per lane.
+// (stats != nullptr: x holds raw rows whose LayerNorm is folded into the GEMMs -- the gathered residual rows are normalised here.)
 __global__ __launch_bounds__(256) void gather_first_rows_kernel(const _Float16* __restrict__ ctx, const _Float16* __restrict__ x, int B,
                                                                 int Lmax, int H, const int* __restrict__ cu,
-                                                                _Float16* __restrict__ ctx_out, _Float16* __restrict__ x_out) {
+                                                                _Float16* __restrict__ ctx_out, _Float16* __restrict__ x_out,
+                                                                const float2* __restrict__ stats, int st_stride, int p,
+                                                                const float* __restrict__ g, const float* __restrict__ b, float eps) {
     const int lane = threadIdx.x & 63;
     const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (seq >= B) return;
     const size_t row = cu ? (size_t)cu[seq] : (size_t)seq * Lmax;
+    float mean = 0.f, rstd = 1.f;
+    if (stats) row_stats(stats, (size_t)st_stride, row, p, lane, 1.0f / H, eps, mean, rstd);
     for (int j = lane * 8; j < H; j += 512) {  // H % 8 == 0 (checked at create)
         *reinterpret_cast<half8*>(ctx_out + (size_t)seq * H + j) = *reinterpret_cast<const half8*>(ctx + row * H + j);
-        *reinterpret_cast<half8*>(x_out + (size_t)seq * H + j) = *reinterpret_cast<const half8*>(x + row * H + j);
+        half8 v = *reinterpret_cast<const half8*>(x + row * H + j);
+        if (stats) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (_Float16)(((float)v[e] - mean) * rstd * g[j + e] + b[j + e]);
+        }
+        *reinterpret_cast<half8*>(x_out + (size_t)seq * H + j) = v;
+    }
+}
+
+// create time: one weight matrix [N][K] (fp32, device) of a GEMM whose input is a LayerNorm output -> the folded form:
+// Wf = fp16(W (.) gamma), cvec[n] = sum_k Wf[n][k] (of the fp16 values the MFMAs will multiply), bf[n] = bias[n] + sum_k W[n][k] beta[k].
+// One wave per output feature.
+__global__ __launch_bounds__(256) void fold_weight_kernel(const float* __restrict__ W, int N, int K, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ bias,
+                                                          _Float16* __restrict__ Wf, float* __restrict__ cvec,
+                                                          float* __restrict__ bf) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float cs = 0.f, bs = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = W[(size_t)n * K + k];
+        const _Float16 wf = (_Float16)(w * gamma[k]);
+        Wf[(size_t)n * K + k] = wf;
+        cs += (float)wf;
+        bs += w * beta[k];
+    }
+    cs = wave_sum(cs);
+    bs = wave_sum(bs);
+    if (lane == 0) {
+        cvec[n] = cs;
+        bf[n] = bias[n] + bs;
     }
 }
 
@@ -890,7 +1150,9 @@ constexpr int kMaxPer = 32;  // hidden <= 2048 (pooling keeps element j = lane +
 
 __global__ __launch_bounds__(256) void pool_normalize_kernel(const _Float16* __restrict__ hidden, const int* __restrict__ mask,
                                                              int B, int Lmax, int H, int pooling, int normalize,
-                                                             const int* __restrict__ cu, float* __restrict__ out) {
+                                                             const int* __restrict__ cu, float* __restrict__ out,
+                                                             const float2* __restrict__ stats, int st_stride, int p,
+                                                             const float* __restrict__ g, const float* __restrict__ b, float eps) {
     const int lane = threadIdx.x & 63;
     const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (seq >= B) return;
@@ -899,23 +1161,38 @@ __global__ __launch_bounds__(256) void pool_normalize_kernel(const _Float16* __r
     float x[kMaxPer];
 #pragma unroll
     for (int i = 0; i < kMaxPer; ++i) x[i] = 0.f;
+    // stats != nullptr: `hidden` holds raw rows whose LayerNorm is folded into the GEMMs (FoldArgs); the pooled rows are
+    // normalised here: sum_l ((h_l - mean_l) rstd_l) gamma + cnt beta
+    float mean = 0.f, rstd = 1.f;
+    int cnt = 1;
     if (pooling == VQA_POOL_CLS) {
+        if (stats) row_stats(stats, (size_t)st_stride, row0, p, lane, 1.0f / H, eps, mean, rstd);
 #pragma unroll
         for (int i = 0; i < kMaxPer; ++i) {
             const int j = lane + 64 * i;
-            if (j < H) x[i] = (float)hidden[row0 * H + j];
+            if (j < H) x[i] = ((float)hidden[row0 * H + j] - mean) * rstd;
         }
     } else {
-        int cnt = 0;
+        cnt = 0;
         for (int l = 0; l < L; ++l) {
             if (!cu && !mask[seq * Lmax + l]) continue;
             ++cnt;
+            if (stats) row_stats(stats, (size_t)st_stride, row0 + l, p, lane, 1.0f / H, eps, mean, rstd);
 #pragma unroll
             for (int i = 0; i < kMaxPer; ++i) {
                 const int j = lane + 64 * i;
-                if (j < H) x[i] += (float)hidden[(row0 + l) * H + j];
+                if (j < H) x[i] += ((float)hidden[(row0 + l) * H + j] - mean) * rstd;
             }
         }
+    }
+    if (stats) {
+#pragma unroll
+        for (int i = 0; i < kMaxPer; ++i) {
+            const int j = lane + 64 * i;
+            if (j < H) x[i] = x[i] * g[j] + (float)cnt * b[j];
+        }
+    }
+    if (pooling != VQA_POOL_CLS) {
         const float inv = 1.0f / fmaxf((float)cnt, 1e-9f);
 #pragma unroll
         for (int i = 0; i < kMaxPer; ++i) x[i] *= inv;
@@ -947,12 +1224,18 @@ struct vqa_encoder {
         _Float16 *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;
         float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
         float *ln1_g = nullptr, *ln1_b = nullptr, *ln2_g = nullptr, *ln2_b = nullptr;
+        // LayerNorm folded into the GEMM that reads its output (FoldArgs): weights scaled by the gamma of the LayerNorm in
+        // front (QKV: the previous layer's second one, or the embedding's; FFN1: this layer's first), their column sums, bias + W beta
+        _Float16 *wqkv_f = nullptr, *w1_f = nullptr;
+        float *cqkv = nullptr, *c1 = nullptr, *bqkv_f = nullptr, *b1_f = nullptr;
     };
     std::vector<Layer> layers;
     bool first_rows_on = true;  // CLS pooling: last layer past the attention on the first-token rows only (encoder_launch)
     std::vector<void*> allocs;
     // activations
     _Float16 *x = nullptr, *qkv = nullptr, *ctx = nullptr, *tmp = nullptr, *ffn = nullptr;
+    float2 *st_x = nullptr, *st_tmp = nullptr;  // folded LayerNorms: the statistics slots of the raw rows in x / tmp, [rows][16]
+    bool fold_on = true;                        // VQA_ENC_FOLD=0 at create: dev / test switch
     // small batches are launch-bound (12 layers x 7 kernels of a few microseconds each): their launch sequence is captured
     // once per (B, L, pooling, normalize) into a hipGraph over these fixed staging buffers and replayed
     int32_t *cu = nullptr, *row_seq = nullptr;    // sequence packing: [max_tokens + 1] row offsets, [max_tokens] packed row -> sequence
@@ -1030,15 +1313,39 @@ int upload_f16(vqa_encoder* e, const float* src, size_t n, _Float16* dst) {
     return VQA_OK;
 }
 
+// fp32 source [N][K] -> the LayerNorm-folded form on the device (fold_weight_kernel), through a temporary fp32 device buffer
+int upload_folded(const float* src, int N, int K, const float* gamma, const float* beta, const float* bias, _Float16* wf, float* cvec,
+                  float* bf) {
+    VQA_REQUIRE(src, "vqa_encoder_create: a weight pointer is null");
+    float* tmp = nullptr;
+    const size_t bytes = (size_t)N * K * 4;
+    if (hipMalloc((void**)&tmp, bytes) != hipSuccess) {
+        vqa_set_error("vqa_encoder_create: staging hipMalloc of %zu bytes failed", bytes);
+        return VQA_ENOMEM;
+    }
+    hipError_t err = hipMemcpy(tmp, src, bytes, hipMemcpyDefault);
+    if (err == hipSuccess) {
+        hipLaunchKernelGGL(fold_weight_kernel, dim3((N + 3) / 4), dim3(256), 0, 0, tmp, N, K, gamma, beta, bias, wf, cvec, bf);
+        err = hipGetLastError();
+        if (err == hipSuccess) err = hipDeviceSynchronize();
+    }
+    (void)hipFree(tmp);
+    if (err != hipSuccess) {
+        vqa_set_error("vqa_encoder_create: folding a LayerNorm into a weight matrix failed: %s", hipGetErrorString(err));
+        return VQA_EHIP;
+    }
+    return VQA_OK;
+}
+
 constexpr int kTokenPad = 256;  // activation buffers are padded to this many rows (the tallest tile)
 
-template <int EPI, int BM, int BN, int WM, int WN, int BK>
+template <int EPI, int BM, int BN, int WM, int WN, int BK, int FOLD = 0>
 int launch_tile(const _Float16* A, const _Float16* W, const float* bias, const _Float16* R, _Float16* C, int M, int N, int K,
-                int num_cu, hipStream_t s) {
+                int num_cu, hipStream_t s, const FoldArgs& fa = FoldArgs{}) {
     using G = TileGeom<BM, BN, BK>;
     static VqaPerDeviceOnce once;
     int rc = once.run([&](int) -> int {
-        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<EPI, BM, BN, WM, WN, BK>),
+        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<EPI, BM, BN, WM, WN, BK, FOLD>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::kLds));
         return VQA_OK;
     });
@@ -1056,8 +1363,8 @@ int launch_tile(const _Float16* A, const _Float16* W, const float* bias, const _
         if (nb_force >= 0 && (nb_force == 0 || (tiles_n % nb_force == 0 && per % nb_force == 0 && rows % (per / nb_force) == 0)))
             nb = nb_force;
     }
-    hipLaunchKernelGGL((gemm_tile_kernel<EPI, BM, BN, WM, WN, BK>), dim3(grid), dim3(512), G::kLds, s, A, W, bias, R, C, M, N, K,
-                       tiles_n, tiles, nb);
+    hipLaunchKernelGGL((gemm_tile_kernel<EPI, BM, BN, WM, WN, BK, FOLD>), dim3(grid), dim3(512), G::kLds, s, A, W, bias, R, C, M, N,
+                       K, tiles_n, tiles, nb, fa);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }
@@ -1069,11 +1376,76 @@ static long tile_cost(int M, int N, int BM, int BN, int num_cu) {
     return (tiles + num_cu - 1) / num_cu * (BM + BN);
 }
 
+// Tile shapes: {BM, BN, BK, WN}.  The cost model is LDS-DMA bytes per CU (rounds of tiles x (BM + BN)): what the K loop is
+// bound by; K-steps of 32 halves pay two barriers per 32-deep step, so a 64-deep shape wins a near tie (x 0.85).
+static const int kTileShapes[5][4] = {{256, 288, 32, 2}, {256, 192, 32, 2}, {256, 128, 64, 2}, {128, 192, 64, 4}, {256, 128, 32, 2}};
+
+// index into kTileShapes of the LDS-DMA tile kernel's shape for this problem; -1: the problem does not take that kernel
+// (fewer than 1024 rows, or no shape divides N / K); -2: HIP error (message set)
+static int tile_choice(int M, int N, int K, int* num_cu_out) {
+    static const int force_tile = getenv("VQA_GEMM_TILE") ? atoi(getenv("VQA_GEMM_TILE")) : -1;  // dev override: shape index 0..4
+    if (!(M >= 1024 && N % 64 == 0 && K % 32 == 0)) return -1;
+    static VqaPerDeviceOnce once;
+    static int num_cu[64] = {};  // written inside the once, read after it
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        vqa_set_error("hipGetDevice failed");
+        return -2;
+    }
+    int rc = once.run([&](int d) -> int {
+        hipDeviceProp_t prop;
+        VQA_HIP_CHECK(hipGetDeviceProperties(&prop, d));
+        num_cu[d & 63] = prop.multiProcessorCount;
+        return VQA_OK;
+    });
+    if (rc != VQA_OK) return -2;
+    const int cu = num_cu[dev & 63];
+    *num_cu_out = cu;
+    int best = -1;
+    double best_cost = 0;
+    for (int i = 0; i < 4; ++i) {
+        const long cst = K % kTileShapes[i][2] ? -1 : tile_cost(M, N, kTileShapes[i][0], kTileShapes[i][1], cu);
+        const double w = cst * (kTileShapes[i][2] == 64 ? 0.85 : 1.0);
+        if (cst >= 0 && (best < 0 || w < best_cost)) {
+            best = i;
+            best_cost = w;
+        }
+    }
+    if (force_tile >= 0 && force_tile < 5 && K % kTileShapes[force_tile][2] == 0 &&
+        tile_cost(M, N, kTileShapes[force_tile][0], kTileShapes[force_tile][1], cu) >= 0)
+        best = force_tile;
+    return best;
+}
+
+// statistics slots per row a FOLD EPI 2 GEMM of this shape writes: N / (BN / WN); 0: the problem does not take the tile kernel
+static int tile_stat_slots(int M, int N, int K) {
+    int cu = 0;
+    const int best = tile_choice(M, N, K, &cu);
+    return best < 0 ? 0 : N / (kTileShapes[best][1] / kTileShapes[best][3]);
+}
+
+// the LayerNorm-folded forms (FoldArgs above); the caller checked with tile_stat_slots that the problem takes the tile kernel
+template <int EPI>
+int launch_gemm_fold(const _Float16* A, const _Float16* W, const float* bias, const _Float16* R, _Float16* C, int M, int N, int K,
+                     const FoldArgs& fa, hipStream_t s) {
+    int cu = 0;
+    const int best = tile_choice(M, N, K, &cu);
+    switch (best) {
+        case 0: return launch_tile<EPI, 256, 288, 4, 2, 32, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
+        case 1: return launch_tile<EPI, 256, 192, 4, 2, 32, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
+        case 2: return launch_tile<EPI, 256, 128, 4, 2, 64, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
+        case 3: return launch_tile<EPI, 128, 192, 2, 4, 64, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
+        case 4: return launch_tile<EPI, 256, 128, 4, 2, 32, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
+        default: break;
+    }
+    if (best != -2) vqa_set_error("launch_gemm_fold: no tile shape for M=%d N=%d K=%d", M, N, K);
+    return best == -2 ? VQA_EHIP : VQA_EINVAL;
+}
+
 template <int EPI>
 int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, const _Float16* R, _Float16* C, int M, int N, int K,
                 hipStream_t s) {
     static const bool force_small = getenv("VQA_GEMM_SMALL") != nullptr;  // dev override, read once
-    static const int force_tile = getenv("VQA_GEMM_TILE") ? atoi(getenv("VQA_GEMM_TILE")) : -1;  // dev override: shape index 0..4
     static const int skinny_max = getenv("VQA_SKINNY_MAX") ? atoi(getenv("VQA_SKINNY_MAX")) : 512;  // dev override; measured crossover with the 128 x 128 kernel ~ 700 tokens
     if (M <= skinny_max && N % 16 == 0 && K % 256 == 0 && !force_small) {
         const int mt = M >= 64 ? 4 : (M + 15) / 16;
@@ -1089,35 +1461,10 @@ int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, const _
         VQA_HIP_CHECK(hipGetLastError());
         return VQA_OK;
     }
-    if (M >= 1024 && N % 64 == 0 && K % 32 == 0 && !force_small) {
-        static VqaPerDeviceOnce once;
-        static int num_cu[64] = {};  // written inside the once, read after it
-        int dev = 0;
-        VQA_HIP_CHECK(hipGetDevice(&dev));
-        int rc = once.run([&](int d) -> int {
-            hipDeviceProp_t prop;
-            VQA_HIP_CHECK(hipGetDeviceProperties(&prop, d));
-            num_cu[d & 63] = prop.multiProcessorCount;
-            return VQA_OK;
-        });
-        if (rc != VQA_OK) return rc;
-        const int cu = num_cu[dev & 63];
-        // Tile shapes: {BM, BN, BK}.  The cost model is LDS-DMA bytes per CU (rounds of tiles x (BM + BN)): what the K loop is
-        // bound by; K-steps of 32 halves pay two barriers per 32-deep step, so a 64-deep shape wins a near tie (x 0.85).
-        static const int shapes[5][3] = {{256, 288, 32}, {256, 192, 32}, {256, 128, 64}, {128, 192, 64}, {256, 128, 32}};
-        int best = -1;
-        double best_cost = 0;
-        for (int i = 0; i < 4; ++i) {
-            const long cst = K % shapes[i][2] ? -1 : tile_cost(M, N, shapes[i][0], shapes[i][1], cu);
-            const double w = cst * (shapes[i][2] == 64 ? 0.85 : 1.0);
-            if (cst >= 0 && (best < 0 || w < best_cost)) {
-                best = i;
-                best_cost = w;
-            }
-        }
-        if (force_tile >= 0 && force_tile < 5 && K % shapes[force_tile][2] == 0 &&
-            tile_cost(M, N, shapes[force_tile][0], shapes[force_tile][1], cu) >= 0)
-            best = force_tile;
+    if (!force_small) {
+        int cu = 0;
+        const int best = tile_choice(M, N, K, &cu);
+        if (best == -2) return VQA_EHIP;
         switch (best) {
             case 0: return launch_tile<EPI, 256, 288, 4, 2, 32>(A, W, bias, R, C, M, N, K, cu, s);
             case 1: return launch_tile<EPI, 256, 192, 4, 2, 32>(A, W, bias, R, C, M, N, K, cu, s);
@@ -1178,6 +1525,7 @@ extern "C" int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encod
     e->cfg = *cfg;
     e->max_tokens = max_tokens;
     e->first_rows_on = !(getenv("VQA_ENC_FIRST_ROWS") && atoi(getenv("VQA_ENC_FIRST_ROWS")) == 0);
+    e->fold_on = !(getenv("VQA_ENC_FOLD") && atoi(getenv("VQA_ENC_FOLD")) == 0);
     const size_t H = cfg->hidden, F = cfg->ffn;
     int rc = VQA_OK;
     do {
@@ -1216,6 +1564,24 @@ extern "C" int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encod
             if ((rc = upload_f32(e, lw.ln1_b, H, &L.ln1_b)) != VQA_OK) break;
             if ((rc = upload_f32(e, lw.ln2_g, H, &L.ln2_g)) != VQA_OK) break;
             if ((rc = upload_f32(e, lw.ln2_b, H, &L.ln2_b)) != VQA_OK) break;
+            if (e->fold_on) {
+                // QKV reads the LayerNorm in front of this layer (the embedding's, or the previous layer's second one), FFN1 this
+                // layer's first one
+                const float* pg = i == 0 ? e->emb_g : e->layers[i - 1].ln2_g;
+                const float* pb = i == 0 ? e->emb_b : e->layers[i - 1].ln2_b;
+                if ((rc = dev_alloc(e, (void**)&L.wqkv_f, 3 * H * H * 2)) != VQA_OK) break;
+                if ((rc = dev_alloc(e, (void**)&L.cqkv, 3 * H * 4)) != VQA_OK) break;
+                if ((rc = dev_alloc(e, (void**)&L.bqkv_f, 3 * H * 4)) != VQA_OK) break;
+                const float* part[3] = {lw.wq, lw.wk, lw.wv};
+                for (int j = 0; j < 3 && rc == VQA_OK; ++j)
+                    rc = upload_folded(part[j], (int)H, (int)H, pg, pb, L.bqkv + j * H, L.wqkv_f + j * H * H, L.cqkv + j * H,
+                                       L.bqkv_f + j * H);
+                if (rc != VQA_OK) break;
+                if ((rc = dev_alloc(e, (void**)&L.w1_f, F * H * 2)) != VQA_OK) break;
+                if ((rc = dev_alloc(e, (void**)&L.c1, F * 4)) != VQA_OK) break;
+                if ((rc = dev_alloc(e, (void**)&L.b1_f, F * 4)) != VQA_OK) break;
+                if ((rc = upload_folded(lw.w1, (int)F, (int)H, L.ln1_g, L.ln1_b, L.b1, L.w1_f, L.c1, L.b1_f)) != VQA_OK) break;
+            }
         }
         if (rc != VQA_OK) break;
         // token rows padded to the large GEMM's 256-row tiles: rows past B * L are read (never written back), so clear them once
@@ -1225,6 +1591,8 @@ extern "C" int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encod
         if ((rc = dev_alloc(e, (void**)&e->ctx, T * H * 2)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->tmp, T * H * 2)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->ffn, T * F * 2)) != VQA_OK) break;
+        if ((rc = dev_alloc(e, (void**)&e->st_x, T * kRowStatSlots * sizeof(float2))) != VQA_OK) break;
+        if ((rc = dev_alloc(e, (void**)&e->st_tmp, T * kRowStatSlots * sizeof(float2))) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->cu, ((size_t)max_tokens + 1) * 4)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->row_seq, (size_t)max_tokens * 4)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->g_ids, (size_t)max_tokens * 4)) != VQA_OK) break;
@@ -1247,7 +1615,9 @@ extern "C" int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encod
             }
         }
         if (hipMemset(e->x, 0, T * H * 2) != hipSuccess || hipMemset(e->ctx, 0, T * H * 2) != hipSuccess ||
-            hipMemset(e->ffn, 0, T * F * 2) != hipSuccess) {
+            hipMemset(e->ffn, 0, T * F * 2) != hipSuccess || hipMemset(e->tmp, 0, T * H * 2) != hipSuccess ||
+            hipMemset(e->st_x, 0, T * kRowStatSlots * sizeof(float2)) != hipSuccess ||
+            hipMemset(e->st_tmp, 0, T * kRowStatSlots * sizeof(float2)) != hipSuccess) {
             vqa_set_error("vqa_encoder_create: clearing the activation buffers failed");
             rc = VQA_EHIP;
             break;
@@ -1283,16 +1653,30 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
         hipLaunchKernelGGL(pack_kernel, dim3(1), dim3(256), 0, s, attn_mask, B, L, real_tokens, e->cu, e->row_seq, e->bad_ids_dev);
         VQA_HIP_CHECK(hipGetLastError());
     }
+    // LayerNorms folded into the GEMMs (FoldArgs): every GEMM of the layer must take the LDS-DMA tile kernel and the two that
+    // produce statistics must fit their slices into the 16 slots of a row
+    const int p_out = e->fold_on ? tile_stat_slots(T, H, H) : 0, p_ffn = e->fold_on ? tile_stat_slots(T, H, F) : 0;
+    const bool fold = e->fold_on && p_out >= 4 && p_out <= kRowStatSlots && p_out % 4 == 0 && p_ffn >= 4 && p_ffn <= kRowStatSlots &&
+                      p_ffn % 4 == 0 && tile_stat_slots(T, 3 * H, H) > 0 && tile_stat_slots(T, F, H) > 0;
+    const int st_stride = (e->max_tokens + kTokenPad - 1) / kTokenPad * kTokenPad;  // rows per statistics slot (the padded row count)
     hipLaunchKernelGGL(embed_ln_kernel, dim3(row_blocks), dim3(256), 0, s, input_ids, T, L, H, e->cfg.pad_id, e->cfg.vocab_size,
-                       e->bad_ids_dev, cu, e->row_seq, B, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x);
+                       e->bad_ids_dev, cu, e->row_seq, B, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x,
+                       fold ? e->st_x : (float2*)nullptr, st_stride);
     VQA_HIP_CHECK(hipGetLastError());
+    // fold: x holds RAW rows; (pg, pb, p_x) = gamma / beta / slots in use of the LayerNorm that belongs on them
+    const float *pg = e->emb_g, *pb = e->emb_b;
+    int p_x = 4;
+    const float inv_h = 1.0f / H;
     const size_t attn_lds = ((size_t)2 * L * (dh + 1) + 4 * L + 4 * dh) * sizeof(float);
     VQA_REQUIRE(attn_lds <= 160 * 1024, "vqa_encoder_forward: L=%d with head size %d needs %zu bytes of LDS", L, dh, attn_lds);
     if (attn_lds > 64 * 1024)
         VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds));
     for (const vqa_encoder::Layer& Ly : e->layers) {
-        int rc = launch_gemm<0>(e->x, Ly.wqkv, Ly.bqkv, nullptr, e->qkv, T, 3 * H, H, s);
+        int rc;
+        if (fold) rc = launch_gemm_fold<0>(e->x, Ly.wqkv_f, Ly.bqkv_f, nullptr, e->qkv, T, 3 * H, H,
+                                           FoldArgs{e->st_x, p_x, st_stride, inv_h, eps, Ly.cqkv, nullptr, nullptr, nullptr}, s);
+        else rc = launch_gemm<0>(e->x, Ly.wqkv, Ly.bqkv, nullptr, e->qkv, T, 3 * H, H, s);
         if (rc != VQA_OK) return rc;
         if (dh == kAttDh && L <= 32 * kAttMaxBlocks) {
             const int nqb = (L + 31) / 32;
@@ -1316,7 +1700,8 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
             _Float16* c_x = c_ctx + (size_t)B * H;
             _Float16* c_tmp = c_x + (size_t)B * H;
             _Float16* c_ffn = c_tmp + (size_t)B * H;
-            hipLaunchKernelGGL(gather_first_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, s, e->ctx, e->x, B, L, H, cu, c_ctx, c_x);
+            hipLaunchKernelGGL(gather_first_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, s, e->ctx, e->x, B, L, H, cu, c_ctx, c_x,
+                               fold ? e->st_x : (const float2*)nullptr, st_stride, p_x, pg, pb, eps);
             VQA_HIP_CHECK(hipGetLastError());
             if ((rc = launch_gemm<2>(c_ctx, Ly.wo, Ly.bo, c_x, c_tmp, B, H, H, s)) != VQA_OK) return rc;
             launch_ln(c_tmp, B, H, Ly.ln1_g, Ly.ln1_b, eps, c_x, s);
@@ -1326,9 +1711,26 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
             launch_ln(c_tmp, B, H, Ly.ln2_g, Ly.ln2_b, eps, c_x, s);
             VQA_HIP_CHECK(hipGetLastError());
             hipLaunchKernelGGL(pool_normalize_kernel, dim3((B + 3) / 4), dim3(256), 0, s, c_x, attn_mask, B, 1, H, pooling, normalize,
-                               (const int*)nullptr, out);
+                               (const int*)nullptr, out, (const float2*)nullptr, 0, 0, (const float*)nullptr, (const float*)nullptr, eps);
             VQA_HIP_CHECK(hipGetLastError());
             return VQA_OK;
+        }
+        if (fold) {
+            // raw rows + statistics all the way: out-projection (residual = LN(x) applied in its epilogue) -> tmp, st_tmp;
+            // FFN1 on tmp with LN1 folded; FFN2 (residual = LN1(tmp)) -> x, st_x; the next layer's QKV folds LN2
+            if ((rc = launch_gemm_fold<2>(e->ctx, Ly.wo, Ly.bo, e->x, e->tmp, T, H, H,
+                                          FoldArgs{e->st_x, p_x, st_stride, inv_h, eps, nullptr, pg, pb, e->st_tmp}, s)) != VQA_OK)
+                return rc;
+            if ((rc = launch_gemm_fold<1>(e->tmp, Ly.w1_f, Ly.b1_f, nullptr, e->ffn, T, F, H,
+                                          FoldArgs{e->st_tmp, p_out, st_stride, inv_h, eps, Ly.c1, nullptr, nullptr, nullptr}, s)) != VQA_OK)
+                return rc;
+            if ((rc = launch_gemm_fold<2>(e->ffn, Ly.w2, Ly.b2, e->tmp, e->x, T, H, F,
+                                          FoldArgs{e->st_tmp, p_out, st_stride, inv_h, eps, nullptr, Ly.ln1_g, Ly.ln1_b, e->st_x}, s)) != VQA_OK)
+                return rc;
+            pg = Ly.ln2_g;
+            pb = Ly.ln2_b;
+            p_x = p_ffn;
+            continue;
         }
         // out-projection / FFN2 add the residual row in their epilogue (EPI 2); the LayerNorm then reads one array
         if ((rc = launch_gemm<2>(e->ctx, Ly.wo, Ly.bo, e->x, e->tmp, T, H, H, s)) != VQA_OK) return rc;
@@ -1339,7 +1741,8 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
         launch_ln(e->tmp, T, H, Ly.ln2_g, Ly.ln2_b, eps, e->x, s);
         VQA_HIP_CHECK(hipGetLastError());
     }
-    hipLaunchKernelGGL(pool_normalize_kernel, dim3((B + 3) / 4), dim3(256), 0, s, e->x, attn_mask, B, L, H, pooling, normalize, cu, out);
+    hipLaunchKernelGGL(pool_normalize_kernel, dim3((B + 3) / 4), dim3(256), 0, s, e->x, attn_mask, B, L, H, pooling, normalize, cu, out,
+                       fold ? e->st_x : (const float2*)nullptr, st_stride, p_x, pg, pb, eps);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }
