@@ -183,3 +183,38 @@ def test_cls_pooling_prunes_the_last_layer_to_first_rows(native_lib, monkeypatch
         assert np.abs(out["1"]["cls", r] - out["0"]["cls", r]).max() < 2e-3
         assert _cos(out["1"]["cls", r][:8], ref).min() > 0.999
         assert np.array_equal(out["1"]["mean", r], out["0"]["mean", r])
+
+
+def test_folded_layernorms_match_the_layernorm_kernels(native_lib, monkeypatch):
+    """Calls of at least 1024 tokens run without LayerNorm kernels: the GEMMs carry raw rows plus per-row statistics and the
+    LayerNorm is applied inside the GEMM epilogues / folded into gamma-scaled weights (encoder.hip FoldArgs).  Same vectors as
+    the LayerNorm-kernel sequence (VQA_ENC_FOLD=0 at create) up to fp16 rounding -- both poolings, padded and packed, with and
+    without the first-row pruning of the last layer -- and the fp64 oracle's."""
+    from vietnamese_qa_system_amd.encoder import QuestionEncoder
+    cfg = dict(E.PHOBERT_BASE, layers=3)
+    w = E.synthetic_weights(cfg, seed=7, layers=3)
+    # LayerNorm parameters away from (1, 0) so that the folded gamma / beta terms carry weight
+    rng = np.random.default_rng(3)
+    for k in list(w):
+        if "LayerNorm.weight" in k:
+            w[k] = (1.0 + 0.3 * rng.standard_normal(w[k].shape)).astype(np.float32)
+        elif "LayerNorm.bias" in k:
+            w[k] = (0.2 * rng.standard_normal(w[k].shape)).astype(np.float32)
+    b, l = 96, 32
+    ids, mask = E.synthetic_tokens(cfg, b, l, seed=35)
+    ids_d, mask_d = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+    out = {}
+    for fold, first in (("1", "1"), ("0", "1"), ("1", "0")):
+        monkeypatch.setenv("VQA_ENC_FOLD", fold)
+        monkeypatch.setenv("VQA_ENC_FIRST_ROWS", first)
+        enc = QuestionEncoder(w, cfg, max_tokens=b * l)
+        out[fold, first] = {(p, r): enc.forward(ids_d, mask_d, pooling=p, real_tokens=int(mask.sum()) if r else 0).cpu().numpy()
+                            for p in ("cls", "mean") for r in (False, True)}
+        enc.close()
+    for p in ("cls", "mean"):
+        ref = E.encode(w, cfg, ids[:6], mask[:6], pooling=p)
+        for r in (False, True):
+            for key in (("1", "1"), ("1", "0")):
+                assert np.abs(out[key][p, r] - out["0", "1"][p, r]).max() < 3e-3, (p, r, key)
+                assert _cos(out[key][p, r][:6], ref).min() > 0.999
+                assert np.abs(out[key][p, r][:6] - ref).max() < 2e-2

@@ -595,8 +595,8 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
                 for (int mi = 0; mi < MT; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
             // FOLD: the statistics slots of this lane's rows (written by the previous kernel: an HBM / Infinity Cache round trip)
             // are requested two K-steps before the epilogue needs them (plain loads inside the LDS-DMA stream: see the K loop).
-            // The 288-wide tile (and the residual form of the 256-row tiles) has no registers to park them in: loaded in the epilogue.
-            constexpr bool kStatsEarly = FOLD && BN < 288 && !(EPI == 2 && BM == 256);  // (those shapes would spill)
+            // The 256- / 288-wide tiles (and the residual form of the 256-row tiles) have no registers to park them in: loaded in the epilogue.
+            constexpr bool kStatsEarly = FOLD && BN < 256 && !(EPI == 2 && BM == 256);  // (those shapes would spill)
             f32x4 su[FOLD ? MT : 1], sw[FOLD ? MT : 1];
             auto load_stats = [&]() __attribute__((always_inline)) {
                 const int t = tile_of(i);
@@ -1378,12 +1378,13 @@ static long tile_cost(int M, int N, int BM, int BN, int num_cu) {
 
 // Tile shapes: {BM, BN, BK, WN}.  The cost model is LDS-DMA bytes per CU (rounds of tiles x (BM + BN)): what the K loop is
 // bound by; K-steps of 32 halves pay two barriers per 32-deep step, so a 64-deep shape wins a near tie (x 0.85).
-static const int kTileShapes[5][4] = {{256, 288, 32, 2}, {256, 192, 32, 2}, {256, 128, 64, 2}, {128, 192, 64, 4}, {256, 128, 32, 2}};
+static const int kTileShapes[6][4] = {{256, 288, 32, 2}, {256, 192, 32, 2}, {256, 128, 64, 2}, {128, 192, 64, 4}, {256, 128, 32, 2},
+                                      {256, 256, 32, 2}};
 
 // index into kTileShapes of the LDS-DMA tile kernel's shape for this problem; -1: the problem does not take that kernel
 // (fewer than 1024 rows, or no shape divides N / K); -2: HIP error (message set)
 static int tile_choice(int M, int N, int K, int* num_cu_out) {
-    static const int force_tile = getenv("VQA_GEMM_TILE") ? atoi(getenv("VQA_GEMM_TILE")) : -1;  // dev override: shape index 0..4
+    static const int force_tile = getenv("VQA_GEMM_TILE") ? atoi(getenv("VQA_GEMM_TILE")) : -1;  // dev override: shape index 0..5
     if (!(M >= 1024 && N % 64 == 0 && K % 32 == 0)) return -1;
     static VqaPerDeviceOnce once;
     static int num_cu[64] = {};  // written inside the once, read after it
@@ -1403,7 +1404,8 @@ static int tile_choice(int M, int N, int K, int* num_cu_out) {
     *num_cu_out = cu;
     int best = -1;
     double best_cost = 0;
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 6; ++i) {
+        if (i == 4) continue;  // 256 x 128 with 32-deep K-steps: forced only (the 64-deep form of the same tile always wins)
         const long cst = K % kTileShapes[i][2] ? -1 : tile_cost(M, N, kTileShapes[i][0], kTileShapes[i][1], cu);
         const double w = cst * (kTileShapes[i][2] == 64 ? 0.85 : 1.0);
         if (cst >= 0 && (best < 0 || w < best_cost)) {
@@ -1411,7 +1413,7 @@ static int tile_choice(int M, int N, int K, int* num_cu_out) {
             best_cost = w;
         }
     }
-    if (force_tile >= 0 && force_tile < 5 && K % kTileShapes[force_tile][2] == 0 &&
+    if (force_tile >= 0 && force_tile < 6 && K % kTileShapes[force_tile][2] == 0 &&
         tile_cost(M, N, kTileShapes[force_tile][0], kTileShapes[force_tile][1], cu) >= 0)
         best = force_tile;
     return best;
@@ -1436,6 +1438,7 @@ int launch_gemm_fold(const _Float16* A, const _Float16* W, const float* bias, co
         case 2: return launch_tile<EPI, 256, 128, 4, 2, 64, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
         case 3: return launch_tile<EPI, 128, 192, 2, 4, 64, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
         case 4: return launch_tile<EPI, 256, 128, 4, 2, 32, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
+        case 5: return launch_tile<EPI, 256, 256, 4, 2, 32, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
         default: break;
     }
     if (best != -2) vqa_set_error("launch_gemm_fold: no tile shape for M=%d N=%d K=%d", M, N, K);
@@ -1471,6 +1474,7 @@ int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, const _
             case 2: return launch_tile<EPI, 256, 128, 4, 2, 64>(A, W, bias, R, C, M, N, K, cu, s);
             case 3: return launch_tile<EPI, 128, 192, 2, 4, 64>(A, W, bias, R, C, M, N, K, cu, s);
             case 4: return launch_tile<EPI, 256, 128, 4, 2, 32>(A, W, bias, R, C, M, N, K, cu, s);
+            case 5: return launch_tile<EPI, 256, 256, 4, 2, 32>(A, W, bias, R, C, M, N, K, cu, s);
             default: break;  // no shape divides N / K: the register-staged kernel below
         }
     }
