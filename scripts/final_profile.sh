@@ -19,3 +19,9 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p -- pyth
 grep encoder $O/p.log
 cp $(ls $O/p/*/*kernel_stats.csv | head -1) $O/kernel_stats_packed.csv
 rm -rf $O/d $O/p
+# the real N = 2 path on ONE device (two ranks share cuda:0 over gloo: HIP search + all-gather + HIP merge as one program)
+cd $GRAFT_REPO_ROOT
+VQA_BENCH_SHARE_GPU=1 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
+  bench.py --gpus 2 --docs-per-gpu 5000000 --steps 50 --warmup 10 --e2e-steps 10 2> gpurun_out/r02_two_ranks.err | grep '^{' > gpurun_out/r02_two_ranks_one_gpu.json
+cut -c1-400 gpurun_out/r02_two_ranks_one_gpu.json
+timeout 1500 python scripts/stress_races.py > gpurun_out/r02_race_screen.txt 2>&1; tail -3 gpurun_out/r02_race_screen.txt
