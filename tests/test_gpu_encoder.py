@@ -139,7 +139,9 @@ def test_sequence_packing_matches_the_padded_form(native_lib):
         padded = enc.forward(ids_d, mask_d, pooling=pooling).cpu().numpy()            # device mask, no count: every position
         packed = enc.forward(ids, mask, pooling=pooling).cpu().numpy()                # host mask: counted and packed
         explicit = enc.forward(ids_d, mask_d, pooling=pooling, real_tokens=int(mask.sum())).cpu().numpy()
-        assert np.abs(packed - padded).max() < 1e-6 and np.array_equal(packed, explicit)
+        # packed and padded row counts take different GEMM tile shapes, so the row statistics of the folded LayerNorms are
+        # added up in a different order: a last-bit change of rstd flips the odd fp16 rounding of a stored activation
+        assert np.abs(packed - padded).max() < 2e-4 and np.array_equal(packed, explicit)
         ref = E.encode(w, cfg, ids[:6], mask[:6], pooling=pooling)
         assert _cos(packed[:6], ref).min() > 0.999
     # a mask with a hole is not right-padded: host-side masks fall back to the padded form ...

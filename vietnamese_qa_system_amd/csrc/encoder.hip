@@ -1378,13 +1378,13 @@ static long tile_cost(int M, int N, int BM, int BN, int num_cu) {
 
 // Tile shapes: {BM, BN, BK, WN}.  The cost model is LDS-DMA bytes per CU (rounds of tiles x (BM + BN)): what the K loop is
 // bound by; K-steps of 32 halves pay two barriers per 32-deep step, so a 64-deep shape wins a near tie (x 0.85).
-static const int kTileShapes[6][4] = {{256, 288, 32, 2}, {256, 192, 32, 2}, {256, 128, 64, 2}, {128, 192, 64, 4}, {256, 128, 32, 2},
-                                      {256, 256, 32, 2}};
+static const int kTileShapes[7][4] = {{256, 288, 32, 2}, {256, 192, 32, 2}, {256, 128, 64, 2}, {128, 192, 64, 4}, {256, 128, 32, 2},
+                                      {256, 256, 32, 2}, {128, 128, 64, 2}};
 
 // index into kTileShapes of the LDS-DMA tile kernel's shape for this problem; -1: the problem does not take that kernel
 // (fewer than 1024 rows, or no shape divides N / K); -2: HIP error (message set)
 static int tile_choice(int M, int N, int K, int* num_cu_out) {
-    static const int force_tile = getenv("VQA_GEMM_TILE") ? atoi(getenv("VQA_GEMM_TILE")) : -1;  // dev override: shape index 0..5
+    static const int force_tile = getenv("VQA_GEMM_TILE") ? atoi(getenv("VQA_GEMM_TILE")) : -1;  // dev override: shape index 0..6
     if (!(M >= 1024 && N % 64 == 0 && K % 32 == 0)) return -1;
     static VqaPerDeviceOnce once;
     static int num_cu[64] = {};  // written inside the once, read after it
@@ -1404,7 +1404,7 @@ static int tile_choice(int M, int N, int K, int* num_cu_out) {
     *num_cu_out = cu;
     int best = -1;
     double best_cost = 0;
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < 7; ++i) {
         if (i == 4) continue;  // 256 x 128 with 32-deep K-steps: forced only (the 64-deep form of the same tile always wins)
         const long cst = K % kTileShapes[i][2] ? -1 : tile_cost(M, N, kTileShapes[i][0], kTileShapes[i][1], cu);
         const double w = cst * (kTileShapes[i][2] == 64 ? 0.85 : 1.0);
@@ -1413,7 +1413,7 @@ static int tile_choice(int M, int N, int K, int* num_cu_out) {
             best_cost = w;
         }
     }
-    if (force_tile >= 0 && force_tile < 6 && K % kTileShapes[force_tile][2] == 0 &&
+    if (force_tile >= 0 && force_tile < 7 && K % kTileShapes[force_tile][2] == 0 &&
         tile_cost(M, N, kTileShapes[force_tile][0], kTileShapes[force_tile][1], cu) >= 0)
         best = force_tile;
     return best;
@@ -1439,6 +1439,7 @@ int launch_gemm_fold(const _Float16* A, const _Float16* W, const float* bias, co
         case 3: return launch_tile<EPI, 128, 192, 2, 4, 64, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
         case 4: return launch_tile<EPI, 256, 128, 4, 2, 32, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
         case 5: return launch_tile<EPI, 256, 256, 4, 2, 32, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
+        case 6: return launch_tile<EPI, 128, 128, 4, 2, 64, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
         default: break;
     }
     if (best != -2) vqa_set_error("launch_gemm_fold: no tile shape for M=%d N=%d K=%d", M, N, K);
@@ -1475,6 +1476,7 @@ int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, const _
             case 3: return launch_tile<EPI, 128, 192, 2, 4, 64>(A, W, bias, R, C, M, N, K, cu, s);
             case 4: return launch_tile<EPI, 256, 128, 4, 2, 32>(A, W, bias, R, C, M, N, K, cu, s);
             case 5: return launch_tile<EPI, 256, 256, 4, 2, 32>(A, W, bias, R, C, M, N, K, cu, s);
+            case 6: return launch_tile<EPI, 128, 128, 4, 2, 64>(A, W, bias, R, C, M, N, K, cu, s);
             default: break;  // no shape divides N / K: the register-staged kernel below
         }
     }
