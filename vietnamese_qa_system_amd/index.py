@@ -125,14 +125,21 @@ class DeviceIndex:
                                                      chunk_ids.data_ptr() if chunk_ids is not None else None),
                         "vqa_index_set_rows")
 
-    def get_rows(self, first: int = 0, count: Optional[int] = None) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+    def get_rows(self, first: int = 0, count: Optional[int] = None,
+                 out: Optional[np.ndarray] = None) -> Tuple[np.ndarray, Optional[np.ndarray]]:
         """Stored rows [first, first + count) as a host array [count, d] in the storage type (``float16``, ``float32`` or
         ``uint8`` e4m3 codes of ``16 * x``) and their ids, if the index has an id vector -- the export used by
-        ``Embeddings.save``."""
+        ``Embeddings.save``.  ``out``: a C-contiguous host array of that shape and type to fill (a pinned one makes the
+        device -> host copy a DMA)."""
         if not self._handle.value:
             raise RuntimeError("index is closed")
         count = self.n - first if count is None else int(count)
-        rows = np.empty((count, self.d), dtype=_STORE_NP[self.dtype])
+        if out is not None:
+            if out.shape != (count, self.d) or out.dtype != _STORE_NP[self.dtype] or not out.flags["C_CONTIGUOUS"]:
+                raise ValueError(f"out must be a C-contiguous {_STORE_NP[self.dtype]} array of shape {(count, self.d)}")
+            rows = out
+        else:
+            rows = np.empty((count, self.d), dtype=_STORE_NP[self.dtype])
         ids = np.empty((count,), dtype=np.int64) if self.has_ids else None
         N.check(self._lib.vqa_index_get_rows(self._handle, int(first), count, rows.ctypes.data if count else None,
                                              ids.ctypes.data if ids is not None and count else None), "vqa_index_get_rows")
