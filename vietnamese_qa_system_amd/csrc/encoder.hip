@@ -7,7 +7,7 @@
 //
 // Kernels (all hand-written, fp16 storage, fp32 accumulation / statistics):
 //   embed_ln        word + position + type embeddings -> LayerNorm                      (one wave per token)
-//   gemm_tile<..>   C[M,N] = A[M,K] . W[N,K]^T + bias (+ erf GELU | + residual row) for >= 1024 tokens: persistent, LDS-DMA ring,
+//   gemm_tile<..>   C[M,N] = A[M,K] . W[N,K]^T + bias (+ erf GELU | + residual row) for > 320 tokens: persistent, LDS-DMA ring,
 //                   anti-phase slot K loop, tile shape picked per problem (256x288 / 256x192 / 256x128 / 128x192), 16-byte stores
 //   gemm_skinny     <= 512 tokens (single queries, small batches): weights streamed once, fragments straight from global memory
 //   gemm_nt<EPI>    the shapes in between: v_mfma_f32_16x16x32_f16, 128x128 tiles, register-staged double-buffered LDS image
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const _Float16* __restrict
     }
 }
 
-// ---- GEMM for the large shapes (M >= 1024 tokens): persistent workgroups (one per CU, 8 waves), BM x BN output tiles, operands
+// ---- GEMM for the large shapes (M > 320 tokens, kTileMinM): persistent workgroups (one per CU, 8 waves), BM x BN output tiles, operands
 // go global -> LDS by LDS-DMA in K-steps of 32 halves (64-byte rows, 1 KiB pieces of 16 rows) into a ring of S stages, and the
 // K loop runs in ANTI-PHASE SLOTS -- the structure of the scoring kernel's slot loop (score_topk.hip): two barriers per
 // K-step; in every slot one wave group only multiplies while the other only moves data (reads the fragments of its next
@@ -420,7 +420,7 @@ __device__ __forceinline__ void tile_wait_vmcnt() {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// ---- LayerNorm folded into the GEMMs around it (FOLD = 1; the forward of >= 1024 tokens, encoder_launch).  The post-LN block
+// ---- LayerNorm folded into the GEMMs around it (FOLD = 1; every forward that runs on the tile kernel, encoder_launch).  The post-LN block
 // h = LN(y) feeds (a) the next GEMM and (b) the next residual add.  Both can start from the RAW sum y and the row's mean /
 // variance:  (a)  LN(y) . W^T = rstd (y . (gamma (.) W)^T) - rstd mean colsum(gamma (.) W) + beta . W^T  -- the GEMM runs on y
 // with the weights scaled by gamma at create time (Wf, cvec = its column sums as stored in fp16, bias' = bias + W beta) and
@@ -1376,6 +1376,12 @@ static long tile_cost(int M, int N, int BM, int BN, int num_cu) {
     return (tiles + num_cu - 1) / num_cu * (BM + BN);
 }
 
+// Token counts: up to kSkinnyMax the skinny kernel (it splits K over its waves: 0.47 ms per 12-layer forward at 32 tokens,
+// 0.79 at 256), above it the LDS-DMA tile kernel, whose forward takes a flat ~0.99 ms up to 1024 tokens (a tile walks all of
+// K at ~0.9 us per K-step however few rows it has); measured crossover 320 tokens (B = 10 at L = 32).
+constexpr int kSkinnyMax = 320;
+constexpr int kTileMinM = kSkinnyMax + 1;
+
 // Tile shapes: {BM, BN, BK, WN}.  The cost model is LDS-DMA bytes per CU (rounds of tiles x (BM + BN)): what the K loop is
 // bound by; K-steps of 32 halves pay two barriers per 32-deep step, so a 64-deep shape wins a near tie (x 0.85).
 static const int kTileShapes[7][4] = {{256, 288, 32, 2}, {256, 192, 32, 2}, {256, 128, 64, 2}, {128, 192, 64, 4}, {256, 128, 32, 2},
@@ -1385,7 +1391,8 @@ static const int kTileShapes[7][4] = {{256, 288, 32, 2}, {256, 192, 32, 2}, {256
 // (fewer than 1024 rows, or no shape divides N / K); -2: HIP error (message set)
 static int tile_choice(int M, int N, int K, int* num_cu_out) {
     static const int force_tile = getenv("VQA_GEMM_TILE") ? atoi(getenv("VQA_GEMM_TILE")) : -1;  // dev override: shape index 0..6
-    if (!(M >= 1024 && N % 64 == 0 && K % 32 == 0)) return -1;
+    static const int tile_min_m = getenv("VQA_TILE_MIN_M") ? atoi(getenv("VQA_TILE_MIN_M")) : kTileMinM;  // dev override
+    if (!(M >= tile_min_m && N % 64 == 0 && K % 32 == 0)) return -1;
     static VqaPerDeviceOnce once;
     static int num_cu[64] = {};  // written inside the once, read after it
     int dev = 0;
@@ -1450,7 +1457,7 @@ template <int EPI>
 int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, const _Float16* R, _Float16* C, int M, int N, int K,
                 hipStream_t s) {
     static const bool force_small = getenv("VQA_GEMM_SMALL") != nullptr;  // dev override, read once
-    static const int skinny_max = getenv("VQA_SKINNY_MAX") ? atoi(getenv("VQA_SKINNY_MAX")) : 512;  // dev override; measured crossover with the 128 x 128 kernel ~ 700 tokens
+    static const int skinny_max = getenv("VQA_SKINNY_MAX") ? atoi(getenv("VQA_SKINNY_MAX")) : kSkinnyMax;  // dev override
     if (M <= skinny_max && N % 16 == 0 && K % 256 == 0 && !force_small) {
         const int mt = M >= 64 ? 4 : (M + 15) / 16;
         const int chunks = (M + 16 * mt - 1) / (16 * mt);
@@ -1653,7 +1660,7 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
     const int row_blocks = (T + 3) / 4;
     // CLS pooling of a large batch: the last layer's out-projection / FFN / LayerNorms only on the first-token rows (below);
     // small calls are launch-bound and keep the plain sequence (VQA_ENC_FIRST_ROWS=0 at create: dev / test switch)
-    const bool first_rows_only = e->first_rows_on && pooling == VQA_POOL_CLS && T >= 1024 && T >= 2 * B && H % 8 == 0 && !e->layers.empty() &&
+    const bool first_rows_only = e->first_rows_on && pooling == VQA_POOL_CLS && T >= kTileMinM && T >= 2 * B && H % 8 == 0 && !e->layers.empty() &&
                                  (size_t)B * (3 * H + F) <= (size_t)e->max_tokens * F;  // the scratch fits the FFN array
     if (packed) {
         hipLaunchKernelGGL(pack_kernel, dim3(1), dim3(256), 0, s, attn_mask, B, L, real_tokens, e->cu, e->row_seq, e->bad_ids_dev);
