@@ -293,6 +293,8 @@ struct LaunchPlan {
     int grid0 = 0;  // its workgroups (a few tiles each)
     int grid1 = 0;  // workgroups of the main pass
     int stage_tiles = 0;  // two-stage search (k <= 12, large shards): tiles of the FIRST stage, 0 = one stage
+    int seeds_per_tile = 2;  // 8 for shards of fewer than 24 tiles (a 1000-row shard has 4: 8 seeds per query would leave the
+                             // thresholds at -inf and every list flooding: 0.43 ms per search instead of 0.08)
 };
 
 static LaunchPlan plan_launch(const vqa_index* ix) {
@@ -310,7 +312,13 @@ static LaunchPlan plan_launch(const vqa_index* ix) {
         int want = ix->seed_mult * ix->max_grid;
         const int div = ix->seed_div;
         if (div > 0 && want > p.tiles / div) want = p.tiles / div > 0 ? p.tiles / div : 1;
+        // ... but never fewer than 24 (or all there are): a tile gives 2 seeds per query, and with fewer than k of them the
+        // threshold stays at -inf and every workgroup floods its lists on its first tile -- a 20 000-row shard (79 tiles,
+        // 4 seed tiles by the 1/16 rule) spent 0.39 ms there, 4x what a 65 536-row shard takes
+        const int floor_tiles = 24;
+        if (want < floor_tiles) want = floor_tiles;
         p.seed_tiles = p.tiles < want ? p.tiles : want;
+        if (p.seed_tiles < floor_tiles) p.seeds_per_tile = 8;
         p.grid0 = p.seed_tiles < ix->max_grid ? p.seed_tiles : ix->max_grid;
         // Two stages: a workgroup only knows its own rows and the seeds, so ~5 candidates per tile pass its threshold test
         // and the epilogue's rare path costs 4.4 % of the scan.  The first stage_pct % of the tiles are
@@ -433,10 +441,11 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             a.tile_end = p.seed_tiles;
             a.grid = p.grid0;
             a.seed_only = true;
+            a.seeds_per_tile = p.seeds_per_tile;
             VQA_HIP_CHECK(hipMemsetAsync(ix->wide_flag, 0, sizeof(int), stream));
             rc = vqa_launch_score_topk(ix->dtype, a, stream);
             if (rc != VQA_OK) return rc;
-            rc = vqa_launch_merge_partials(ix->partial, p.seed_tiles, vqa_score_topk_seeds_per_tile(), nq, k, nullptr, 0, nullptr,
+            rc = vqa_launch_merge_partials(ix->partial, p.seed_tiles, p.seeds_per_tile, nq, k, nullptr, 0, nullptr,
                                            nullptr, nullptr, ix->thr0, 1.0f, k, 0, nullptr, true, nullptr, stream);
             if (rc != VQA_OK) return rc;
             a.thr_init = ix->thr0;
@@ -473,9 +482,10 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
                 a.tile_end = p.seed_tiles;
                 a.grid = p.grid0;
                 a.seed_only = true;
+                a.seeds_per_tile = p.seeds_per_tile;
                 rc = vqa_launch_score_topk(ix->dtype, a, stream);
                 if (rc != VQA_OK) return rc;
-                rc = vqa_launch_merge_partials(ix->partial, p.seed_tiles, vqa_score_topk_seeds_per_tile(), nq, kk, nullptr, 0, nullptr,
+                rc = vqa_launch_merge_partials(ix->partial, p.seed_tiles, p.seeds_per_tile, nq, kk, nullptr, 0, nullptr,
                                                nullptr, nullptr, ix->thr0, 1.0f, kk, 0, nullptr, true, gate, stream);
                 if (rc != VQA_OK) return rc;
             }

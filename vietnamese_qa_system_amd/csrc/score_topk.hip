@@ -132,7 +132,7 @@ constexpr int kLdsTotal = 160 * 1024;
 constexpr int kCap = (kLdsTotal - kPipeBytes - 2 * kQ * 4) / (kQ * 8);  // 15 candidate slots per query
 constexpr int kExt = kOperandBytes / (kQ * 8);                           // 8 more in the idle X stage during an epilogue
 constexpr int kMaxK = kCap - 3;                                         // 12
-constexpr int kSeedsPerTile = 2;  // seed pass: sub-maxima kept per query and tile (one per row half)
+constexpr int kSeedsPerTile = 2;  // seed pass: sub-maxima kept per query and tile (one per row half; 8, one per 32 rows, for tiny shards)
 static_assert(kPipeBytes <= 144 * 1024, "ring sizes");
 
 constexpr int kOverBit = 1 << 30;  // "an append was refused" flag, kept in bit 30 of cnt[0] (LDS is fully used)
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
                                                               const vqa_key* __restrict__ upper,
                                                               vqa_key* __restrict__ out, long long N, int KT, int nq, int k,
                                                               int tile_begin, int tile_end, const int* __restrict__ gate,
-                                                              int row_lists, int list_offset) {
+                                                              int row_lists, int list_offset, int seeds) {
     // gated launch (fallback passes of a large-k search, capi.hip): nothing to do when the one-pass result was verified
     if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -549,6 +549,10 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
                     }
                 }
             vqa_key key = (m > -INFINITY && q < nq) ? vqa_make_key(m, row0 + (uint32_t)arg) : 0ull;
+            if (seeds == 8) {  // one seed per 32-row group: this lane's own maximum
+                out[((size_t)q * seed_tiles + tile_local) * 8 + wm * 4 + g] = key;
+                continue;
+            }
             // max over the four lane groups g that hold the other rows of this query (lanes c, c + 16, c + 32, c + 48)
             vqa_key o = __shfl_xor(key, 16, 64);
             key = o > key ? o : key;
@@ -1080,7 +1084,8 @@ static int launch_dt(const ScoreTopkArgs& a, int KT, int lds, hipStream_t stream
     if (rc != VQA_OK) return rc;
     auto kern = a.seed_only ? score_topk_kernel<0, DT> : a.first_stage ? score_topk_kernel<1, DT, 1> : score_topk_kernel<1, DT>;
     hipLaunchKernelGGL(kern, dim3(a.grid), dim3(kThreads), lds, stream, a.x, a.q, a.thr_init, a.upper, a.partial, (long long)a.n,
-                       KT, a.nq, a.k, a.tile_begin, a.tile_end, a.gate, a.row_lists > 0 ? a.row_lists : a.grid, a.list_offset);
+                       KT, a.nq, a.k, a.tile_begin, a.tile_end, a.gate, a.row_lists > 0 ? a.row_lists : a.grid, a.list_offset,
+                       a.seeds_per_tile);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }
@@ -1093,6 +1098,7 @@ int vqa_launch_score_topk(int dtype, const ScoreTopkArgs& a, hipStream_t stream)
     VQA_REQUIRE(a.k >= 1 && a.k <= kMaxK, "score_topk: k=%d outside [1, %d]", a.k, kMaxK);
     VQA_REQUIRE(a.nq >= 1 && a.nq <= kQ, "score_topk: nq=%d outside [1, %d]", a.nq, kQ);
     VQA_REQUIRE(a.grid >= 1 && a.tile_end > a.tile_begin, "score_topk: empty launch");
+    VQA_REQUIRE(a.seeds_per_tile == 2 || a.seeds_per_tile == 8, "score_topk: %d seeds per tile", a.seeds_per_tile);
     VQA_REQUIRE(a.grid <= a.tile_end - a.tile_begin, "score_topk: %d workgroups for %d tiles (every workgroup needs a tile)", a.grid,
                 a.tile_end - a.tile_begin);
     const int lds = vqa_score_topk_lds_bytes(dtype, a.k);
