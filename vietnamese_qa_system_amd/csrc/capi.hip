@@ -297,7 +297,7 @@ struct LaunchPlan {
                              // thresholds at -inf and every list flooding: 0.43 ms per search instead of 0.08)
 };
 
-static LaunchPlan plan_launch(const vqa_index* ix) {
+static LaunchPlan plan_launch(const vqa_index* ix, int k = 0) {
     LaunchPlan p;
     p.tiles = (int)((ix->n + 255) / 256);
     p.grid1 = p.tiles < ix->max_grid ? p.tiles : ix->max_grid;
@@ -317,8 +317,10 @@ static LaunchPlan plan_launch(const vqa_index* ix) {
         // 4 seed tiles by the 1/16 rule) spent 0.39 ms there, 4x what a 65 536-row shard takes
         const int floor_tiles = 24;
         if (want < floor_tiles) want = floor_tiles;
+        // a large k on a small shard: the threshold is the k-th largest seed, so there must be k of them
+        if (2 * want < k) want = (k + 1) / 2;
         p.seed_tiles = p.tiles < want ? p.tiles : want;
-        if (p.seed_tiles < floor_tiles) p.seeds_per_tile = 8;
+        if (p.seed_tiles < floor_tiles || 2 * p.seed_tiles < k) p.seeds_per_tile = 8;
         p.grid0 = p.seed_tiles < ix->max_grid ? p.seed_tiles : ix->max_grid;
         // Two stages: a workgroup only knows its own rows and the seeds, so ~5 candidates per tile pass its threshold test
         // and the epilogue's rare path costs 4.4 % of the scan.  The first stage_pct % of the tiles are
@@ -338,7 +340,7 @@ static LaunchPlan plan_launch(const vqa_index* ix) {
 
 extern "C" int vqa_index_launch_info(const vqa_index* ix, int32_t B, int32_t k, vqa_launch_info* out) {
     VQA_REQUIRE(ix && out, "vqa_index_launch_info: null pointer");
-    const LaunchPlan p = plan_launch(ix);
+    const LaunchPlan p = plan_launch(ix, k);
     (void)B;
     out->grid = p.grid1;
     out->block = 512;
@@ -399,7 +401,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
     VQA_REQUIRE(busy.ok, "vqa_index_search: this index handle is in use by another host thread (one call at a time per handle)");
     DeviceGuard guard(ix->device);
     const int qeb = q_dtype == VQA_F32 ? 4 : 2;
-    const LaunchPlan p = plan_launch(ix);
+    const LaunchPlan p = plan_launch(ix, k);
     for (int q0 = 0; q0 < B; q0 += VQA_QUERY_TILE) {
         const int nq = B - q0 < VQA_QUERY_TILE ? B - q0 : VQA_QUERY_TILE;
         float* os = out_scores + (size_t)q0 * k;
