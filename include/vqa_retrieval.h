@@ -155,7 +155,7 @@ int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encoder_config* 
 void vqa_encoder_destroy(vqa_encoder* enc);
 /* input_ids, attn_mask: [B, L] int32 device.  out: [B, hidden] fp32 device.
  * real_tokens: 0 = unknown (every one of the B * L positions is computed), else the number of set mask entries of a
- * RIGHT-PADDED mask (mask[b][l] = 1 exactly for l < n_b, n_b >= 1): calls of more than 4096 positions then compute only those
+ * RIGHT-PADDED mask (mask[b][l] = 1 exactly for l < n_b, n_b >= 1): calls of more than 1024 positions then compute only those
  * rows (sequence packing; the results of the real tokens are identical, padding keys carry zero attention weight either
  * way).  A mask that is not right-padded, or holds more set entries than announced, invalidates that call's output and makes
  * the NEXT vqa_encoder_forward on the handle fail with VQA_EINVAL.

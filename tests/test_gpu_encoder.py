@@ -76,7 +76,7 @@ def test_baseline_config1_encoder_batch_at_full_size(native_lib):
 
 
 def test_small_batches_replay_a_graph(native_lib):
-    """B * L <= 4096 tokens: the first call of a shape runs eagerly, the second captures a hipGraph over the encoder's
+    """B * L <= 1024 tokens: the first call of a shape runs eagerly, the second captures a hipGraph over the encoder's
     staging buffers, later ones replay it -- every call must see ITS inputs and agree with the oracle."""
     from vietnamese_qa_system_amd.encoder import QuestionEncoder
     cfg = dict(E.PHOBERT_BASE, layers=2)

@@ -1379,6 +1379,7 @@ static long tile_cost(int M, int N, int BM, int BN, int num_cu) {
 // Token counts: up to kSkinnyMax the skinny kernel (it splits K over its waves: 0.47 ms per 12-layer forward at 32 tokens,
 // 0.79 at 256), above it the LDS-DMA tile kernel, whose forward takes a flat ~0.99 ms up to 1024 tokens (a tile walks all of
 // K at ~0.9 us per K-step however few rows it has); measured crossover 320 tokens (B = 10 at L = 32).
+constexpr int kGraphMaxTokens = 1024;  // calls up to this many positions replay a hipGraph (vqa_encoder_forward)
 constexpr int kSkinnyMax = 320;
 constexpr int kTileMinM = kSkinnyMax + 1;
 
@@ -1792,10 +1793,12 @@ extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, con
     DevGuard guard(e->device);
     const int T = B * L;
     // Launch-bound sizes replay a captured graph (unless the caller's stream is itself being captured: then the kernels
-    // simply join the caller's capture).
+    // simply join the caller's capture).  Above 1024 tokens the kernels are long enough for eager launches to stay ahead of
+    // the GPU (graph = eager: 1.10 / 1.28 / 1.41 ms at 2048 / 3072 / 4096 tokens), and eager calls can pack a ragged batch
+    // (1.02 / 1.11 / 1.17 ms at the SURVEY's length distribution).
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);
-    if (!e->use_graphs || T > 4096 || cap != hipStreamCaptureStatusNone)
+    if (!e->use_graphs || T > kGraphMaxTokens || cap != hipStreamCaptureStatusNone)
         return encoder_launch(e, input_ids, attn_mask, B, L, real_tokens, pooling, normalize, out, s);
     // (launch-bound sizes replay a graph of the padded form: a graph is keyed by shape, a packed row count is not one)
     vqa_encoder::Graph* gr = nullptr;
