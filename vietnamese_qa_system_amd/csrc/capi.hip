@@ -40,7 +40,8 @@ struct vqa_index {
     bool two_pass = true;
     int seed_mult = 2;  // seed pass covers seed_mult * CUs tiles (VQA_SEED_MULT = 1..4)
     int seed_div = 16;  // ... but at most 1 / seed_div of the shard's tiles (VQA_SEED_DIV: dev override, 0 = no cap)
-    int stage_min_tiles = 40;  // two-stage search when the shard has at least this many tiles per workgroup (VQA_STAGE_MIN: dev /
+    int stage_min_tiles = 24;  // two-stage search when the shard has at least this many tiles per workgroup (1.6M rows: measured
+                               // crossover between 1M rows, +1 % step time, and 2M rows, -2 %; VQA_STAGE_MIN: dev /
                                // test override, 0 disables); the first stage takes stage_pct % of the tiles (VQA_STAGE_PCT)
     int stage_pct = 10;
     // workspace (allocated once; search never allocates)
