@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VQA_VERSION 102 /* 0.1.2: vqa_encoder_forward takes real_tokens; vqa_launch_info.seed_tiles, .first_stage_rows */
+#define VQA_VERSION 103 /* 0.1.3: vqa_launch_info reports the fused seed / stage merges; host rows upload through pinned staging */
 
 /* error codes */
 #define VQA_OK 0
@@ -157,8 +157,9 @@ void vqa_encoder_destroy(vqa_encoder* enc);
  * real_tokens: 0 = unknown (every one of the B * L positions is computed), else the number of set mask entries of a
  * RIGHT-PADDED mask (mask[b][l] = 1 exactly for l < n_b, n_b >= 1): calls of more than 1024 positions then compute only those
  * rows (sequence packing; the results of the real tokens are identical, padding keys carry zero attention weight either
- * way).  A mask that is not right-padded, or holds more set entries than announced, invalidates that call's output and makes
- * the NEXT vqa_encoder_forward on the handle fail with VQA_EINVAL.
+ * way).  A mask that is not right-padded, or whose number of set entries differs from real_tokens (more: rows would be
+ * dropped; fewer: the GEMMs would run on stale workspace rows), invalidates that call's output and makes the NEXT
+ * vqa_encoder_forward on the handle fail with VQA_EINVAL.
  * Token ids outside [0, vocab_size) never index the embedding table: they are embedded as pad_id and a host-visible flag
  * is raised, which makes the NEXT vqa_encoder_forward on the handle fail with VQA_EINVAL (the call that saw them cannot
  * report it without a synchronisation). */

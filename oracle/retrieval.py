@@ -95,6 +95,22 @@ def e4m3_encode(x: np.ndarray) -> np.ndarray:
     return code.astype(np.uint8)
 
 
+def e4m3_encode_fast(x: np.ndarray) -> np.ndarray:
+    """The same conversion as :func:`e4m3_encode`, written on the fp32 bit patterns (a handful of integer passes instead of
+    float64 logarithms: ~20x faster; ``tests/test_oracle.py`` holds the two equal on every binade boundary and on random
+    data).  Normal range: the code is the fp32 pattern re-biased by 120 exponent steps and rounded to nearest even on the 20
+    dropped mantissa bits (the carry walks into the exponent by itself); below 2^-6: round(|x| * 2^9) sub-steps."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    u = x.view(np.uint32)
+    a = u & np.uint32(0x7FFFFFFF)
+    norm = ((a - np.uint32(120 << 23)) + np.uint32(0x7FFFF) + ((a >> np.uint32(20)) & np.uint32(1))) >> np.uint32(20)
+    small = a < np.uint32(121 << 23)
+    sub = np.rint(np.where(small, np.abs(x), np.float32(0)) * np.float32(512.0)).astype(np.uint32)  # exact scaling, half to even
+    code = np.where(small, sub, np.minimum(norm, np.uint32(0x7E)))
+    code |= (u >> np.uint32(24)) & np.uint32(0x80)
+    return np.where(a > np.uint32(0x7F800000), np.uint32(0x7F), code).astype(np.uint8)  # NaN: one code, as e4m3_encode
+
+
 def quantize_rows(x: np.ndarray, dtype: int) -> np.ndarray:
     """fp32 rows -> the values the index stores, returned in their storage representation
     (float32 / float16 arrays, uint8 e4m3 codes)."""

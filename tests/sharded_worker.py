@@ -1,10 +1,15 @@
-"""One rank of the job tests/test_gpu_sharded_exec.py starts with ``python -m torch.distributed.run --nproc-per-node 2``.
+"""One rank of the jobs tests/test_gpu_sharded_exec.py and tests/test_gpu_rccl_world1.py start with
+``python -m torch.distributed.run --nproc-per-node R`` (R = 1, 2 or 8).
 
 Runs the REAL sharded path -- DeviceIndex.search (HIP) -> dist.all_gather_into_tensor -> vqa_merge_topk (HIP) -- and
 asserts on every rank that the result equals, bit for bit, the single-shard search of the concatenated corpus on the
-same device: cross-shard exact ties, a shard shorter than k, string ids, k > 12, the per-rank-slice build and the
-sharded save -> load round trip.  ``--share`` puts both ranks on cuda:0 (gloo, since RCCL refuses two ranks on one
-device); without it every rank takes its own GPU over nccl (= RCCL).
+same device and in the same storage type (fp16, fp8 e4m3, fp32): exact ties on both sides of and straddling every shard
+boundary, a row count the world size does not divide, ranks with fewer rows than k, an id vector, string ids, k > 12,
+the R * k = 8192 limit of the merge (8 ranks x 1024 candidates: what a hybrid search at limit >= 103 asks for), the
+per-rank-slice build, the row-producer build and the sharded save -> load round trip (fp16 and fp8).
+``--share`` puts every rank on cuda:0 (gloo, since RCCL refuses two ranks on one device); without it every rank takes its
+own GPU over nccl (= RCCL).  A world of ONE rank over nccl with VQA_ALWAYS_GATHER=1 takes every collective call of the
+path through RCCL on a 1-GPU box.
 """
 import argparse
 import json
@@ -43,13 +48,14 @@ def main():
     from vietnamese_qa_system_amd.sharded import shard_bounds
 
     checks = []
+    collective = world > 1 or os.environ.get("VQA_ALWAYS_GATHER") == "1"
 
     def unit(rng, n, d):
         v = rng.standard_normal((n, d)).astype(np.float32)
         return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float16)
 
-    def single(x16, ids, q, k, id_base=0):
-        ix = DeviceIndex(x16, ids=ids, id_base=id_base, dtype="fp16", device=dev_index)
+    def single(x16, ids, q, k, id_base=0, dtype="fp16"):
+        ix = DeviceIndex(x16, ids=ids, id_base=id_base, dtype=dtype, device=dev_index)
         s, i, _ = ix.search(q, k)
         torch.cuda.synchronize()
         out = s.clone(), i.clone()
@@ -57,19 +63,26 @@ def main():
         return out
 
     def compare(name, emb, q, k, ref):
+        before = emb._searcher.collectives
         s, i = emb._searcher.search(q, k)
         torch.cuda.synchronize()
         assert torch.equal(i, ref[1]), f"{name}: ids differ on rank {rank}"
         assert torch.equal(s, ref[0]), f"{name}: scores differ on rank {rank}"
+        assert emb._searcher.collectives == before + (1 if collective else 0), f"{name}: the all-gather did not run"
         checks.append(name)
 
     rng = np.random.default_rng(5)
-    n, d, b, k = 6001, 96, 37, 10
+    n, d, b, k = 6001, 96, 37, 10  # 6001 = 8 * 750 + 1: ragged over 2 and over 8 ranks
     x = unit(rng, n, d)
-    lo1, _ = shard_bounds(n, world, world - 1)
-    x[lo1 + 999] = x[10]           # exact duplicates on both sides of the shard boundary: equal scores, order by position
+    bounds = [shard_bounds(n, world, r) for r in range(world)]
+    lo1 = bounds[-1][0]
+    x[(lo1 + 999) % n] = x[10]     # exact duplicates in the first and the last shard: equal scores, order by position
     x[n - 2] = x[10]
-    x[lo1 - 1] = x[lo1] = x[77]    # ... and straddling it
+    # ... and a run of three equal rows straddling EVERY shard boundary (up to three boundaries with 4+ ranks): the tie
+    # group of query 1 then spans every pair of neighbouring shards
+    straddle = sorted({lo for lo, _ in bounds[1:4] if lo > 0})
+    for lo in straddle:
+        x[lo - 1] = x[lo] = x[lo + 1] = x[77]
     q16 = unit(rng, b, d)
     q16[0], q16[1] = x[10], x[77]  # the duplicate groups lead these queries' results
     q = torch.from_numpy(q16).to(device)
@@ -81,16 +94,22 @@ def main():
     ref = single(x, ids, q, k)
     compare("id-vector", emb, q, k, ref)
     dup = ref[1][0, :3].cpu().numpy().tolist()
-    assert dup == [int(ids[10]), int(ids[lo1 + 999]), int(ids[n - 2])], dup  # the tie group, by global row position
+    assert dup == sorted(int(ids[p]) for p in {10, (lo1 + 999) % n, n - 2}), dup  # the tie group, by global row position
+    if straddle:
+        rows77 = sorted({77} | {p for lo in straddle for p in (lo - 1, lo, lo + 1)})
+        got77 = ref[1][1, :len(rows77)].cpu().numpy().tolist()
+        assert got77 == [int(ids[p]) for p in rows77][:len(got77)], got77
     # the txtai-shaped call returns the same thing on every rank
     res = emb.batchsearch(q16[:4].astype(np.float32), 5)
     assert [r[0] for r in res[0][:3]] == dup
-    # 1b. pipelined batches: the all-gather of batch i runs under the scan of batch i + 1; results equal per-batch search
-    batches = [q, q[:5], torch.from_numpy(unit(rng, 64, d)).to(device), q]
+    # 1b. pipelined batches: the all-gather of batch i runs under the scan of batch i + 1; results equal per-batch search.
+    #     Six distinct (B, k) shapes in a row: the buffer pools must survive them without dropping a slot in flight.
+    batches = [q, q[:5], torch.from_numpy(unit(rng, 64, d)).to(device), q, q[:7], q[:9], q[:11], q[:13]]
     want = [tuple(t.clone() for t in emb._searcher.search(bq, k)) for bq in batches]
     got = emb._searcher.search_pipelined(batches, k)
     torch.cuda.synchronize()
     assert len(got) == len(want) and all(torch.equal(g[0], w[0]) and torch.equal(g[1], w[1]) for g, w in zip(got, want))
+    assert len(emb._searcher._pools) <= 2
     checks.append("pipelined")
     # 2. k > 12 (one-pass wide search per shard + merge of R * k candidates)
     compare("k=300", emb, q, 300, single(x, ids, q, 300))
@@ -100,7 +119,7 @@ def main():
     emb2 = Embeddings(device=dev_index, min_score=None).load(path)
     compare("save-load", emb2, q, k, ref)
     assert emb2.load_stats["bytes"] == (shard_bounds(n, world, rank)[1] - shard_bounds(n, world, rank)[0]) * d * 2
-    # 4. per-rank slices only (no rank holds the whole corpus), contiguous positions as ids
+    # 4. per-rank slices only (no rank holds the whole corpus), contiguous positions as ids; total by all_reduce
     lo, hi = shard_bounds(n, world, rank)
     emb3 = Embeddings(dtype="fp16", device=dev_index, min_score=None)
     emb3.index_vectors(None, x[lo:hi], local=True)
@@ -109,7 +128,8 @@ def main():
     emb4 = Embeddings(dtype="fp16", device=dev_index, min_score=None)
     emb4.index_vectors(None, lambda a, c: x[a:c], total=n, chunk_rows=1000)
     compare("producer", emb4, q, k, single(x, None, q, k, id_base=0))
-    # 6. a shard shorter than k: 15 rows over the ranks, k = 10 (padding candidates (-inf, -1) take part in the merge)
+    # 6. shards shorter than k: 15 rows over the ranks, k = 10 (padding candidates (-inf, -1) take part in the merge);
+    #    with 8 ranks every shard holds one or two rows
     xs = unit(rng, 15, d)
     emb5 = Embeddings(dtype="fp16", device=dev_index, min_score=None)
     emb5.index_vectors(list(range(1, 16)), xs)  # contiguous ids: id_base path
@@ -128,9 +148,66 @@ def main():
     assert [[t[0] for t in row] for row in r7] == (pos + 100).tolist()
     checks.append("reindex")
 
+    # 8. the other storage types of BASELINE configs[1] / configs[4] through shard -> gather -> merge: bit-equal to the
+    #    single-shard search of the same storage type (a row's score does not depend on the shard it sits in)
+    for dt in ("fp8", "fp32"):
+        e = Embeddings(dtype=dt, device=dev_index, min_score=None)
+        e.index_vectors(ids.tolist(), x)
+        r_dt = single(x, ids, q, k, dtype=dt)
+        compare(f"{dt}-shards", e, q, k, r_dt)
+        compare(f"{dt}-k=40", e, q, 40, single(x, ids, q, 40, dtype=dt))
+        if dt == "fp8":
+            # scores of an fp8 index come back divided by 256 (rows and queries are stored as e4m3(16 x)); the duplicate
+            # group still leads query 0, by position
+            assert r_dt[1][0, :3].cpu().numpy().tolist() == dup
+            # sharded save of an fp8 index (codes -> exactly representable fp16) -> load re-encodes the very same codes
+            p8 = os.path.join(args.out, "saved_fp8")
+            e.save(p8)
+            e2 = Embeddings(device=dev_index, min_score=None).load(p8)
+            assert e2.dtype == "fp8"
+            compare("fp8-save-load", e2, q, k, r_dt)
+        e._index.close()
+
+    # 9. the merge at its R * k limit: 1024 candidates per rank (what hybrid search asks for from limit = 103 on) -- at 8
+    #    ranks R * k = 8192 = the documented maximum of vqa_merge_topk; shards of 750 rows pad their lists with (-inf, -1)
+    n2 = 20011
+    x2 = unit(rng, n2, 64)
+    q2 = torch.from_numpy(unit(rng, 5, 64)).to(device)
+    e9 = Embeddings(dtype="fp16", device=dev_index, min_score=None)
+    e9.index_vectors(None, x2)
+    compare("k=1024", e9, q2, 1024, single(x2, None, q2, 1024))
+    compare("k=1024-short-shards", emb, q[:3], 1024, single(x, ids, q[:3], 1024))
+    e9._index.close()
+    # ... and through the hybrid (dense + BM25) entry point that produces such a k: index(documents) with a text encoder
+    # (every rank encodes only its own shard: the row-producer path), batchsearch(list[str], limit = 103)
+    texts = [f"tok{j} grp{j % 13} fam{j % 101}" for j in range(n2)]
+    vec_of = {t: x2[j].astype(np.float32) for j, t in enumerate(texts)}
+    qtexts = [f"grp{3} fam{7}", f"tok{55} fam{55}"]
+    for t_ in qtexts:
+        vec_of[t_] = x2[len(vec_of) % n2].astype(np.float32)
+    calls = []
+
+    def fake_encoder(ts):
+        calls.append(len(ts))
+        return torch.from_numpy(np.stack([vec_of[t] for t in ts]))
+
+    eh = Embeddings(hybrid=True, dtype="fp16", device=dev_index, encoder=fake_encoder)
+    eh.index([{"id": j + 1, "text": t} for j, t in enumerate(texts)], batch_size=500)
+    lo2, hi2 = shard_bounds(n2, world, rank)
+    assert sum(calls) <= (hi2 - lo2) + 1, (sum(calls), hi2 - lo2)  # this rank encoded its own rows only (+ the shape probe)
+    before = eh._searcher.collectives
+    rh = eh.batchsearch(qtexts, 103)
+    assert eh._searcher.collectives == before + (1 if collective else 0)
+    assert all(0 < len(r) <= 103 for r in rh) and all(r[j][1] >= r[j + 1][1] for r in rh for j in range(len(r) - 1))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, [[t[0] for t in r] for r in rh])
+    assert all(g == gathered[0] for g in gathered), "hybrid results differ between ranks"
+    checks.append("hybrid-limit-103")
+
     dist.barrier()
     with open(os.path.join(args.out, f"rank{rank}.json"), "w") as f:
-        json.dump({"rank": rank, "world": world, "backend": args.backend, "device": dev_index, "checks": checks}, f)
+        json.dump({"rank": rank, "world": world, "backend": args.backend, "device": dev_index, "checks": checks,
+                   "collectives": emb._searcher.collectives}, f)
     dist.destroy_process_group()
 
 

@@ -56,3 +56,25 @@ def test_bench_two_ranks_sharing_the_device(native_lib):
     assert r["n_gpus"] == 2 and r["config"]["docs_total"] == 400000 and r["scaling"] == "weak"
     assert r["recall_at_10"] == 1.0 and "cpu_baseline" not in r  # the CPU baseline is an N = 1 leg
     assert r["roofline"]["launches"] == 4 and r["end_to_end"]["value"] > 0
+
+
+def test_bench_eight_ranks_sharing_the_device(native_lib):
+    """The world size of BASELINE configs[3] / configs[4] as the driver would launch it on an 8-GPU node, with all eight ranks
+    on cuda:0 (gloo): 8 x 200 000 rows, rank-strided merge of 8 candidate blocks, max-over-ranks timing, one JSON line."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, VQA_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--docs-per-gpu",
+                          "200000", "--steps", "4", "--warmup", "2", "--verify-queries", "4", "--e2e-steps", "2"],
+                         capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 8 and r["config"]["docs_total"] == 1600000 and r["scaling"] == "weak"
+    assert r["config"]["parallelism"] == "row-shard x8" and r["recall_at_10"] == 1.0 and "cpu_baseline" not in r
+    assert r["roofline"]["launches"] == 4 and r["end_to_end"]["value"] > 0
+    assert r["pipelined"]["value"] > 0 and r["pipelined"]["batches"] >= 2

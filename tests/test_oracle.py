@@ -158,3 +158,22 @@ def test_oracle_against_same_stored_fp64_golden(golden_dir, key, dtype):
     gaps = exp_sc[:, :-1] - exp_sc[:, 1:]
     clear = (gaps[:, :10] > 1e-9) & np.concatenate([np.ones((gaps.shape[0], 1), bool), gaps[:, :9] > 1e-9], axis=1)
     assert np.array_equal(p[clear], exp_pos[:, :10][clear]) and clear.mean() > 0.99
+
+
+def test_fast_e4m3_encoder_equals_the_reference_definition():
+    """oracle.e4m3_encode_fast (integer passes on the fp32 bits; what bench.py uses over millions of rows) against
+    oracle.e4m3_encode (the float64 definition pinned to torch's codec above): every code point, every midpoint between
+    neighbouring code points and its two fp32 neighbours (round half to even), the saturation edge, non-finite values, and
+    random data over 27 binades."""
+    tab = R.e4m3_decode(np.arange(256, dtype=np.uint8)).astype(np.float64)
+    pos = np.sort(tab[np.isfinite(tab) & (tab >= 0)])
+    mids = ((pos[:-1] + pos[1:]) / 2).astype(np.float32)
+    pts = np.concatenate([pos.astype(np.float32), mids, np.nextafter(mids, np.float32(0)), np.nextafter(mids, np.float32(1e9)),
+                          np.array([448, 449, 463.9, 464, 464.1, 480, 500, 1e9, np.inf, np.nan, 1e-10, 0.0, 2 ** -10,
+                                    2 ** -10 * 1.0001, 2 ** -9, 2 ** -7], dtype=np.float32)])
+    pts = np.concatenate([pts, -pts])
+    with np.errstate(invalid="ignore"):
+        assert np.array_equal(R.e4m3_encode(pts), R.e4m3_encode_fast(pts))
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal(300_000) * np.exp(rng.uniform(-12, 7, 300_000))).astype(np.float32)
+    assert np.array_equal(R.e4m3_encode(x), R.e4m3_encode_fast(x))

@@ -12,6 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VQA_LIB") or os.path.join(_HERE, "lib", "libvqa_retrieval.so")  # VQA_LIB: dev override
 
+VQA_VERSION = 103  # include/vqa_retrieval.h: the ABI these bindings were written against
 VQA_F32, VQA_F16, VQA_FP8_E4M3 = 0, 1, 2
 VQA_INDEX_HAS_IDS = 1
 VQA_QUERY_TILE = 256
@@ -74,6 +75,12 @@ def load() -> ctypes.CDLL:
     lib = ctypes.CDLL(LIB_PATH)
     c = ctypes
     lib.vqa_version.restype = c.c_int
+    got = lib.vqa_version()
+    if got != VQA_VERSION:
+        # a stale library (git-ignored, copied from another checkout) would be called with shifted arguments: a GPU memory
+        # fault instead of an error
+        raise RuntimeError(f"{LIB_PATH} reports ABI version {got} but these bindings expect {VQA_VERSION}: rebuild it with "
+                           "`python -m vietnamese_qa_system_amd.build --force`")
     lib.vqa_last_error.restype = c.c_char_p
     lib.vqa_index_create.argtypes = [c.POINTER(c.c_void_p), c.c_int, c.c_int64, c.c_int32, c.c_int32, c.c_void_p,
                                      c.c_int32, c.c_void_p, c.c_int64, c.c_uint32]

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <thread>
 #include <vector>
 
 #include "vqa_common.h"
@@ -46,8 +47,15 @@ struct vqa_index {
     int stage_pct = 10;
     // workspace (allocated once; search never allocates)
     void* q_stage = nullptr;     // one 256-row tile in TILED layout
-    void* q_rows = nullptr;      // staging for host -> device row chunks in set_rows (lazy)
+    void* q_rows = nullptr;      // device staging for get_rows' host path (lazy)
     size_t q_rows_bytes = 0;
+    // host rows -> shard (set_rows with a host pointer): two pinned + two device staging buffers and a copy stream (lazy), so
+    // that the caller's pageable rows travel CPU copy -> DMA -> transpose kernel with chunk i + 1's CPU copy under chunk i's DMA
+    void* up_pinned[2] = {nullptr, nullptr};
+    void* up_dev[2] = {nullptr, nullptr};
+    hipEvent_t up_done[2] = {nullptr, nullptr};
+    hipStream_t up_stream = nullptr;
+    size_t up_bytes = 0;
     vqa_key* partial = nullptr;  // [max_grid, 256, max(max_k, seeds per query)]: seed pass output, then main pass lists
     float* thr0 = nullptr;       // [256]
     vqa_key* upper = nullptr;    // [256] last key returned per query (continuation passes of a search with k > 12)
@@ -88,12 +96,86 @@ extern "C" void vqa_index_destroy(vqa_index* ix) {
     if (ix->ids) (void)hipFree(ix->ids);
     if (ix->q_stage) (void)hipFree(ix->q_stage);
     if (ix->q_rows) (void)hipFree(ix->q_rows);
+    for (int b = 0; b < 2; ++b) {
+        if (ix->up_pinned[b]) (void)hipHostFree(ix->up_pinned[b]);
+        if (ix->up_dev[b]) (void)hipFree(ix->up_dev[b]);
+        if (ix->up_done[b]) (void)hipEventDestroy(ix->up_done[b]);
+    }
+    if (ix->up_stream) (void)hipStreamDestroy(ix->up_stream);
     if (ix->partial) (void)hipFree(ix->partial);
     if (ix->thr0) (void)hipFree(ix->thr0);
     if (ix->upper) (void)hipFree(ix->upper);
     if (ix->wide_flag) (void)hipFree(ix->wide_flag);
     for (hipEvent_t e : ix->ev) (void)hipEventDestroy(e);
     delete ix;
+}
+
+
+// ---- host rows -> shard.  What Embeddings.load() does in Python (pinned double buffering, a few copier threads) for any
+// C-ABI caller: the caller's (pageable) rows are copied by kUpThreads host threads into one of two PINNED staging buffers,
+// travel to the device by DMA on a private stream and are transposed into the tiled layout by the kernel queued behind the
+// copy, while the host threads already fill the other buffer.  (hipMemcpy from pageable memory stages through the runtime's
+// own small bounce buffers and blocks: 3-5 GB/s; this path is bound by the host copy into the pinned buffer.)
+constexpr size_t kUpChunkBytes = 32u << 20;
+constexpr int kUpThreads = 4;
+
+static void parallel_copy(void* dst, const void* src, size_t bytes) {
+    if (bytes < (4u << 20)) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t cut = ((bytes + kUpThreads - 1) / kUpThreads + 4095) / 4096 * 4096;
+    std::thread workers[kUpThreads];
+    int started = 0;
+    for (size_t off = cut; off < bytes && started < kUpThreads - 1; off += cut) {
+        const size_t len = std::min(cut, bytes - off);
+        workers[started++] = std::thread([=] { memcpy(static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, len); });
+    }
+    memcpy(dst, src, std::min(cut, bytes));
+    for (int i = 0; i < started; ++i) workers[i].join();
+}
+
+static int upload_host_rows(vqa_index* ix, int64_t first, int64_t count, const void* rows, int32_t src_dtype) {
+    const size_t row_bytes = (size_t)ix->d * (src_dtype == VQA_F32 ? 4 : 2);
+    const int64_t chunk_rows = std::max<int64_t>(1, (int64_t)(kUpChunkBytes / row_bytes));
+    const size_t need = (size_t)std::min(chunk_rows, count) * row_bytes;
+    if (ix->up_bytes < need) {
+        for (int b = 0; b < 2; ++b) {
+            if (ix->up_pinned[b]) (void)hipHostFree(ix->up_pinned[b]);
+            if (ix->up_dev[b]) (void)hipFree(ix->up_dev[b]);
+            ix->up_pinned[b] = ix->up_dev[b] = nullptr;
+        }
+        ix->up_bytes = 0;
+        for (int b = 0; b < 2; ++b) {
+            if (hipHostMalloc(&ix->up_pinned[b], need, hipHostMallocDefault) != hipSuccess ||
+                hipMalloc(&ix->up_dev[b], need) != hipSuccess) {
+                (void)hipGetLastError();
+                vqa_set_error("vqa_index_set_rows: allocating 2 x %zu staging bytes (pinned + device) failed", need);
+                return VQA_ENOMEM;
+            }
+        }
+        ix->up_bytes = need;
+    }
+    if (!ix->up_stream) VQA_HIP_CHECK(hipStreamCreateWithFlags(&ix->up_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b)
+        if (!ix->up_done[b]) VQA_HIP_CHECK(hipEventCreateWithFlags(&ix->up_done[b], hipEventDisableTiming));
+    VQA_HIP_CHECK(hipStreamSynchronize(nullptr));  // earlier fills of this shard (device-pointer calls run on the null stream)
+    bool used[2] = {false, false};
+    int i = 0;
+    for (int64_t c0 = 0; c0 < count; c0 += chunk_rows, ++i) {
+        const int b = i & 1;
+        const int64_t c = std::min(chunk_rows, count - c0);
+        if (used[b]) VQA_HIP_CHECK(hipEventSynchronize(ix->up_done[b]));  // chunk i - 2 has left this buffer pair
+        parallel_copy(ix->up_pinned[b], static_cast<const char*>(rows) + (size_t)c0 * row_bytes, (size_t)c * row_bytes);
+        VQA_HIP_CHECK(hipMemcpyAsync(ix->up_dev[b], ix->up_pinned[b], (size_t)c * row_bytes, hipMemcpyHostToDevice, ix->up_stream));
+        int rc = vqa_launch_tile_rows(ix->up_dev[b], src_dtype, first + c0, c, c, ix->d, ix->d_pad, ix->dtype, ix->scale, ix->rows,
+                                      ix->up_stream);
+        if (rc != VQA_OK) return rc;
+        VQA_HIP_CHECK(hipEventRecord(ix->up_done[b], ix->up_stream));
+        used[b] = true;
+    }
+    VQA_HIP_CHECK(hipStreamSynchronize(ix->up_stream));
+    return VQA_OK;
 }
 
 extern "C" int vqa_index_set_rows(vqa_index* ix, int64_t first, int64_t count, const void* rows, int32_t src_dtype,
@@ -111,33 +193,12 @@ extern "C" int vqa_index_set_rows(vqa_index* ix, int64_t first, int64_t count, c
     hipPointerAttribute_t attr;
     bool on_device = hipPointerGetAttributes(&attr, rows) == hipSuccess && attr.type == hipMemoryTypeDevice;
     (void)hipGetLastError();  // an unregistered host pointer reports an error: not ours
-    const int seb = src_dtype == VQA_F32 ? 4 : 2;
     if (on_device) {
         int rc = vqa_launch_tile_rows(rows, src_dtype, first, count, count, ix->d, ix->d_pad, ix->dtype, ix->scale, ix->rows, nullptr);
         if (rc != VQA_OK) return rc;
     } else {
-        // host rows: stage through a device buffer, 64 Mi elements at a time
-        const int64_t chunk_rows = std::max<int64_t>(1, (64ll << 20) / ix->d);
-        const size_t need = (size_t)std::min(chunk_rows, count) * ix->d * seb;
-        if (ix->q_rows_bytes < need) {
-            if (ix->q_rows) (void)hipFree(ix->q_rows);
-            ix->q_rows = nullptr;
-            ix->q_rows_bytes = 0;
-            if (hipMalloc(&ix->q_rows, need) != hipSuccess) {
-                vqa_set_error("vqa_index_set_rows: hipMalloc of %zu staging bytes failed", need);
-                return VQA_ENOMEM;
-            }
-            ix->q_rows_bytes = need;
-        }
-        for (int64_t c0 = 0; c0 < count; c0 += chunk_rows) {
-            const int64_t c = std::min(chunk_rows, count - c0);
-            VQA_HIP_CHECK(hipMemcpy(ix->q_rows, reinterpret_cast<const char*>(rows) + (size_t)c0 * ix->d * seb,
-                                    (size_t)c * ix->d * seb, hipMemcpyHostToDevice));
-            int rc = vqa_launch_tile_rows(ix->q_rows, src_dtype, first + c0, c, c, ix->d, ix->d_pad, ix->dtype, ix->scale, ix->rows,
-                                          nullptr);
-            if (rc != VQA_OK) return rc;
-            VQA_HIP_CHECK(hipStreamSynchronize(nullptr));
-        }
+        int rc = upload_host_rows(ix, first, count, rows, src_dtype);
+        if (rc != VQA_OK) return rc;
     }
     if (ids_or_null) VQA_HIP_CHECK(hipMemcpy(ix->ids + first, ids_or_null, (size_t)count * 8, hipMemcpyDefault));
     VQA_HIP_CHECK(hipStreamSynchronize(nullptr));

@@ -125,7 +125,8 @@ __device__ __forceinline__ void row_raw_stats(float (&x)[kChunks][8], int H, int
 // cu[b] + l and every kernel below takes its per-sequence length from cu (cu == nullptr: the padded [B, L] layout).
 // Padding keys carry exactly zero attention weight in the padded form (HF adds finfo.min), so the real tokens' results are
 // identical.  One workgroup: per-sequence counts -> exclusive scan -> cu[0 .. B], row_seq[packed row] = b.  A mask that is not
-// right-padded, or more real tokens than the caller announced, raises the host-visible flag (the next forward fails).
+// right-padded, or a count of real tokens that differs from what the caller announced (more: rows would be dropped; fewer: the
+// GEMMs would run on stale workspace rows past cu[B]), raises the host-visible flag (the next forward fails).
 __global__ __launch_bounds__(256) void pack_kernel(const int* __restrict__ mask, int B, int L, int announced, int* __restrict__ cu,
                                                    int* __restrict__ row_seq, int* __restrict__ bad) {
     __shared__ int part[256];
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const int* __restrict__ mask,
     }
     if (tid == 255) {
         cu[B] = part[255];
-        if (part[255] > announced) __hip_atomic_store(bad, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (part[255] != announced) __hip_atomic_store(bad, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (!ragged_ok) __hip_atomic_store(bad, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     int off = part[tid] - sum;  // exclusive
@@ -1786,8 +1787,8 @@ extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, con
     if (__atomic_load_n(e->bad_ids_host, __ATOMIC_RELAXED)) {
         __atomic_store_n(e->bad_ids_host, 0, __ATOMIC_RELAXED);
         vqa_set_error("vqa_encoder_forward: an earlier forward on this handle saw token ids outside [0, %d) (embedded as the pad token: "
-                      "tokenizer / vocabulary mismatch?) or a packed call whose mask was not right-padded / held more real tokens than "
-                      "announced (its output is invalid)", e->cfg.vocab_size);
+                      "tokenizer / vocabulary mismatch?) or a packed call whose mask was not right-padded / whose number of real tokens "
+                      "differed from the announced one (its output is invalid)", e->cfg.vocab_size);
         return VQA_EINVAL;
     }
     DevGuard guard(e->device);

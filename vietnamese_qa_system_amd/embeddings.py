@@ -14,8 +14,9 @@ across the ranks with an RCCL all-gather of per-shard candidates (:mod:`.sharded
 Conventions kept from txtai [recalled, SURVEY.md section 8b]: results sorted by score descending; default ``limit=3``;
 ``content=False`` -> ``[(id, score)]``, ``content=True`` -> ``[{"id", "text", "score"}]``; results with
 ``score <= 0`` are dropped -- a HOST-side filter (``min_score=0.0``, exclusive; ``None`` disables it), never part
-of the kernel.  ``hybrid=True`` is accepted for call compatibility but only the dense score is computed (the BM25
-half of txtai's hybrid score is out of scope); a warning says so.
+of the kernel.  ``hybrid=True`` (``heavy_ranker.py:78``) adds a host-side BM25 keyword half (:mod:`.sparse`, txtai's
+scoring restated from memory: parity unpinned) and returns the 0.5 / 0.5 convex combination of the two scores for text
+queries; vector queries are dense only.
 """
 from __future__ import annotations
 
@@ -87,7 +88,7 @@ class Embeddings:
         self._host_ids: Optional[list] = None  # non-integer external ids, by row position
         self._docs_db: Optional[str] = None
         self._docs_mem: Optional[dict] = None   # device-level id -> document (lookup at search time)
-        self._docs_rows: Optional[list] = None  # [(global row position, document)] of the rows this rank was given
+        self._docs_rows: Optional[list] = None  # [(device-level id, document)] of the rows this rank was given
         self._lo = 0                            # first global row of this rank's shard
         self.load_stats: Optional[dict] = None  # filled by load(): bytes, seconds, GB/s of the file -> HBM stream
         self.n = 0
@@ -124,12 +125,20 @@ class Embeddings:
     def index(self, documents: Iterable, vectors=None, batch_size: int = 512) -> None:
         """Build the index from documents (``heavy_ranker.py:86``); ``vectors`` [n, d] skips the encoder."""
         docs = self._normalise_documents(documents)
+        total = None
         if vectors is None:
-            chunks = []
-            for c0 in range(0, len(docs), batch_size):
-                chunks.append(self._encode([str(d.get("text", "")) for d in docs[c0:c0 + batch_size]]).float())
-            vectors = torch.cat(chunks) if chunks else torch.zeros((0, 1))
-        self.index_vectors([d["id"] for d in docs], vectors, documents=docs if self.content else None)
+            # the encoder's output goes chunk by chunk straight into the shard (row-producer path): no [n, d] fp32 copy of
+            # the corpus ever exists (30 GB at 10M documents), and with torch.distributed initialised every rank encodes
+            # only the documents of its own row shard
+            texts = [str(d.get("text", "")) for d in docs]
+            total = len(docs)
+
+            def vectors(lo: int, hi: int) -> torch.Tensor:
+                return self._encode(texts[lo:hi]).float()
+            if total == 0:
+                vectors, total = torch.zeros((0, 1)), None
+        self.index_vectors([d["id"] for d in docs], vectors, documents=docs if self.content else None, total=total,
+                           chunk_rows=max(int(batch_size), 1) * 8)
         if self.hybrid:  # every rank indexes the whole corpus' text (host side, small next to the vectors)
             self._sparse = BM25Index().index(str(d.get("text", "")) for d in docs)
 
@@ -142,7 +151,8 @@ class Embeddings:
         * ``local=True``: ``vectors`` (and ``ids``, ``documents``) are only THIS rank's rows [lo, hi) of a corpus of ``total``
           rows -- no rank ever holds the whole corpus (80M x 768 fp16 = 123 GB).  ``total`` defaults to the sum over ranks.
         * ``vectors`` may also be a callable ``rows(lo, hi) -> [hi - lo, d] array`` (needs ``total``); it is asked for this
-          rank's rows in chunks of ``chunk_rows`` and the shard is filled chunk by chunk without a second copy.
+          rank's rows in chunks of ``chunk_rows`` and the shard is filled chunk by chunk without a second copy.  ``ids`` /
+          ``documents`` then cover either this rank's rows or the whole corpus (told apart by their length).
         """
         self._host_ids = None  # ids of an earlier index() on this object must not leak into the new one
         producer = vectors if callable(vectors) else None
@@ -163,7 +173,7 @@ class Embeddings:
             if local:
                 mine = int(v.shape[0])
                 if total is None:
-                    if self.world > 1:
+                    if self.world > 1 or (dist.is_initialized() and os.environ.get("VQA_ALWAYS_GATHER") == "1"):
                         t = torch.tensor([mine], dtype=torch.int64)
                         if dist.get_backend(self.group) == "nccl":
                             t = t.cuda(self.device)
@@ -179,6 +189,11 @@ class Embeddings:
                 n = int(v.shape[0])
                 lo, hi = shard_bounds(n, self.world, self.rank)
         part = local or producer is not None  # ids / documents cover only this rank's rows
+        if producer is not None and not local and (len(ids) if ids is not None else len(documents) if documents is not None
+                                                   else hi - lo) == n:
+            part = False  # a row producer with the whole corpus' ids / documents (what index(documents) passes)
+        if documents is not None and len(documents) != (hi - lo if part else n):
+            raise ValueError(f"{len(documents)} documents for {(hi - lo) if part else n} vectors")
         if ids is not None and len(ids) != (hi - lo if part else n):
             raise ValueError(f"{len(ids)} ids for {(hi - lo) if part else n} vectors")
         int_ids = ids is None or all(isinstance(i, (int, np.integer)) for i in ids)
@@ -225,10 +240,13 @@ class Embeddings:
         self._docs_db = None
         self._docs_rows = self._docs_mem = None
         if documents is not None:
+            # key = what the device reports for the row: its global position (ids=None or non-integer ids, which map through
+            # _host_ids afterwards), else the integer id given for it -- never the document's own "id" field, which need
+            # not be an integer nor agree with `ids`
             base = lo if part else 0
-            self._docs_rows = [(base + i, d_) for i, d_ in enumerate(documents)]
-            # lookup key = what the device reports for the row: the row position (string ids) or the integer id
-            self._docs_mem = {(pos if self._host_ids is not None else int(d_["id"])): d_ for pos, d_ in self._docs_rows}
+            by_pos = ids is None or not int_ids
+            self._docs_rows = [(base + i if by_pos else int(ids[i]), d_) for i, d_ in enumerate(documents)]
+            self._docs_mem = dict(self._docs_rows)
 
     def _local_search(self, q: torch.Tensor, k: int, out_s: torch.Tensor, out_i: torch.Tensor) -> None:
         self._index.search(q, k, out=(out_s, out_i))
@@ -345,6 +363,8 @@ class Embeddings:
             if has_ids:
                 with open(ids_path, "wb") as f:
                     f.truncate(self.n * 8)
+            elif os.path.exists(ids_path):
+                os.remove(ids_path)  # left by an earlier save of an index WITH an id vector into the same directory
         if self.world > 1:
             dist.barrier(group=self.group)
         # chunks leave the device into one of two pinned buffers (a DMA) and are written by a few threads, each its own byte
@@ -413,8 +433,8 @@ class Embeddings:
                     if os.path.exists(db):
                         os.remove(db)
                     # one row per corpus row, keyed by what the device reports for it (row position for string ids)
-                    docstore.write_documents(db, [{"id": pos if self._host_ids is not None else int(doc["id"]),
-                                                   "text": doc.get("text"), "source": doc.get("source")} for pos, doc in docs_rows])
+                    docstore.write_documents(db, [{"id": key, "text": doc.get("text"), "source": doc.get("source")}
+                                                  for key, doc in docs_rows])
                 elif self._docs_db is not None and os.path.abspath(self._docs_db) != os.path.abspath(db):
                     shutil.copyfile(self._docs_db, db)  # a loaded index keeps its documents on re-save
         if self.world > 1:

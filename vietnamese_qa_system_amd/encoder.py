@@ -43,7 +43,7 @@ class QuestionEncoder:
     vocab_size, hidden, layers, heads, ffn, max_pos, type_vocab, pad_id, ln_eps.  ``max_tokens`` bounds B * L of one call.
     """
 
-    def __init__(self, weights: Dict[str, object], config: dict, *, device: int = 0, max_tokens: int = 256 * 64):
+    def __init__(self, weights: Dict[str, object], config: dict, *, device: int = 0, max_tokens: int = 1024 * 32):
         if not torch.cuda.is_available():
             raise RuntimeError("QuestionEncoder needs an MI355X (gfx950); there is no CPU fallback")
         self._lib = N.load()
@@ -150,10 +150,13 @@ class TextEncoder:
 
     ``tokenizer(texts) -> (input_ids [B, L], attention_mask [B, L])`` (lists, numpy or torch); any HF tokenizer wrapped
     as ``lambda t: (lambda e: (e["input_ids"], e["attention_mask"]))(tok(t, padding=True, truncation=True,
-    max_length=128, return_tensors="np"))`` fits."""
+    max_length=128, return_tensors="np"))`` fits.  ``batch_size`` texts are tokenised together and go through the encoder
+    in ONE forward when the workspace (``max_tokens``) holds them: 1024 questions of 32 tokens run the GEMMs at 1.5x the
+    rate of four batches of 256 (``bench.py: end_to_end.super_batch``), so ``Embeddings.batchsearch`` with many text queries
+    is a throughput path."""
 
     def __init__(self, tokenizer: Callable[[List[str]], Tuple[Sequence, Sequence]], encoder: QuestionEncoder, *,
-                 pooling: str = "mean", normalize: bool = True, batch_size: int = 256):
+                 pooling: str = "mean", normalize: bool = True, batch_size: int = 1024):
         self.tokenizer, self.encoder = tokenizer, encoder
         self.pooling, self.normalize, self.batch_size = pooling, normalize, batch_size
 

@@ -12,6 +12,7 @@ Ties resolve by (rank asc, slot asc) = global row position asc, identical to a s
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional, Tuple
 
 import torch
@@ -33,11 +34,15 @@ class ShardedSearcher:
     ``local_search(queries, k, out_scores, out_ids)`` writes the shard's ``[B, k]`` candidates into the two given
     tensors -- views of ONE send buffer ``[ids int64 | scores float32]`` (12 * B * k bytes, padded to 8), so a batch
     costs a single collective; ``merge(scores [R, B, k], ids [R, B, k], k)`` gets rank-strided views of the gathered
-    buffer."""
+    buffer.
+
+    ``always_gather`` (default: the environment variable ``VQA_ALWAYS_GATHER=1``) runs the all-gather and the merge even in
+    a process group of ONE rank, so that a single-GPU box takes every collective call of the N > 1 path through RCCL
+    (``tests/test_gpu_rccl_world1.py``); without it a lone rank returns its shard's result directly."""
 
     def __init__(self, local_search: Callable[[torch.Tensor, int, torch.Tensor, torch.Tensor], None],
                  merge: Optional[Callable[[torch.Tensor, torch.Tensor, int], Tuple[torch.Tensor, torch.Tensor]]] = None,
-                 group=None):
+                 group=None, always_gather: Optional[bool] = None):
         self.local_search = local_search
         if merge is None:
             from .index import merge_topk
@@ -45,30 +50,40 @@ class ShardedSearcher:
         self.merge = merge
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self._slots = {}  # (B, k, device, slot) -> (send, recv, (send_s, send_i, recv_s, recv_i))
+        if always_gather is None:
+            always_gather = os.environ.get("VQA_ALWAYS_GATHER") == "1"
+        self.collective = self.world > 1 or (bool(always_gather) and dist.is_initialized())
+        self._pools = {}  # (device, slot) -> [send bytes, recv bytes]: grown, never dropped (see _buffers)
+        self.collectives = 0  # all-gathers issued (tests / bench read it)
 
     def _buffers(self, b: int, k: int, device: torch.device, slot: int = 0):
-        key = (b, k, device, slot)
-        if key not in self._slots:
-            if len(self._slots) >= 8:
-                self._slots.clear()
-            row = (12 * b * k + 7) // 8 * 8  # bytes per rank: ids [B, k] int64, scores [B, k] float32, pad to 8
-            send = torch.zeros((row,), dtype=torch.uint8, device=device)
-            recv = torch.zeros((self.world, row), dtype=torch.uint8, device=device)
-            n = b * k
-            send_i = send[:8 * n].view(torch.int64).view(b, k)
-            send_s = send[8 * n:12 * n].view(torch.float32).view(b, k)
-            recv_i = recv[:, :8 * n].view(torch.int64).unflatten(1, (b, k))
-            recv_s = recv[:, 8 * n:12 * n].view(torch.float32).unflatten(1, (b, k))
-            self._slots[key] = (send, recv, (send_s, send_i, recv_s, recv_i))
-        return self._slots[key]
+        """Views of this slot's byte pools for a [b, k] batch.  A pool only ever GROWS (to the next power of two): batches of
+        any mix of sizes reuse the same two allocations per slot, so an asynchronous gather in flight on one slot never
+        sees its buffers dropped or re-allocated under a stream of varied (B, k) -- the round-2 cache cleared itself at 8
+        keys.  (A grown pool replaces the old one only for LATER batches; a pending gather keeps its views alive.)"""
+        row = (12 * b * k + 7) // 8 * 8  # bytes per rank: ids [B, k] int64, scores [B, k] float32, pad to 8
+        pool = self._pools.get((device, slot))
+        if pool is None or pool[0].numel() < row:
+            cap = 1 << max(12, (row - 1).bit_length())
+            pool = [torch.zeros((cap,), dtype=torch.uint8, device=device),
+                    torch.zeros((self.world * cap,), dtype=torch.uint8, device=device)]
+            self._pools[(device, slot)] = pool
+        send = pool[0][:row]
+        recv = pool[1][:self.world * row].view(self.world, row)
+        n = b * k
+        send_i = send[:8 * n].view(torch.int64).view(b, k)
+        send_s = send[8 * n:12 * n].view(torch.float32).view(b, k)
+        recv_i = recv[:, :8 * n].view(torch.int64).unflatten(1, (b, k))
+        recv_s = recv[:, 8 * n:12 * n].view(torch.float32).unflatten(1, (b, k))
+        return send, recv, (send_s, send_i, recv_s, recv_i)
 
     def search(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
         b = int(queries.shape[0])
         send, recv, (send_s, send_i, recv_s, recv_i) = self._buffers(b, k, self._device(queries))
         self.local_search(queries, k, send_s, send_i)
-        if self.world == 1:
+        if not self.collective:
             return send_s.clone(), send_i.clone()
+        self.collectives += 1
         dist.all_gather_into_tensor(recv.view(-1), send, group=self.group)  # the one exchange step
         return self.merge(recv_s, recv_i, k)
 
@@ -84,7 +99,8 @@ class ShardedSearcher:
             send, recv, (send_s, send_i, recv_s, recv_i) = self._buffers(b, k, self._device(queries), slot=n & 1)
             self.local_search(queries, k, send_s, send_i)
             work = None
-            if self.world > 1:
+            if self.collective:
+                self.collectives += 1
                 work = dist.all_gather_into_tensor(recv.view(-1), send, group=self.group, async_op=True)
             if pending is not None:
                 results.append(self._finish(*pending, k))
