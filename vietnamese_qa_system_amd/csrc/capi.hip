@@ -45,6 +45,7 @@ struct vqa_index {
                                // crossover between 1M rows, +1 % step time, and 2M rows, -2 %; VQA_STAGE_MIN: dev /
                                // test override, 0 disables); the first stage takes stage_pct % of the tiles (VQA_STAGE_PCT)
     int stage_pct = 10;
+    int f16_loop = 0;  // fp16 K loop: 0 = anti-phase slots (two barriers per K-step), 1 = K-step pairs on the stagger loop (VQA_F16_LOOP)
     // workspace (allocated once; search never allocates)
     void* q_stage = nullptr;     // one 256-row tile in TILED layout
     void* q_rows = nullptr;      // device staging for get_rows' host path (lazy)
@@ -251,6 +252,8 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
     if (sg) ix->stage_min_tiles = atoi(sg);
     const char* sp = getenv("VQA_STAGE_PCT");
     if (sp && atoi(sp) >= 1 && atoi(sp) <= 50) ix->stage_pct = atoi(sp);
+    const char* fl = getenv("VQA_F16_LOOP");
+    if (fl && fl[0] >= '0' && fl[0] <= '2') ix->f16_loop = fl[0] - '0';  // 2: pairs for the main launch of a two-stage search only
     const char* sm = getenv("VQA_SEED_MULT");
     if (sm && sm[0] >= '1' && sm[0] <= '4') ix->seed_mult = sm[0] - '0';
     const int eb = elem_bytes(dtype);
@@ -499,6 +502,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             a.nq = nq;
             a.k = max_k;
             a.upper = nullptr;
+            a.loop = ix->f16_loop == 1 ? 1 : 0;
             a.thr_init = nullptr;
             a.partial = ix->partial;
             a.tile_begin = 0;
@@ -539,6 +543,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             a.k = kk;
             a.upper = upper;
             a.gate = gate;
+            a.loop = ix->f16_loop == 1 ? 1 : 0;
             if (p.grid0 > 0) {
                 a.thr_init = nullptr;
                 a.partial = ix->partial;
@@ -578,6 +583,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
                 a.tile_begin = p.stage_tiles;
                 a.tile_end = p.tiles;
                 a.list_offset = p.grid1;
+                if (ix->f16_loop == 2) a.loop = 1;
             }
             if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
             rc = vqa_launch_score_topk(ix->dtype, a, stream);

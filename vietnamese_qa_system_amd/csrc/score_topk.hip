@@ -94,6 +94,33 @@ __device__ __forceinline__ void mma_block_mx(f32x4 (&acc)[8][4], const v8i (&a)[
                                                                            kUnitScale);
 }
 
+// fp16 on the same K-step-pair operands (the stagger loop, LOOP = 1): the low / high 16 bytes of a lane's 32-byte operand are
+// its fragments of the even / odd K-step; 2 x 32 v_mfma_f32_16x16x32_f16, K-step outermost (consecutive MFMAs hit different
+// accumulators)
+typedef int v4i __attribute__((ext_vector_type(4)));
+template <int DT>
+__device__ __forceinline__ void mma_pair(f32x4 (&acc)[8][4], const v8i (&a)[8], const v8i (&b)[4]) {
+    if constexpr (DT == VQA_FP8_E4M3) {
+        mma_block_mx<0, 8>(acc, a, b);
+    } else {
+        static_assert(DT == VQA_F16, "K-step pairs: fp8 (block-scaled MFMA) or fp16");
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                    __builtin_bit_cast(half8, __builtin_shufflevector(a[mi], a[mi], 0, 1, 2, 3)),
+                    __builtin_bit_cast(half8, __builtin_shufflevector(b[ni], b[ni], 0, 1, 2, 3)), acc[mi][ni], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                    __builtin_bit_cast(half8, __builtin_shufflevector(a[mi], a[mi], 4, 5, 6, 7)),
+                    __builtin_bit_cast(half8, __builtin_shufflevector(b[ni], b[ni], 4, 5, 6, 7)), acc[mi][ni], 0, 0, 0);
+    }
+}
+
 // row groups [M0, M1) x all four query groups; sub-step outermost so consecutive MFMAs hit different accumulators
 // (v_mfma_f32_16x16x4_f32 has a 40-cycle dependent latency against a 32-cycle issue)
 template <int DT, int T, int M0, int M1>
@@ -317,7 +344,7 @@ __device__ unsigned long long g_stamps[8 * 64 * kStampSlots];
 #define VQA_STAMP_FLUSH(KT) (void)0
 #endif
 
-template <int MODE, int DT, int STAGE = 0>
+template <int MODE, int DT, int STAGE = 0, int LOOP = 0>
 __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __restrict__ X, const void* __restrict__ Qs,
                                                               const float* __restrict__ thr_init,
                                                               const vqa_key* __restrict__ upper,
@@ -339,7 +366,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // fp16 / fp32: group = corpus-row half (the two groups run the K-step memory-first / matrix-first).
     // fp8: group = QUERY half (the two groups run one slot apart and own disjoint candidate lists, see stagger_loop).
-    constexpr bool kStagger = DT == VQA_FP8_E4M3;
+    constexpr bool kStagger = DT == VQA_FP8_E4M3 || (DT == VQA_F16 && LOOP == 1);  // LOOP 1: fp16 on the K-step-pair stagger loop
     const int grp = wave >> 2;                              // waves w and w + 4 share a SIMD: one of each group
     const int wm = kStagger ? (wave >> 1) & 1 : grp;        // corpus-row half
     const int wn = kStagger ? 2 * grp + (wave & 1) : wave & 3;  // query quarter
@@ -565,38 +592,50 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     // when some append was refused (list full); the refused accumulators are left in pend[] for process_pending.
     auto append_epilogue = [&](const f32x4 (&acc)[8][4], uint32_t row0, uint32_t (&pend)[4], int spill)
                                __attribute__((always_inline)) -> bool {
-        bool refused = false;
+        // Common path, straight-line: the four thresholds are read first, the four maxima are reduced as independent
+        // v_max3 trees (depth 4 instead of a 16-deep chain each), and ONE branch covers all four query columns -- a wave
+        // whose 64 x 4 maxima all stay below their thresholds (the usual case) takes no divergent path at all.
+        float th[4], m[4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             pend[ni] = 0u;
-            const int q = wn * 64 + ni * 16 + c;
-            const float th = L.thr[q];
-            float m = -INFINITY;
+            th[ni] = L.thr[wn * 64 + ni * 16 + c];
+        }
 #pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {  // two v_max3_f32 per accumulator vector
-                m = fmaxf(fmaxf(m, acc[mi][ni][0]), acc[mi][ni][1]);
-                m = fmaxf(fmaxf(m, acc[mi][ni][2]), acc[mi][ni][3]);
-            }
+        for (int ni = 0; ni < 4; ++ni) {
+            float r[8];
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)  // two v_max3_f32 per accumulator vector
+                r[mi] = fmaxf(fmaxf(fmaxf(acc[mi][ni][0], acc[mi][ni][1]), acc[mi][ni][2]), acc[mi][ni][3]);
+            const float r01 = fmaxf(fmaxf(r[0], r[1]), r[2]), r23 = fmaxf(fmaxf(r[3], r[4]), r[5]);
+            m[ni] = fmaxf(fmaxf(r01, r23), fmaxf(r[6], r[7]));
 #if VQA_ABLATE & 8
-            asm volatile("" : "+v"(m));
-            m = -INFINITY;
+            asm volatile("" : "+v"(m[ni]));
+            m[ni] = -INFINITY;
 #endif
-            if (m >= th) {
-                // rare: some accumulator of this (lane, query) beats the threshold.  Two static levels (row group, then
-                // element) instead of a 32-way select: ~50 instructions for the usual single survivor.
-                const vqa_key up = upper ? load_key_now(upper, q) : ~0ull;
+        }
+        bool refused = false;
+        if ((m[0] >= th[0]) | (m[1] >= th[1]) | (m[2] >= th[2]) | (m[3] >= th[3])) {
 #pragma unroll
-                for (int mi = 0; mi < 8; ++mi) {
-                    const float mm = fmaxf(fmaxf(acc[mi][ni][0], acc[mi][ni][1]), fmaxf(acc[mi][ni][2], acc[mi][ni][3]));
-                    if (mm >= th) {
+            for (int ni = 0; ni < 4; ++ni) {
+                if (m[ni] >= th[ni]) {
+                    // rare: some accumulator of this (lane, query) beats the threshold.  Two static levels (row group, then
+                    // element) instead of a 32-way select: ~50 instructions for the usual single survivor.
+                    const int q = wn * 64 + ni * 16 + c;
+                    const vqa_key up = upper ? load_key_now(upper, q) : ~0ull;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const float v = acc[mi][ni][j];
-                            if (v >= th) {
-                                const uint32_t pos = row0 + (uint32_t)(wm * 128 + mi * 16 + g * 4 + j);
-                                if (vqa_make_key(v, pos) < up && !append_candidate(L, q, v, pos, spill)) {
-                                    pend[ni] |= 1u << (mi * 4 + j);
-                                    refused = true;
+                    for (int mi = 0; mi < 8; ++mi) {
+                        const float mm = fmaxf(fmaxf(acc[mi][ni][0], acc[mi][ni][1]), fmaxf(acc[mi][ni][2], acc[mi][ni][3]));
+                        if (mm >= th[ni]) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const float v = acc[mi][ni][j];
+                                if (v >= th[ni]) {
+                                    const uint32_t pos = row0 + (uint32_t)(wm * 128 + mi * 16 + g * 4 + j);
+                                    if (vqa_make_key(v, pos) < up && !append_candidate(L, q, v, pos, spill)) {
+                                        pend[ni] |= 1u << (mi * 4 + j);
+                                        refused = true;
+                                    }
                                 }
                             }
                         }
@@ -999,7 +1038,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
                              "+v"(a2[7]));
                 VQA_SB();
 #if !(VQA_ABLATE & 4)
-                mma_block_mx<0, 8>(acc, a2, b2);
+                mma_pair<DT>(acc, a2, b2);
 #endif
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi)
@@ -1069,20 +1108,21 @@ int vqa_score_topk_max_k(int dtype) {
 
 int vqa_score_topk_seeds_per_tile() { return kSeedsPerTile; }
 
-template <int DT>
+template <int DT, int LOOP>
 static int launch_dt(const ScoreTopkArgs& a, int KT, int lds, hipStream_t stream) {
     static VqaPerDeviceOnce once;
     int rc = once.run([&](int) -> int {
-        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<0, DT>),
+        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<0, DT, 0, LOOP>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<1, DT>),
+        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<1, DT, 0, LOOP>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<1, DT, 1>),
+        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<1, DT, 1, LOOP>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         return VQA_OK;
     });
     if (rc != VQA_OK) return rc;
-    auto kern = a.seed_only ? score_topk_kernel<0, DT> : a.first_stage ? score_topk_kernel<1, DT, 1> : score_topk_kernel<1, DT>;
+    auto kern = a.seed_only ? score_topk_kernel<0, DT, 0, LOOP>
+                            : a.first_stage ? score_topk_kernel<1, DT, 1, LOOP> : score_topk_kernel<1, DT, 0, LOOP>;
     hipLaunchKernelGGL(kern, dim3(a.grid), dim3(kThreads), lds, stream, a.x, a.q, a.thr_init, a.upper, a.partial, (long long)a.n,
                        KT, a.nq, a.k, a.tile_begin, a.tile_end, a.gate, a.row_lists > 0 ? a.row_lists : a.grid, a.list_offset,
                        a.seeds_per_tile);
@@ -1103,9 +1143,9 @@ int vqa_launch_score_topk(int dtype, const ScoreTopkArgs& a, hipStream_t stream)
                 a.tile_end - a.tile_begin);
     const int lds = vqa_score_topk_lds_bytes(dtype, a.k);
     const int KT = a.d_pad * esize / kRowBytes;  // even
-    if (dtype == VQA_F16) return launch_dt<VQA_F16>(a, KT, lds, stream);
-    if (dtype == VQA_FP8_E4M3) return launch_dt<VQA_FP8_E4M3>(a, KT, lds, stream);
-    return launch_dt<VQA_F32>(a, KT, lds, stream);
+    if (dtype == VQA_F16) return a.loop == 1 ? launch_dt<VQA_F16, 1>(a, KT, lds, stream) : launch_dt<VQA_F16, 0>(a, KT, lds, stream);
+    if (dtype == VQA_FP8_E4M3) return launch_dt<VQA_FP8_E4M3, 0>(a, KT, lds, stream);
+    return launch_dt<VQA_F32, 0>(a, KT, lds, stream);
 }
 
 #ifdef VQA_STAMPS

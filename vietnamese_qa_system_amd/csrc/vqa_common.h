@@ -84,6 +84,7 @@ struct ScoreTopkArgs {
     int32_t list_offset = 0;    // ... and the slot of this launch's workgroup 0 inside the row (two-stage search: the first
                                 // stage fills slots [0, grid), the main launch [grid, 2 grid) of rows of 2 grid lists)
     bool first_stage = false;   // the first-stage launch of a two-stage search: same code, its own kernel symbol
+    int32_t loop = 0;           // fp16 only: 0 = anti-phase slot loop, 1 = K-step-pair stagger loop (the fp8 structure)
     bool seed_only = false;  // MODE 0: writes seeds_per_tile sub-maxima per query and tile to `partial` as [query][tile - tile_begin][.]
     int32_t seeds_per_tile = 2;  // 2 (one per 128-row half) or 8 (one per 32-row group: shards of a few tiles, where 2 per tile
                                  // are fewer than k values and leave the thresholds at -inf)
