@@ -400,18 +400,49 @@ struct TileGeom {
     static_assert(kStages >= 3, "the anti-phase ring needs three stages");
 };
 
-// one LDS-DMA piece: 64 lanes x 16 B from `base + voff` (per lane) to LDS `lds_dst + lane * 16`
-__device__ __forceinline__ void tile_dma_piece(const char* base, uint32_t voff, uint32_t lds_dst) {
+// N pieces of one wave behind ONE M0 write (the scoring kernel's form): piece j goes to LDS lds_dst + 1024 j (the instruction
+// offset moves the LDS side) from base[j] + voff + 1024 j (... and the global side: the caller passes base[j] - 1024 j).  A
+// stamped timeline of the one-piece-per-M0 form showed ~95 cycles per piece in the issuing wave (M0 write -> s_nop -> load ->
+// M0 restore, each a dependent scalar hop) against ~40 per instruction for back-to-back loads under one M0.
+template <int N, int NJ>
+__device__ __forceinline__ void tile_dma_pieces(const char* const (&b)[NJ], uint32_t voff, uint32_t lds_dst) {
+    static_assert(N >= 1 && N <= 7 && N <= NJ, "pieces per wave and K-step");
     uint32_t keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %3\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, %2\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(voff), "s"(base), "s"(lds_dst)
-        : "memory");
+#define VQA_P_HEAD "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+#define VQA_P_TAIL "s_mov_b32 m0, %0"
+    if constexpr (N == 1)
+        asm volatile(VQA_P_HEAD "global_load_lds_dwordx4 %1, %3\n\t" VQA_P_TAIL
+                     : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(b[0]) : "memory");
+    else if constexpr (N == 2)
+        asm volatile(VQA_P_HEAD "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %4 offset:1024\n\t" VQA_P_TAIL
+                     : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(b[0]), "s"(b[1]) : "memory");
+    else if constexpr (N == 3)
+        asm volatile(VQA_P_HEAD "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %4 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %5 offset:2048\n\t" VQA_P_TAIL
+                     : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(b[0]), "s"(b[1]), "s"(b[2]) : "memory");
+    else if constexpr (N == 4)
+        asm volatile(VQA_P_HEAD "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %4 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %5 offset:2048\n\tglobal_load_lds_dwordx4 %1, %6 offset:3072\n\t" VQA_P_TAIL
+                     : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(b[0]), "s"(b[1]), "s"(b[2]), "s"(b[3]) : "memory");
+    else {
+        // five to seven pieces: the instruction offset reaches +4095, so a second M0 serves pieces 4 ..
+        asm volatile(VQA_P_HEAD "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %4 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %1, %5 offset:2048\n\tglobal_load_lds_dwordx4 %1, %6 offset:3072\n\t" VQA_P_TAIL
+                     : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(b[0]), "s"(b[1]), "s"(b[2]), "s"(b[3]) : "memory");
+        const uint32_t d2 = lds_dst + 4096;
+        if constexpr (N == 5)
+            asm volatile(VQA_P_HEAD "global_load_lds_dwordx4 %1, %3\n\t" VQA_P_TAIL
+                         : "=&s"(keep) : "v"(voff), "s"(d2), "s"(b[4]) : "memory");
+        else if constexpr (N == 6)
+            asm volatile(VQA_P_HEAD "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %4 offset:1024\n\t" VQA_P_TAIL
+                         : "=&s"(keep) : "v"(voff), "s"(d2), "s"(b[4]), "s"(b[5]) : "memory");
+        else
+            asm volatile(VQA_P_HEAD "global_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %1, %4 offset:1024\n\t"
+                         "global_load_lds_dwordx4 %1, %5 offset:2048\n\t" VQA_P_TAIL
+                         : "=&s"(keep) : "v"(voff), "s"(d2), "s"(b[4]), "s"(b[5]), "s"(b[6]) : "memory");
+    }
+#undef VQA_P_HEAD
+#undef VQA_P_TAIL
 }
 
 template <int N>
@@ -456,7 +487,36 @@ struct FoldArgs {
     float2* st_out;       // EPI 2: slots of the rows of C
 };
 
-template <int EPI, int BM, int BN, int WM, int WN, int BK, int FOLD = 0>
+#ifdef VQA_GSTAMPS
+// dev-only diagnostic build (scripts/gemm_bench.py --stamps): s_memtime stamps of one workgroup's K-steps during its first
+// tile, written by scalar stores to a buffer no other code reads (the instrumentation costs ~10 %: never in the product build)
+constexpr int kGStampWg = 37, kGStampSlots = 8;
+__device__ unsigned long long g_gstamps[8 * 64 * kGStampSlots];
+#define VQA_GSTAMP(J)                                                             \
+    do {                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+        if (stamp_on) asm volatile("s_memtime %0" : "=s"(stamp_t[J]));            \
+        __builtin_amdgcn_sched_barrier(0);                                        \
+    } while (0)
+#define VQA_GSTAMP_FLUSH(KT)                                                                                           \
+    do {                                                                                                               \
+        if (stamp_on && (KT) < 64) {                                                                                   \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+            unsigned long long* sp_ = g_gstamps + ((size_t)wave * 64 + (KT)) * kGStampSlots;                           \
+            asm volatile(                                                                                              \
+                "s_store_dwordx2 %1, %0, 0x0\n\ts_store_dwordx2 %2, %0, 0x8\n\ts_store_dwordx2 %3, %0, 0x10\n\t"        \
+                "s_store_dwordx2 %4, %0, 0x18\n\ts_store_dwordx2 %5, %0, 0x20\n\ts_store_dwordx2 %6, %0, 0x28\n\t"      \
+                "s_store_dwordx2 %7, %0, 0x30\n\ts_store_dwordx2 %8, %0, 0x38"                                           \
+                :: "s"(sp_), "s"(stamp_t[0]), "s"(stamp_t[1]), "s"(stamp_t[2]), "s"(stamp_t[3]), "s"(stamp_t[4]),       \
+                   "s"(stamp_t[5]), "s"(stamp_t[6]), "s"(stamp_t[7]) : "memory");                                       \
+        }                                                                                                              \
+    } while (0)
+#else
+#define VQA_GSTAMP(J) (void)0
+#define VQA_GSTAMP_FLUSH(KT) (void)0
+#endif
+
+template <int EPI, int BM, int BN, int WM, int WN, int BK, int FOLD = 0, int ONEBAR = 0>
 __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                                                         const float* __restrict__ bias, const _Float16* __restrict__ R,
                                                         _Float16* __restrict__ C, int M, int N, int K, int tiles_n,
@@ -473,6 +533,10 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave / WN, wc = wave % WN;  // token rows [wr BM/WM, +BM/WM) x output features [wc BN/WN, +BN/WN) of the tile
     const int grp = wave >> 2;                 // partners w, w + 4 share a SIMD: one of each group
+#ifndef VQA_GEMM_STAGGER
+#define VQA_GEMM_STAGGER 0  // 1: a group's odd waves issue their pieces before their reads (measured 7 % SLOWER: DESIGN.md)
+#endif
+    const bool dma_first = VQA_GEMM_STAGGER && (wave & 1);
     const int c = lane & 15, g = lane >> 4;
     const int Gd = gridDim.x, wg = blockIdx.x;
     const bool swz = (tiles_total % 8 == 0) && (Gd % 8 == 0);
@@ -498,7 +562,10 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
     const size_t row_bytes = (size_t)K * 2;
     const int prow = lane / SP, pslot = lane % SP;
     const uint32_t voff = (uint32_t)(prow * row_bytes + ((pslot ^ (BK == 32 ? 3 * ((prow >> 3) & 1) : (prow & 7))) << 4));
-    const int n_mine = (G::kPieces - wave + 7) / 8;  // NJ or NJ - 1
+    // this wave's pieces of every K-step: the contiguous range [p0, p0 + n_mine) (NJ or NJ - 1 of them), so that their LDS
+    // destinations are 1 KiB apart and one M0 write serves them all (tile_dma_pieces)
+    const int p0 = G::kPieces * wave / 8;
+    const int n_mine = G::kPieces * (wave + 1) / 8 - p0;
     int is_tile = 0, is_kt = 0, is_stage = 0, is_n = 0;  // issue cursor: tile, K-step inside it, ring stage, K-steps issued
     const char* src[NJ];
 #pragma unroll
@@ -509,15 +576,17 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
             const size_t bm = (size_t)(t / tiles_n) * BM, bn = (size_t)(t % tiles_n) * BN;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int p = wave + 8 * j;
-                src[j] = p < PA ? reinterpret_cast<const char*>(A) + (bm + PR * p) * row_bytes
-                                : reinterpret_cast<const char*>(W) + (bn + PR * (p - PA)) * row_bytes;
+                const int p = p0 + j < G::kPieces ? p0 + j : G::kPieces - 1;
+                src[j] = (p < PA ? reinterpret_cast<const char*>(A) + (bm + PR * p) * row_bytes
+                                 : reinterpret_cast<const char*>(W) + (bn + PR * (p - PA)) * row_bytes) - 1024 * (j & 3);
             }
         }
-        const uint32_t dst = lds_base + is_stage * G::kStageB + wave * 1024;
+        const uint32_t dst = lds_base + is_stage * G::kStageB + p0 * 1024;
+        const char* at[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            if (j < n_mine) tile_dma_piece(src[j] + (size_t)is_kt * kTileRowB, voff, dst + j * 8192);
+        for (int j = 0; j < NJ; ++j) at[j] = src[j] + (size_t)is_kt * kTileRowB;
+        if (n_mine == NJ) tile_dma_pieces<NJ, NJ>(at, voff, dst);
+        else if constexpr (NJ > 1) tile_dma_pieces<NJ - 1, NJ>(at, voff, dst);
         ++is_n;
         if (is_n < total) {  // past the end the cursor stays on the last K-step
             if (++is_kt == KT) {
@@ -544,16 +613,34 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
     const int w_off = BM * kTileRowB + wc * (BN / WN) * kTileRowB;
     int rstage = 0;  // stage of the K-step this group reads next
     half8 wf[KSUB][NT], xf[KSUB][MT];
-#define VQA_T_READ()                                                                                          \
+    half8 wf2[ONEBAR == 1 ? KSUB : 1][ONEBAR == 1 ? NT : 1], xf2[ONEBAR == 1 ? KSUB : 1][ONEBAR == 1 ? MT : 1];  // ONEBAR: the other fragment set
+#define VQA_T_READ_SET(WF, XF)                                                                                \
     do {                                                                                                      \
         const char* st = lds + rstage * G::kStageB;                                                           \
         if (++rstage == S) rstage = 0;                                                                        \
         _Pragma("unroll") for (int ks = 0; ks < KSUB; ++ks) {                                                 \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                    \
-                wf[ks][j] = *reinterpret_cast<const half8*>(st + w_off + j * 16 * kTileRowB + frag[ks]);      \
+                WF[ks][j] = *reinterpret_cast<const half8*>(st + w_off + j * 16 * kTileRowB + frag[ks]);      \
             _Pragma("unroll") for (int j = 0; j < MT; ++j)                                                    \
-                xf[ks][j] = *reinterpret_cast<const half8*>(st + x_off + j * 16 * kTileRowB + frag[ks]);      \
+                XF[ks][j] = *reinterpret_cast<const half8*>(st + x_off + j * 16 * kTileRowB + frag[ks]);      \
         }                                                                                                     \
+    } while (0)
+#define VQA_T_READ() VQA_T_READ_SET(wf, xf)
+// feature tiles [N0, N1) of one K-step from the fragment set (WF, XF); the pins keep hipcc from moving the MFMAs across what
+// surrounds them (they are register-only)
+#define VQA_T_MMA_SET(WF, XF, N0, N1)                                                                             \
+    do {                                                                                                          \
+        _Pragma("unroll") for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(XF[0][j]));                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
+        if (!(VQA_GEMM_ABLATE & 4)) {                                                                             \
+            _Pragma("unroll") for (int ks = 0; ks < KSUB; ++ks)                                                   \
+                _Pragma("unroll") for (int ni = (N0); ni < (N1); ++ni)                                            \
+                    _Pragma("unroll") for (int mi = 0; mi < MT; ++mi)                                             \
+                        acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(WF[ks][ni], XF[ks][mi], acc[ni][mi], 0, 0, 0); \
+        }                                                                                                         \
+        _Pragma("unroll") for (int ni = (N0); ni < (N1); ++ni)                                                    \
+            _Pragma("unroll") for (int mi = 0; mi < MT; ++mi) asm volatile("" ::"v"(acc[ni][mi]));                \
+        __builtin_amdgcn_sched_barrier(0);                                                                        \
     } while (0)
 // the MFMAs are register-only: the pins keep hipcc from moving them across the slot's barriers
 #define VQA_T_MMA()                                                                                               \
@@ -578,16 +665,17 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
     } while (0)
     // prologue: K-steps 0 .. D - 1 issued, K-step 0 landed; group 1 holds fragments(0)
     for (int i = 0; i < D; ++i) issue_next();
-    wait_keep(std::integral_constant<int, D - 1>{}, std::integral_constant<int, 0>{});
+    if constexpr (ONEBAR == 1) wait_keep(std::integral_constant<int, (D >= 2 ? D - 2 : 0)>{}, std::integral_constant<int, 0>{});  // K-steps 0, 1 landed
+    else wait_keep(std::integral_constant<int, D - 1>{}, std::integral_constant<int, 0>{});
     VQA_T_BARRIER();
     // the tile loop exists once per group, the wave-uniform branch sits outside it (no diamond around the MFMA blocks)
     auto run = [&](auto first_group_tag) __attribute__((always_inline)) {
         constexpr bool kG0 = decltype(first_group_tag)::value;
-        if constexpr (!kG0) {
+        if constexpr (ONEBAR == 1 || !kG0) {
             VQA_T_READ();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-        VQA_T_BARRIER();
+        if constexpr (ONEBAR != 1) VQA_T_BARRIER();
         for (int i = 0; i < my_tiles; ++i) {
             f32x4 acc[NT][MT];  // [feature tile ni][token tile mi]
 #pragma unroll
@@ -611,28 +699,105 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
                 }
             };
             // one K-step (two slots); EX: plain loads in flight that are newer than the pieces the counted waits are for
+#ifdef VQA_GSTAMPS
+            const bool stamp_on = blockIdx.x == kGStampWg && i == 0;
+            unsigned long long stamp_t[kGStampSlots] = {};
+            int stamp_kt = 0;
+#endif
             auto kstep = [&](auto extra_tag) __attribute__((always_inline)) {
                 // ---- slot 1
+                VQA_GSTAMP(0);
                 if constexpr (kG0) {
-                    VQA_T_READ();
-                    issue_next();
+                    // (VQA_GEMM_STAGGER=1, dev: the group's odd waves issue their pieces before their reads so that one pair's reads
+                    // run while the other pair's pieces drain -- measured 7 % slower: the pieces then take 445 instead of 358 cycles)
+                    if (dma_first) {
+                        issue_next();
+                        VQA_T_READ();
+                    } else {
+                        VQA_T_READ();
+                        VQA_GSTAMP(1);
+                        issue_next();
+                    }
+                    VQA_GSTAMP(2);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    VQA_GSTAMP(3);
                     wait_keep(std::integral_constant<int, D - 1>{}, extra_tag);  // own pieces of kappa + 1 landed (group 1 reads them in slot 2)
                 } else {
                     VQA_T_MMA();
+                    VQA_GSTAMP(1);
+                    VQA_GSTAMP(2);
+                    VQA_GSTAMP(3);
                     wait_keep(std::integral_constant<int, D - 2>{}, extra_tag);  // own pieces of kappa + 1 landed
                 }
+                VQA_GSTAMP(4);
                 VQA_T_BARRIER();
+                VQA_GSTAMP(5);
                 // ---- slot 2
                 if constexpr (kG0) {
                     VQA_T_MMA();
+                    VQA_GSTAMP(6);
                 } else {
-                    VQA_T_READ();
-                    issue_next();
+                    if (dma_first) {
+                        issue_next();
+                        VQA_T_READ();
+                    } else {
+                        VQA_T_READ();
+                        issue_next();
+                    }
+                    VQA_GSTAMP(6);
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
+                VQA_GSTAMP(7);
                 VQA_T_BARRIER();
+#ifdef VQA_GSTAMPS
+                VQA_GSTAMP_FLUSH(stamp_kt);
+                ++stamp_kt;
+#endif
             };
+            // ---- ONEBAR: one barrier per K-step, two fragment sets (K1's tile_loop form).  Iteration kappa: the fragments of
+            // kappa + 1 go to the other set, this wave's pieces of kappa + D are issued (into the stage of kappa - 1: its
+            // fragments were read an iteration ago, before the last barrier), the MFMAs of kappa run from the current set; then
+            // lgkmcnt(0), a counted vmcnt (this wave's pieces of kappa + 2 landed: they are read in the next iteration, behind
+            // the barrier) and the barrier.  Group 0 runs memory -> matrix, group 1 half matrix -> memory -> half matrix, so the
+            // partners of a SIMD start on different pipes.  Why: the stamped timeline of the slot form (scripts/gemm_bench.py
+            // --stamps) shows slots bound by their memory phase -- 10 reads + 4 LDS-DMA pieces take 600-660 cycles against 440 for
+            // the other group's 24 MFMAs -- plus ~150 cycles per barrier: 1570 cycles per 32-deep K-step for 768 cycles of MFMAs.
+#define VQA_T_STEP1(CW, CX, NW, NX, EXTRA)                                                                            \
+    do {                                                                                                              \
+        VQA_GSTAMP(0);                                                                                                \
+        if constexpr (!kG0) VQA_T_MMA_SET(CW, CX, 0, NT / 2);                                                         \
+        VQA_GSTAMP(1);                                                                                                \
+        VQA_T_READ_SET(NW, NX);                                                                                       \
+        VQA_GSTAMP(2);                                                                                                \
+        issue_next();                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        VQA_GSTAMP(3);                                                                                                \
+        if constexpr (kG0) VQA_T_MMA_SET(CW, CX, 0, NT);                                                              \
+        else VQA_T_MMA_SET(CW, CX, NT / 2, NT);                                                                       \
+        VQA_GSTAMP(4);                                                                                                \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                            \
+        VQA_GSTAMP(5);                                                                                                \
+        wait_keep(std::integral_constant<int, (D >= 2 ? D - 2 : 0)>{}, std::integral_constant<int, (EXTRA)>{});       \
+        VQA_GSTAMP(6);                                                                                                \
+        VQA_T_BARRIER();                                                                                              \
+        VQA_GSTAMP(7);                                                                                                \
+        VQA_GSTAMP_FLUSH(stamp_kt_);                                                                                  \
+        ++stamp_kt_;                                                                                                  \
+    } while (0)
+            [[maybe_unused]] int stamp_kt_ = 0;
+            if constexpr (ONEBAR == 1) {
+                static_assert(ONEBAR != 1 || D >= 2, "the one-barrier loop needs three stages");
+                constexpr int kEx = (kStatsEarly && !(VQA_FOLD_ABLATE & 2)) ? 4 * MT : 0;
+                // statistics loads in flight during the last two K-steps: they count in a wait only when they are NEWER than the
+                // pieces it is for (K-step s + 2, issued in iteration s + 2 - D; the loads go out before iteration KT - 2)
+                for (int kt = 0; kt < KT - 2; kt += 2) {
+                    VQA_T_STEP1(wf, xf, wf2, xf2, 0);
+                    VQA_T_STEP1(wf2, xf2, wf, xf, 0);
+                }
+                if constexpr (kEx > 0) load_stats();
+                VQA_T_STEP1(wf, xf, wf2, xf2, (D > 2 ? kEx : 0));
+                VQA_T_STEP1(wf2, xf2, wf, xf, (D > 3 ? kEx : 0));
+            } else
             if constexpr (kStatsEarly && !(VQA_FOLD_ABLATE & 2)) {
                 // the last two K-steps run with the 4 MT statistics loads in flight.  The pieces their waits are for (K-step
                 // kappa + 1, issued D - 1 steps before) are older than those loads when D >= 3 -- the loads stay outstanding
@@ -845,7 +1010,10 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
     else run(std::true_type{});
     tile_wait_vmcnt<0>();  // the pieces issued past the end of the stream land before the LDS is released
 #undef VQA_T_READ
+#undef VQA_T_READ_SET
 #undef VQA_T_MMA
+#undef VQA_T_MMA_SET
+#undef VQA_T_STEP1
 #undef VQA_T_BARRIER
 }
 
@@ -1340,13 +1508,13 @@ int upload_folded(const float* src, int N, int K, const float* gamma, const floa
 
 constexpr int kTokenPad = 256;  // activation buffers are padded to this many rows (the tallest tile)
 
-template <int EPI, int BM, int BN, int WM, int WN, int BK, int FOLD = 0>
+template <int EPI, int BM, int BN, int WM, int WN, int BK, int FOLD = 0, int ONEBAR = 0>
 int launch_tile(const _Float16* A, const _Float16* W, const float* bias, const _Float16* R, _Float16* C, int M, int N, int K,
                 int num_cu, hipStream_t s, const FoldArgs& fa = FoldArgs{}) {
     using G = TileGeom<BM, BN, BK>;
     static VqaPerDeviceOnce once;
     int rc = once.run([&](int) -> int {
-        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<EPI, BM, BN, WM, WN, BK, FOLD>),
+        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<EPI, BM, BN, WM, WN, BK, FOLD, ONEBAR>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::kLds));
         return VQA_OK;
     });
@@ -1364,7 +1532,7 @@ int launch_tile(const _Float16* A, const _Float16* W, const float* bias, const _
         if (nb_force >= 0 && (nb_force == 0 || (tiles_n % nb_force == 0 && per % nb_force == 0 && rows % (per / nb_force) == 0)))
             nb = nb_force;
     }
-    hipLaunchKernelGGL((gemm_tile_kernel<EPI, BM, BN, WM, WN, BK, FOLD>), dim3(grid), dim3(512), G::kLds, s, A, W, bias, R, C, M, N,
+    hipLaunchKernelGGL((gemm_tile_kernel<EPI, BM, BN, WM, WN, BK, FOLD, ONEBAR>), dim3(grid), dim3(512), G::kLds, s, A, W, bias, R, C, M, N,
                        K, tiles_n, tiles, nb, fa);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
@@ -1499,6 +1667,48 @@ int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, const _
 }
 
 }  // namespace
+
+#ifdef VQA_DEV
+// dev-only entry points (scripts/gemm_bench.py; built with -DVQA_DEV into a variant library, never part of the product build):
+// one GEMM of the encoder through a chosen tile shape (index into kTileShapes, -1 = the launcher's own choice)
+extern "C" int vqa_dev_gemm(const void* A, const void* W, const float* bias, const void* R, void* C, int M, int N, int K, int epi,
+                            int shape, void* stream) {
+    const _Float16 *a = (const _Float16*)A, *w = (const _Float16*)W, *r = (const _Float16*)R;
+    _Float16* c = (_Float16*)C;
+    hipStream_t s = (hipStream_t)stream;
+    hipDeviceProp_t prop;
+    int dev = 0;
+    VQA_HIP_CHECK(hipGetDevice(&dev));
+    VQA_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    const int cu = prop.multiProcessorCount;
+#define VQA_DEV_SHAPE(E)                                                                                \
+    switch (shape) {                                                                                    \
+        case 0: return launch_tile<E, 256, 288, 4, 2, 32>(a, w, bias, r, c, M, N, K, cu, s);            \
+        case 1: return launch_tile<E, 256, 192, 4, 2, 32>(a, w, bias, r, c, M, N, K, cu, s);            \
+        case 2: return launch_tile<E, 256, 128, 4, 2, 64>(a, w, bias, r, c, M, N, K, cu, s);            \
+        case 3: return launch_tile<E, 128, 192, 2, 4, 64>(a, w, bias, r, c, M, N, K, cu, s);            \
+        case 4: return launch_tile<E, 256, 128, 4, 2, 32>(a, w, bias, r, c, M, N, K, cu, s);            \
+        case 5: return launch_tile<E, 256, 256, 4, 2, 32>(a, w, bias, r, c, M, N, K, cu, s);            \
+        case 6: return launch_tile<E, 128, 128, 4, 2, 64>(a, w, bias, r, c, M, N, K, cu, s);            \
+        case 7: return launch_tile<E, 256, 192, 4, 2, 32, 0, 1>(a, w, bias, r, c, M, N, K, cu, s);      \
+        case 8: return launch_tile<E, 256, 256, 4, 2, 32, 0, 1>(a, w, bias, r, c, M, N, K, cu, s);      \
+        case 9: return launch_tile<E, 256, 128, 4, 2, 64, 0, 1>(a, w, bias, r, c, M, N, K, cu, s);      \
+        case 10: return launch_tile<E, 128, 192, 2, 4, 64, 0, 1>(a, w, bias, r, c, M, N, K, cu, s);     \
+        case 11: return launch_tile<E, 128, 128, 4, 2, 64, 0, 1>(a, w, bias, r, c, M, N, K, cu, s);     \
+        default: return launch_gemm<E>(a, w, bias, r, c, M, N, K, s);                                   \
+    }
+    if (epi == 0) { VQA_DEV_SHAPE(0) }
+    if (epi == 1) { VQA_DEV_SHAPE(1) }
+    VQA_DEV_SHAPE(2)
+#undef VQA_DEV_SHAPE
+}
+#ifdef VQA_GSTAMPS
+extern "C" int vqa_dev_read_gstamps(unsigned long long* out, int n) {
+    const size_t bytes = sizeof(unsigned long long) * (size_t)(n < 8 * 64 * kGStampSlots ? n : 8 * 64 * kGStampSlots);
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_gstamps), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
+#endif
 
 extern "C" void vqa_encoder_destroy(vqa_encoder* e) {
     if (!e) return;
