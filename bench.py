@@ -314,7 +314,7 @@ def main():
                        "parallelism": f"row-shard x{world}"},
             # per-step event times on rank 0's stream (the bracketed wall clock above is what value / ms_per_step report)
             "step_ms": percentiles(np, step_ms),
-            "roofline": {"bound": "hbm", "kernel": f"score_topk_kernel<1, {mode}, 0>", "achieved": round(achieved, 1) if achieved else None,
+            "roofline": {"bound": "hbm", "kernel": f"score_topk_kernel<1, {mode}, 0, 0>", "achieved": round(achieved, 1) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "traffic": traffic, "kernel_ms": round(kern_ms, 4), "launches": launches,
                          "bytes_per_launch": info.bytes_per_launch, "flops_per_launch": info.flops_per_launch,
@@ -324,7 +324,7 @@ def main():
                          "step_minus_kernel_ms": round(float(np.median(step_ms)) - kern_ms, 4) if launches else None,
                          "seed_pass_rows": int(info.seed_tiles) * int(info.rows_per_tile),
                          # two-stage search: the dominant launch covers rows_per_launch of the shard's rows, a first-stage
-                         # launch of the same code (symbol score_topk_kernel<1, DT, 1>) the first first_stage_rows; bytes,
+                         # launch of the same code (symbol score_topk_kernel<1, DT, 1, 0>) the first first_stage_rows; bytes,
                          # flops, achieved and kernel_ms above are the dominant launch's alone.  whole_step_frac prices the
                          # WHOLE step (every launch, merges, gaps) as one read of the shard: shard bytes / median step / peak
                          "rows_per_launch": int(info.rows_per_launch), "first_stage_rows": int(info.first_stage_rows),

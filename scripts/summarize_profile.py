@@ -20,8 +20,8 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
     agg = collections.defaultdict(list)
     for r in rows(sub, "counter_collection.csv"):
         # the main launch: score_topk_kernel<1, DT, 0> (<1, DT, 1> is the first stage of a two-stage search, <0, ..> the seed pass)
-        if re.search(r"score_topk_kernel<1, \d, 0>|score_topk_kernelILi1ELi\dELi0E", r["Kernel_Name"]):
-            main_name = r["Kernel_Name"].split("(")[0]
+        if re.search(r"score_topk_kernel<1, \d, 0(, \d)?>|score_topk_kernelILi1ELi\dELi0E", r["Kernel_Name"]):
+            main_name = re.search(r"score_topk_kernel(<[^>]*>|IL\w*E)", r["Kernel_Name"]).group(0)
             agg[r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     for name, v in agg.items():
         v = v[3:] if len(v) > 6 else v  # drop the warm-up launches

@@ -1157,40 +1157,45 @@ __global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restri
     }
 }
 
-// ---- attention on the matrix cores (head size 64, L <= 256): one workgroup per (sequence, head), one wave per block of
-// 32 queries.  S^T = K . Q^T with v_mfma_f32_32x32x16_f16 (A = keys, B = queries: a lane then holds ONE query's scores
+// ---- attention on the matrix cores (head size 64, L <= 256): one workgroup per (sequence, HPW heads), one wave per head and
+// block of 32 queries.  S^T = K . Q^T with v_mfma_f32_32x32x16_f16 (A = keys, B = queries: a lane then holds ONE query's scores
 // for 16 keys per 32-key block in registers, so the softmax is register-local plus one cross-half shuffle); the
 // normalised probabilities, converted to fp16, are used straight from the accumulator registers as the A operand of
-// P . V (X^T . B form: no lane movement), with V read from a transposed LDS image in the matching permuted key order.
+// P . V (X^T . B form: no lane movement).  V sits in LDS ROW-major, as it lies in memory (16-byte stores), and the B operand --
+// 8 keys of one head dimension per lane, in the permuted key order of the accumulator registers -- comes out of it through the
+// transposing read ds_read_b64_tr_b16: per 16-lane group a block of 4 keys x 16 dimensions, lane i gets dimension i of the 4
+// keys.  (Round 2 wrote a transposed image with 2-byte LDS stores: 82 % of the kernel's LDS cycles were bank conflicts.)
+// Image: key row of 128 B = two 64-byte halves (dimensions 0-31 | 32-63), the halves of rows with bit 1 of the key set are
+// swapped, so the four rows of a block start on banks 0 / 32 / 16 / 48: every transposed read and every store is conflict-free.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 constexpr int kAttDh = 64;
 constexpr int kAttMaxBlocks = 8;  // L <= 256
 
-template <int NQB>
-__global__ __launch_bounds__(64 * NQB) void attention_mfma_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ mask,
-                                                                   int Lmax, int H, int heads, const int* __restrict__ cu,
-                                                                   _Float16* __restrict__ ctx) {
+template <int NQB, int HPW>
+__global__ __launch_bounds__(64 * NQB * HPW) void attention_mfma_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ mask,
+                                                                         int Lmax, int H, int heads, const int* __restrict__ cu,
+                                                                         _Float16* __restrict__ ctx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int Lp = NQB * 32;
-    constexpr int kVtStride = Lp + 8;  // halves per dim row (+16 B so that consecutive dims start on different banks)
-    _Float16* vt = reinterpret_cast<_Float16*>(smem);  // [64][kVtStride]
-    const int seq = blockIdx.x / heads, head = blockIdx.x - seq * heads;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hw = wave / NQB, qb = wave - hw * NQB;  // head inside the workgroup, query block
+    const int groups = heads / HPW;
+    const int seq = blockIdx.x / groups, head = (blockIdx.x - seq * groups) * HPW + hw;
+    char* vimg = smem + hw * (Lp * 128);  // this head's V image: [Lp keys][128 B]
     const int li = lane & 31, h = lane >> 5;
     const size_t row_stride = (size_t)3 * H;
     // packed rows: the sequence owns rows [cu[seq], cu[seq + 1]) and every one of them is a real token
     const size_t row0 = cu ? (size_t)cu[seq] : (size_t)seq * Lmax;
     const int L = cu ? cu[seq + 1] - cu[seq] : Lmax;
     const _Float16* base = qkv + row0 * row_stride + head * kAttDh;
-    // V -> LDS, transposed (keys beyond L are zero)
-    for (int i = tid; i < Lp * 8; i += 64 * NQB) {
+    // V -> LDS by the NQB waves of this head, 16 bytes per lane and step (keys beyond L are zero)
+    for (int i = tid - hw * 64 * NQB; i < Lp * 8; i += 64 * NQB) {
         const int key = i >> 3, ch = i & 7;
         half8 v = half8{0, 0, 0, 0, 0, 0, 0, 0};
         if (key < L) v = *reinterpret_cast<const half8*>(base + (size_t)key * row_stride + 2 * H + ch * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) vt[(ch * 8 + e) * kVtStride + key] = v[e];
+        *reinterpret_cast<half8*>(vimg + key * 128 + (((ch >> 2) ^ ((key >> 1) & 1)) << 6) + ((ch & 3) << 4)) = v;
     }
-    const int qb = wave;
     const int qrow = qb * 32 + li < L ? qb * 32 + li : L - 1;  // padded query rows recompute the last row, never stored
     half8 qf[4];
 #pragma unroll
@@ -1233,7 +1238,13 @@ __global__ __launch_bounds__(64 * NQB) void attention_mfma_kernel(const _Float16
         }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
-    __syncthreads();  // V^T image complete
+    __syncthreads();  // V images complete
+    // transposed read of this lane: block row q_ = (lane & 15) >> 2 (+ the key base), columns 4 p_ .. 4 p_ + 3 of the 16-lane
+    // group's 16 dimensions 16 (group & 1) ..; rows k0 + q_ with k0 a multiple of 4, so the half swap of a row is (q_ >> 1) & 1
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+    const int q_ = (lane & 15) >> 2, p_ = lane & 3, gi = lane >> 4;
+    const int tr_off = q_ * 128 + ((gi & 1) << 5) + (p_ << 3);  // + key base * 128 + (db ^ swap) * 64
+    const int swap = (q_ >> 1) & 1;
     f32x16 o[2] = {};
 #pragma unroll
     for (int kb = 0; kb < NQB; ++kb)
@@ -1246,12 +1257,12 @@ __global__ __launch_bounds__(64 * NQB) void attention_mfma_kernel(const _Float16
             const int k0 = kb * 32 + 16 * s2 + 4 * h;
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                const _Float16* vrow = vt + (db * 32 + li) * kVtStride + k0;
-                typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-                const half4 lo = *reinterpret_cast<const half4*>(vrow);
-                const half4 hi = *reinterpret_cast<const half4*>(vrow + 8);
-                const half8 vf = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, vf, o[db], 0, 0, 0);
+                const char* at = vimg + k0 * 128 + ((db ^ swap) << 6) + tr_off;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(at));             // keys k0 .. k0 + 3
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(at + 8 * 128));   // keys k0 + 8 .. k0 + 11
+                typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
+                const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, __builtin_bit_cast(half8, both), o[db], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -1905,16 +1916,35 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
         if (rc != VQA_OK) return rc;
         if (dh == kAttDh && L <= 32 * kAttMaxBlocks) {
             const int nqb = (L + 31) / 32;
-            const size_t lds = (size_t)kAttDh * (nqb * 32 + 8) * sizeof(_Float16);
-#define VQA_ATT(NQB)                                                                                                   \
-    case NQB:                                                                                                          \
-        hipLaunchKernelGGL(attention_mfma_kernel<NQB>, dim3(B * heads), dim3(64 * NQB), lds, s, e->qkv, attn_mask, L, H, heads, \
-                           cu, e->ctx);                                                                               \
+            // heads per workgroup: as many as keep the workgroup at <= 512 threads and divide the head count
+            int hpw = nqb <= 2 ? 4 : nqb <= 4 ? 2 : 1;
+            while (heads % hpw) hpw >>= 1;
+            const size_t lds = (size_t)hpw * nqb * 32 * 128;  // per head: [32 nqb keys][128 B]
+#define VQA_ATT(NQB, HPW)                                                                                                   \
+    hipLaunchKernelGGL((attention_mfma_kernel<NQB, HPW>), dim3(B * (heads / HPW)), dim3(64 * NQB * HPW), lds, s, e->qkv, attn_mask, \
+                       L, H, heads, cu, e->ctx)
+#define VQA_ATT_H(NQB)                             \
+    case NQB:                                      \
+        if (hpw == 4) VQA_ATT(NQB, 4);             \
+        else if (hpw == 2) VQA_ATT(NQB, 2);        \
+        else VQA_ATT(NQB, 1);                      \
+        break;
+#define VQA_ATT_L(NQB)                             \
+    case NQB:                                      \
+        if (hpw == 2) VQA_ATT(NQB, 2);             \
+        else VQA_ATT(NQB, 1);                      \
+        break;
+#define VQA_ATT_1(NQB)                             \
+    case NQB:                                      \
+        VQA_ATT(NQB, 1);                           \
         break;
             switch (nqb) {
-                VQA_ATT(1) VQA_ATT(2) VQA_ATT(3) VQA_ATT(4) VQA_ATT(5) VQA_ATT(6) VQA_ATT(7) VQA_ATT(8)
+                VQA_ATT_H(1) VQA_ATT_H(2) VQA_ATT_L(3) VQA_ATT_L(4) VQA_ATT_1(5) VQA_ATT_1(6) VQA_ATT_1(7) VQA_ATT_1(8)
             }
 #undef VQA_ATT
+#undef VQA_ATT_H
+#undef VQA_ATT_L
+#undef VQA_ATT_1
         } else {
             hipLaunchKernelGGL(attention_kernel, dim3(B * heads), dim3(256), attn_lds, s, e->qkv, attn_mask, L, H, heads, e->ctx);
         }
