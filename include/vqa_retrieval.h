@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VQA_VERSION 103 /* 0.1.3: vqa_launch_info reports the fused seed / stage merges; host rows upload through pinned staging */
+#define VQA_VERSION 103 /* 0.1.3: VQA_INDEX_SKETCH, vqa_launch_info.sketch_scan; host rows upload through pinned staging */
 
 /* error codes */
 #define VQA_OK 0
@@ -41,6 +41,12 @@ extern "C" {
 
 /* vqa_index_create flags */
 #define VQA_INDEX_HAS_IDS 1 /* reserve the id vector even though ids_or_null is NULL (filled later by vqa_index_set_rows) */
+#define VQA_INDEX_SKETCH 2  /* fp16 shards: keep an int8 sketch of the rows beside them (+50 % memory).  Large shards (the
+                             * two-stage search: >= 24 tiles of 256 rows per compute unit, k <= VQA_MAX_K) then run their main
+                             * launch over the sketch -- v_mfma_i32_16x16x64_i8, half the bytes and twice the matrix rate per
+                             * row -- with a rigorous upper bound on every (query, row) score, and score exactly (fp16 rows, fp32
+                             * accumulation) only the pairs the bound cannot exclude: the results are those of the exact scan.
+                             * Ignored for other storage types. */
 
 /* limits of the fused scoring + top-k kernel */
 #define VQA_MAX_K 12       /* top-k per query found by ONE exact pass over the index (LDS candidate lists; BASELINE k = 10) */
@@ -118,6 +124,9 @@ typedef struct vqa_launch_info {
     int32_t seed_tiles;       /* tiles of rows_per_tile rows the seeding pass scores */
     int64_t first_stage_rows; /* large shards, k <= VQA_MAX_K: rows scored by the first-stage launch of the same kernel (its exact
                                * k-th best scores seed the main launch's thresholds); 0 = the main launch covers every row */
+    int32_t sketch_scan;      /* 1: the main launch scans the int8 sketch (VQA_INDEX_SKETCH): bytes_per_launch counts one byte per
+                               * element, flops_per_launch the same multiply-adds (int8 x int8 -> int32) */
+    int32_t pad_;
 } vqa_launch_info;
 int vqa_index_launch_info(const vqa_index* index, int32_t B, int32_t k, vqa_launch_info* out);
 int vqa_index_set_timing(vqa_index* index, int32_t enabled);

@@ -115,7 +115,10 @@ def test_two_stage_300001_x_64_against_fp64(native_lib, dtype):
     _check(s, p, exp_sc, exp_pos, **tol)
     assert p[0, :4].tolist() == [5, 6, 7, 40_000] and p[1, :3].tolist() == [65_535, 65_536, 65_537]
     assert p[2, :3].tolist() == [100_000, 250_000, 300_000] and p[3, :2].tolist() == [1000, 200_001]
-    # the same search in one stage returns the same bits
+    # the same search in one stage returns the same rows; the same bits too for fp8 -- an fp16 shard of this size runs its main
+    # launch over the int8 sketch and scores the surviving pairs in a summation order of its own (last-bit differences)
     s1, p1, ix1, info1 = _search(x16, q16, dtype, env={"VQA_STAGE_MIN": "0"})
     ix1.close()
-    assert info1.first_stage_rows == 0 and np.array_equal(p, p1) and np.array_equal(s, s1)
+    assert info1.first_stage_rows == 0 and np.array_equal(p, p1)
+    assert info.sketch_scan == (1 if dtype == "fp16" else 0) and info1.sketch_scan == 0
+    assert np.array_equal(s, s1) if dtype == "fp8" else np.abs(s - s1).max() <= 3e-7

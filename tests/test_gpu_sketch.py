@@ -1,0 +1,124 @@
+"""The int8 sketch pre-pass of large fp16 shards (include/vqa_retrieval.h VQA_INDEX_SKETCH) -- needs an MI355X.
+
+A shard large enough for the two-stage search runs its main launch over an int8 sketch of the rows (v_mfma_i32_16x16x64_i8:
+half the bytes, twice the matrix rate per row) with a RIGOROUS upper bound on every (query, row) score, and scores exactly
+-- fp16 rows, fp32 accumulation -- only the pairs the bound cannot exclude.  The results must be those of the exact scan:
+the oracle's rows (tie-aware), the exact scan's rows position for position, scores within the last bits of fp32, exact
+duplicates bit-equal and in position order whichever stage they sit in.  VQA_STAGE_MIN brings the switch-over down to sizes
+the oracle handles (131 072 rows on 256 compute units)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import retrieval as R
+
+pytestmark = pytest.mark.gpu
+SCORE_TOL, TIE_TOL = 1e-5, 2e-6
+
+
+def _unit(rng, n, d):
+    return R.l2_normalize(rng.standard_normal((n, d)).astype(np.float32)).astype(np.float16)
+
+
+def _index(x, monkeypatch, sketch, stage_min="2", ids=None, id_base=0):
+    from vietnamese_qa_system_amd.index import DeviceIndex
+    monkeypatch.setenv("VQA_STAGE_MIN", stage_min)
+    return DeviceIndex(x, ids=ids, id_base=id_base, dtype="fp16", device=0, sketch=sketch)
+
+
+def _search(ix, q, k):
+    s, i, p = ix.search(torch.from_numpy(q).cuda(), k, return_positions=True)
+    torch.cuda.synchronize()
+    return s.cpu().numpy(), i.cpu().numpy(), p.cpu().numpy()
+
+
+@pytest.mark.parametrize("n,d,b,k", [(300_001, 64, 41, 10), (200_000, 100, 256, 12), (150_000, 768, 64, 1), (262_144, 128, 7, 10)])
+def test_sketch_search_equals_the_exact_scan(native_lib, monkeypatch, n, d, b, k):
+    rng = np.random.default_rng(n + d)
+    x, q = _unit(rng, n, d), _unit(rng, b, d)
+    dup = [3, 40_000, 65_535, 65_536, n - 1]  # exact duplicates in the first stage, astride its end (256 tiles) and in the last tile
+    for r in dup[1:]:
+        x[r] = x[dup[0]]
+    q[0] = x[dup[0]]
+    ids = np.arange(n, dtype=np.int64) * 5 + 9
+    ref = _index(x, monkeypatch, sketch=False, ids=ids)
+    ske = _index(x, monkeypatch, sketch=True, ids=ids)
+    assert ref.launch_info(b, k).sketch_scan == 0 and ske.launch_info(b, k).sketch_scan == 1
+    assert ske.launch_info(b, k).first_stage_rows == 256 * 256
+    assert ske.launch_info(b, k).bytes_per_launch == (n - 65536) * d  # one byte per element
+    s0, i0, p0 = _search(ref, q, k)
+    s1, i1, p1 = _search(ske, q, k)
+    s2, _, p2 = _search(ske, q, k)  # the handle's candidate buffers are reused: same bits again
+    ref.close()
+    ske.close()
+    assert np.array_equal(p1, p2) and np.array_equal(s1, s2)
+    s_full = R.full_scores(q.astype(np.float32), x, R.DTYPE_F16)
+    R.check_topk(s1, p1, s_full, k, score_tol=SCORE_TOL, tie_tol=TIE_TOL)
+    assert np.array_equal(p1, p0), "the sketch search returns other rows than the exact scan"
+    assert np.array_equal(i1, ids[p1]) and np.abs(s1 - s0).max() <= 3e-7
+    nd = min(k, len(dup))
+    assert p1[0, :nd].tolist() == dup[:nd] and len(set(s1[0, :nd].tolist())) == 1  # bit-equal scores, position order
+
+
+def test_rows_the_bound_cannot_prune_take_the_exact_fallback(native_lib, monkeypatch):
+    """Every row equal to every query: each (query, row) pair is a candidate, the scan's regions fill up, the overflow flag
+    sends the search through the exact main launch (gated on the flag, no host round trip) -- same bits as the exact scan."""
+    n, d, b, k = 200_000, 64, 48, 10
+    rng = np.random.default_rng(1)
+    v = _unit(rng, 1, d)
+    x = np.repeat(v, n, axis=0)
+    x[77_777] = _unit(rng, 1, d)[0]  # one row that is not a duplicate
+    q = np.repeat(v, b, axis=0)
+    ref = _index(x, monkeypatch, sketch=False)
+    ske = _index(x, monkeypatch, sketch=True)
+    s0, _, p0 = _search(ref, q, k)
+    s1, _, p1 = _search(ske, q, k)
+    ref.close()
+    ske.close()
+    assert np.array_equal(p1, p0) and np.array_equal(s1, s0)
+    assert p1[0].tolist() == list(range(k))  # ties by position
+
+
+def test_outlier_rows_unnormalised_rows_and_zero_rows(native_lib, monkeypatch):
+    """The bound holds for any fp16 rows: a tile whose scale one huge component sets (coarse codes for its other rows), rows of
+    norm 30, zero rows, a zero query."""
+    n, d, b, k = 180_000, 96, 32, 10
+    rng = np.random.default_rng(5)
+    x, q = _unit(rng, n, d), _unit(rng, b, d)
+    x[70_000, 5] = np.float16(900.0)        # one component of one row: the scale of its tile grows 5000-fold
+    x[70_001] = (x[70_001].astype(np.float32) * 30).astype(np.float16)
+    x[100_000:100_300] = 0
+    x[150_000] = (q[3].astype(np.float32) * 0.5).astype(np.float16)
+    q[1] = 0
+    q[2, 5] = np.float16(1.0)               # looks along the outlier component
+    ref = _index(x, monkeypatch, sketch=False)
+    ske = _index(x, monkeypatch, sketch=True)
+    s0, _, p0 = _search(ref, q, k)
+    s1, _, p1 = _search(ske, q, k)
+    ref.close()
+    ske.close()
+    s_full = R.full_scores(q.astype(np.float32), x, R.DTYPE_F16)
+    R.check_topk(s1, p1, s_full, k, score_tol=2e-3, tie_tol=1e-3)  # scores up to 900: the tolerance is relative to them
+    keep = np.arange(b) != 1  # (the zero query scores 0 everywhere: any rows are a valid answer, by position)
+    assert np.array_equal(p1[keep], p0[keep]) and p1[2, 0] == 70_000 and p1[1].tolist() == list(range(k))
+    assert np.abs(s1 - s0).max() <= 1e-4 * max(1.0, np.abs(s0[np.isfinite(s0)]).max())
+
+
+def test_shard_filled_in_unaligned_chunks_has_a_consistent_sketch(native_lib, monkeypatch):
+    """vqa_index_set_rows re-derives the sketch of every tile a call touches from the stored rows, so chunks that start and end
+    inside tiles leave the same sketch as one call -- and the same results, bit for bit."""
+    from vietnamese_qa_system_amd.index import DeviceIndex
+    n, d, b, k = 150_003, 64, 16, 10
+    rng = np.random.default_rng(9)
+    x, q = _unit(rng, n, d), _unit(rng, b, d)
+    whole = _index(x, monkeypatch, sketch=True)
+    monkeypatch.setenv("VQA_STAGE_MIN", "2")
+    parts = DeviceIndex.empty(n, d, dtype="fp16", device=0, sketch=True)
+    for lo, hi in ((100_000, 150_003), (0, 777), (777, 40_001), (40_001, 100_000)):
+        parts.set_rows(lo, x[lo:hi])
+    assert parts.launch_info(b, k).sketch_scan == 1
+    s0, _, p0 = _search(whole, q, k)
+    s1, _, p1 = _search(parts, q, k)
+    whole.close()
+    parts.close()
+    assert np.array_equal(p0, p1) and np.array_equal(s0, s1)

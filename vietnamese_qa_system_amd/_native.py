@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("VQA_LIB") or os.path.join(_HERE, "lib", "libvqa_retri
 VQA_VERSION = 103  # include/vqa_retrieval.h: the ABI these bindings were written against
 VQA_F32, VQA_F16, VQA_FP8_E4M3 = 0, 1, 2
 VQA_INDEX_HAS_IDS = 1
+VQA_INDEX_SKETCH = 2
 VQA_QUERY_TILE = 256
 VQA_POOL_CLS, VQA_POOL_MEAN = 0, 1
 
@@ -39,7 +40,8 @@ class LaunchInfo(ctypes.Structure):
     _fields_ = [("grid", ctypes.c_int32), ("block", ctypes.c_int32), ("lds_bytes", ctypes.c_int32),
                 ("rows_per_tile", ctypes.c_int32), ("rows_per_launch", ctypes.c_int64),
                 ("bytes_per_launch", ctypes.c_int64), ("flops_per_launch", ctypes.c_int64),
-                ("seed_grid", ctypes.c_int32), ("seed_tiles", ctypes.c_int32), ("first_stage_rows", ctypes.c_int64)]
+                ("seed_grid", ctypes.c_int32), ("seed_tiles", ctypes.c_int32), ("first_stage_rows", ctypes.c_int64),
+                ("sketch_scan", ctypes.c_int32), ("pad_", ctypes.c_int32)]
 
 
 class EncoderConfig(ctypes.Structure):

@@ -62,12 +62,29 @@ struct vqa_index {
     vqa_key* upper = nullptr;    // [256] last key returned per query (continuation passes of a search with k > 12)
     int* wide_flag = nullptr;    // 1 = the one-pass large-k result could not be verified: the gated continuation passes run
     bool wide = true;            // VQA_WIDE_K=0 disables the one-pass large-k attempt
+    // int8 sketch of a large fp16 shard (VQA_INDEX_SKETCH): the rigorous pruning pre-pass of the main launch (score_topk.hip MODE 2)
+    bool sketch = false;
+    int32_t d_pad8 = 0;             // sketch row length (multiple of 128 elements)
+    void* rows8 = nullptr;          // TILED int8: ceil(n/256) tiles x (d_pad8/64) blocks of 16 KiB
+    size_t rows8_bytes = 0;
+    float* tile_info = nullptr;     // [tiles][4]: max ||x_hi||, max ||x_lo||, 1 / scale, scale of every 256-row tile (x_int = rint(x / scale))
+    void* q8_stage = nullptr;       // sketch of the staged query tile
+    float* qrow = nullptr;          // [3][256] per query: scale, ||q_lo||, ||q||
+    float* qconst = nullptr;        // [4][256] the scan's per-query constants
+    unsigned long long* regions = nullptr;  // [max_grid][kSketchCap] candidate pairs per workgroup of the scan
+    unsigned* region_cnt = nullptr;         // [max_grid]
+    vqa_key* cand_keys = nullptr;           // [256][kSketchCap] exact (score, position) keys per query
+    unsigned* cand_cnt = nullptr;           // [256]
+    int* sketch_flag = nullptr;             // 1 = a candidate buffer filled up: the exact fallback scan runs
+    long long* stage_pos = nullptr;         // [256][max_k] row positions of the first stage's top-k
     // opt-in kernel timing (bench.py): event pairs around the main scoring kernel
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
     size_t ev_used = 0;
     std::atomic_flag busy = ATOMIC_FLAG_INIT;  // one search at a time per handle (the workspace is shared)
 };
+
+constexpr int kSketchCap = 16384;  // candidate pairs per workgroup region / keys per query list (expected: 2-4 thousand at 10M rows)
 
 struct HandleBusy {  // a second concurrent call on one handle is refused instead of corrupting the shared workspace
     std::atomic_flag& f;
@@ -103,6 +120,10 @@ extern "C" void vqa_index_destroy(vqa_index* ix) {
         if (ix->up_done[b]) (void)hipEventDestroy(ix->up_done[b]);
     }
     if (ix->up_stream) (void)hipStreamDestroy(ix->up_stream);
+    for (void* p : {(void*)ix->rows8, (void*)ix->tile_info, ix->q8_stage, (void*)ix->qrow, (void*)ix->qconst,
+                    (void*)ix->regions, (void*)ix->region_cnt, (void*)ix->cand_keys, (void*)ix->cand_cnt, (void*)ix->sketch_flag,
+                    (void*)ix->stage_pos})
+        if (p) (void)hipFree(p);
     if (ix->partial) (void)hipFree(ix->partial);
     if (ix->thr0) (void)hipFree(ix->thr0);
     if (ix->upper) (void)hipFree(ix->upper);
@@ -201,6 +222,19 @@ extern "C" int vqa_index_set_rows(vqa_index* ix, int64_t first, int64_t count, c
         int rc = upload_host_rows(ix, first, count, rows, src_dtype);
         if (rc != VQA_OK) return rc;
     }
+    if (ix->sketch) {
+        // the sketch of every tile these rows touch, from the stored fp16 values: the tile's scale (max |x| / 127 over its 256
+        // rows), then its rows' int8 codes and the two maxima the pruning bound needs -- whole tiles, so a tile filled by
+        // several calls always ends up consistent
+        VQA_HIP_CHECK(hipStreamSynchronize(nullptr));
+        const int64_t t0 = first >> 8, t1 = (first + count - 1) >> 8;
+        int rc = vqa_launch_tile_scales(ix->rows, t0, t1 - t0 + 1, ix->d_pad, ix->tile_info, nullptr);
+        if (rc != VQA_OK) return rc;
+        const int64_t r0 = t0 * 256, r1 = std::min<int64_t>(ix->n, (t1 + 1) * 256);
+        rc = vqa_launch_sketch_rows(ix->rows, r0, r1 - r0, ix->d_pad, ix->d_pad8, ix->tile_info, ix->rows8, nullptr, nullptr, nullptr,
+                                    nullptr);
+        if (rc != VQA_OK) return rc;
+    }
     if (ids_or_null) VQA_HIP_CHECK(hipMemcpy(ix->ids + first, ids_or_null, (size_t)count * 8, hipMemcpyDefault));
     VQA_HIP_CHECK(hipStreamSynchronize(nullptr));
     return VQA_OK;
@@ -213,7 +247,7 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
     VQA_REQUIRE(n >= 0 && n < 0xFFFFFFFFll, "vqa_index_create: n=%lld outside [0, 2^32-1) rows per shard", (long long)n);
     VQA_REQUIRE(d >= 1 && d <= 65536, "vqa_index_create: d=%d", d);
     VQA_REQUIRE(dtype == VQA_F32 || dtype == VQA_F16 || dtype == VQA_FP8_E4M3, "vqa_index_create: dtype %d", dtype);
-    VQA_REQUIRE((flags & ~(uint32_t)VQA_INDEX_HAS_IDS) == 0, "vqa_index_create: unknown flags 0x%x", flags);
+    VQA_REQUIRE((flags & ~(uint32_t)(VQA_INDEX_HAS_IDS | VQA_INDEX_SKETCH)) == 0, "vqa_index_create: unknown flags 0x%x", flags);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         vqa_set_error("vqa_index_create: no HIP device visible");
@@ -294,6 +328,34 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
             vqa_set_error("vqa_index_create: workspace allocation failed");
             rc = VQA_ENOMEM;
             break;
+        }
+        // int8 sketch: fp16 shards only, and only where a workgroup's tile maxima fit the scan's LDS
+        // (and only for shards large enough for the two-stage search, whose main launch the sketch scan replaces)
+        ix->sketch = (flags & VQA_INDEX_SKETCH) && dtype == VQA_F16 && n > 0 && ix->stage_min_tiles > 0 &&
+                     tiles >= (int64_t)ix->stage_min_tiles * ix->max_grid &&
+                     (tiles + ix->max_grid - 1) / ix->max_grid <= vqa_score_topk_sketch_max_tiles() && d <= 8192;
+        if (ix->sketch) {
+            ix->d_pad8 = (d + 127) / 128 * 128;
+            ix->rows8_bytes = (size_t)tiles * 256 * ix->d_pad8;
+            const size_t qc = VQA_QUERY_TILE * sizeof(float);
+            if (hipMalloc(&ix->rows8, ix->rows8_bytes) != hipSuccess || hipMalloc((void**)&ix->tile_info, (size_t)tiles * 16) != hipSuccess ||
+                hipMalloc(&ix->q8_stage, (size_t)VQA_QUERY_TILE * ix->d_pad8) != hipSuccess ||
+                hipMalloc((void**)&ix->qrow, 3 * qc) != hipSuccess || hipMalloc((void**)&ix->qconst, 4 * qc) != hipSuccess ||
+                hipMalloc((void**)&ix->regions, (size_t)ix->max_grid * kSketchCap * 8) != hipSuccess ||
+                hipMalloc((void**)&ix->region_cnt, (size_t)ix->max_grid * 4) != hipSuccess ||
+                hipMalloc((void**)&ix->cand_keys, (size_t)VQA_QUERY_TILE * kSketchCap * sizeof(vqa_key)) != hipSuccess ||
+                hipMalloc((void**)&ix->cand_cnt, VQA_QUERY_TILE * 4) != hipSuccess || hipMalloc((void**)&ix->sketch_flag, 4) != hipSuccess ||
+                hipMalloc((void**)&ix->stage_pos, (size_t)VQA_QUERY_TILE * max_k * 8) != hipSuccess) {
+                vqa_set_error("vqa_index_create: allocating the int8 sketch (%zu bytes) failed", ix->rows8_bytes);
+                rc = VQA_ENOMEM;
+                break;
+            }
+            if (hipMemset(ix->rows8, 0, ix->rows8_bytes) != hipSuccess || hipMemset(ix->tile_info, 0, (size_t)tiles * 16) != hipSuccess ||
+                hipMemset(ix->q8_stage, 0, (size_t)VQA_QUERY_TILE * ix->d_pad8) != hipSuccess) {
+                vqa_set_error("vqa_index_create: clearing the int8 sketch failed");
+                rc = VQA_EHIP;
+                break;
+            }
         }
         if (rows && n > 0) rc = vqa_index_set_rows(ix, 0, n, rows, rows_dtype, ids_or_null);
     } while (0);
@@ -403,6 +465,11 @@ static LaunchPlan plan_launch(const vqa_index* ix, int k = 0) {
     return p;
 }
 
+// the sketch path serves exactly the searches the two-stage plan serves (one exact pass, k <= 12, a large shard)
+static bool sketch_active(const vqa_index* ix, const LaunchPlan& p, int k) {
+    return ix->sketch && p.stage_tiles > 0 && p.grid0 > 0 && k <= vqa_score_topk_max_k(ix->dtype);
+}
+
 extern "C" int vqa_index_launch_info(const vqa_index* ix, int32_t B, int32_t k, vqa_launch_info* out) {
     VQA_REQUIRE(ix && out, "vqa_index_launch_info: null pointer");
     const LaunchPlan p = plan_launch(ix, k);
@@ -413,7 +480,9 @@ extern "C" int vqa_index_launch_info(const vqa_index* ix, int32_t B, int32_t k, 
     out->rows_per_tile = 256;
     out->first_stage_rows = k <= vqa_score_topk_max_k(ix->dtype) ? (int64_t)p.stage_tiles * 256 : 0;
     out->rows_per_launch = ix->n - out->first_stage_rows;
-    out->bytes_per_launch = out->rows_per_launch * (int64_t)ix->d * elem_bytes(ix->dtype);
+    out->sketch_scan = sketch_active(ix, p, k) ? 1 : 0;
+    out->pad_ = 0;
+    out->bytes_per_launch = out->rows_per_launch * (int64_t)ix->d * (out->sketch_scan ? 1 : elem_bytes(ix->dtype));
     out->flops_per_launch = 2 * (int64_t)VQA_QUERY_TILE * out->rows_per_launch * (int64_t)ix->d;
     out->seed_grid = p.grid0;
     out->seed_tiles = p.seed_tiles;
@@ -486,6 +555,12 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
         int rc = vqa_launch_tile_rows(reinterpret_cast<const char*>(q) + (size_t)q0 * ix->d * qeb, q_dtype, 0, VQA_QUERY_TILE, nq,
                                       ix->d, ix->d_pad, ix->dtype, ix->scale, ix->q_stage, stream);
         if (rc != VQA_OK) return rc;
+        const bool use_sketch = sketch_active(ix, p, k);
+        if (use_sketch) {  // the query tile's int8 sketch (every query its own scale) + ||q_lo||, ||q||
+            rc = vqa_launch_sketch_rows(ix->q_stage, 0, VQA_QUERY_TILE, ix->d_pad, ix->d_pad8, nullptr, ix->q8_stage, ix->qrow,
+                                        ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, stream);
+            if (rc != VQA_OK) return rc;
+        }
         // k <= 12: one pass.  Larger k, first attempt: ONE pass in which every workgroup keeps its local top 12 above the
         // seeded threshold (the k-th largest seed, a valid lower bound of the k-th best score), merged to k results.  The
         // global top-k is inside the union of the local lists unless some workgroup owns more than 12 of them (with 256
@@ -576,24 +651,93 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
                 a.first_stage = true;
                 rc = vqa_launch_score_topk(ix->dtype, a, stream);
                 if (rc != VQA_OK) return rc;
-                rc = vqa_launch_merge_partials(ix->partial, p.grid1, kk, nq, kk, nullptr, 0, nullptr, nullptr, nullptr, ix->thr0, 1.0f, kk,
-                                               0, nullptr, true, gate, stream, lists);
+                rc = vqa_launch_merge_partials(ix->partial, p.grid1, kk, nq, kk, nullptr, 0, nullptr, nullptr,
+                                               use_sketch ? reinterpret_cast<int64_t*>(ix->stage_pos) : nullptr, ix->thr0, 1.0f, kk, 0,
+                                               nullptr, true, gate, stream, lists);
                 if (rc != VQA_OK) return rc;
                 a.first_stage = false;
                 a.tile_begin = p.stage_tiles;
                 a.tile_end = p.tiles;
                 a.list_offset = p.grid1;
                 if (ix->f16_loop == 2) a.loop = 1;
+                if (use_sketch) {
+                    // Main launch over the int8 sketch (half the bytes, twice the MFMA rate per row): with theta = the first stage's
+                    // exact k-th best score it leaves the (query, row) pairs whose rigorous upper bound reaches theta; those and the
+                    // first stage's k rows are scored exactly and the k best of each query's list are the result.  Should a
+                    // candidate buffer fill up (adversarial data: the bound prunes nothing), sketch_flag sends the search through
+                    // the exact main launch below, gated on the flag.
+                    rc = vqa_launch_sketch_qconst(ix->thr0, ix->qrow, ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, ix->qconst,
+                                                  ix->cand_cnt, ix->sketch_flag, stream);
+                    if (rc != VQA_OK) return rc;
+                    SketchScanArgs sk;
+                    sk.tile_info = reinterpret_cast<const float4*>(ix->tile_info);
+                    sk.qconst = ix->qconst;
+                    sk.regions = ix->regions;
+                    sk.counts = ix->region_cnt;
+                    sk.overflow = ix->sketch_flag;
+                    sk.cap = kSketchCap;
+                    ScoreTopkArgs b;
+                    b.x = ix->rows8;
+                    b.q = ix->q8_stage;
+                    b.n = ix->n;
+                    b.d_pad = ix->d_pad8;
+                    b.nq = nq;
+                    b.k = kk;
+                    b.thr_init = nullptr;
+                    b.partial = nullptr;
+                    b.tile_begin = p.stage_tiles;
+                    b.tile_end = p.tiles;
+                    b.grid = p.grid1;
+                    b.sketch = &sk;
+                    if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
+                    rc = vqa_launch_score_topk(VQA_I8_SKETCH, b, stream);
+                    if (rc != VQA_OK) return rc;
+                    if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
+                    rc = vqa_launch_rescore(ix->regions, ix->region_cnt, kSketchCap, p.grid1, ix->stage_pos, nq, kk, ix->rows, ix->q_stage,
+                                            ix->d_pad, ix->cand_keys, ix->cand_cnt, kSketchCap, ix->sketch_flag, stream);
+                    if (rc != VQA_OK) return rc;
+                    rc = vqa_launch_merge_partials(ix->cand_keys, 1, kSketchCap, nq, kk, ix->ids, ix->id_base, os, oi, op, nullptr, 1.0f, k, 0,
+                                                   nullptr, true, nullptr, stream, 1, ix->cand_cnt);
+                    if (rc != VQA_OK) return rc;
+                    a.gate = ix->sketch_flag;  // the exact main launch + merge below: only when the flag is up
+                }
             }
-            if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
+            const bool time_it = ix->timing && !(staged && use_sketch);  // a sketch search times its sketch scan instead
+            if (time_it && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
             rc = vqa_launch_score_topk(ix->dtype, a, stream);
             if (rc != VQA_OK) return rc;
-            if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
+            if (time_it && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
             rc = vqa_launch_merge_partials(ix->partial, lists, kk, nq, kk, ix->ids, ix->id_base, os, oi, op, nullptr,
-                                           1.0f / (ix->scale * ix->scale), k, done, done + kk < k ? ix->upper : nullptr, true, gate,
-                                           stream);
+                                           1.0f / (ix->scale * ix->scale), k, done, done + kk < k ? ix->upper : nullptr, true,
+                                           staged && use_sketch ? ix->sketch_flag : gate, stream);
             if (rc != VQA_OK) return rc;
         }
     }
     return VQA_OK;
 }
+
+#ifdef VQA_DEV
+// dev-only (scripts/probes/sketch_probe.py, -DVQA_DEV builds): what the last sketch search left in its candidate buffers --
+// out[0] = candidate pairs of the scan, out[1] = largest region, out[2] = longest per-query list, out[3] = overflow flag
+extern "C" int vqa_dev_sketch_stats(vqa_index* ix, long long* out) {
+    VQA_REQUIRE(ix && out && ix->sketch, "vqa_dev_sketch_stats: no sketch");
+    DeviceGuard guard(ix->device);
+    VQA_HIP_CHECK(hipDeviceSynchronize());
+    std::vector<unsigned> rc(ix->max_grid), cc(VQA_QUERY_TILE);
+    int flag = 0;
+    VQA_HIP_CHECK(hipMemcpy(rc.data(), ix->region_cnt, rc.size() * 4, hipMemcpyDeviceToHost));
+    VQA_HIP_CHECK(hipMemcpy(cc.data(), ix->cand_cnt, cc.size() * 4, hipMemcpyDeviceToHost));
+    VQA_HIP_CHECK(hipMemcpy(&flag, ix->sketch_flag, 4, hipMemcpyDeviceToHost));
+    long long sum = 0, mx = 0, mq = 0;
+    for (unsigned v : rc) {
+        sum += v;
+        mx = std::max<long long>(mx, v);
+    }
+    for (unsigned v : cc) mq = std::max<long long>(mq, v);
+    out[0] = sum;
+    out[1] = mx;
+    out[2] = mq;
+    out[3] = flag;
+    return VQA_OK;
+}
+#endif

@@ -131,6 +131,117 @@ __global__ __launch_bounds__(256) void normalize_convert_kernel(const float* __r
     }
 }
 
+// ---- int8 sketch of fp16 rows (the pruning pre-pass of a large fp16 shard, score_topk.hip MODE 2).  One wave per row of a
+// TILED fp16 array (index rows or the staged query tile): the stored values x -> x_int = clamp(rint(x / s), -127, 127) in the
+// TILED int8 layout (K-blocks of 64 elements), with s the scale of the row's 256-row TILE (index rows: max|x| of the tile
+// / 127, tile_scale_kernel) or the row's own max|x| / 127 (queries), plus what the bound  |q . x - s_q s_x (q_int . x_int)| <= ||q_lo|| ||x_hi|| + ||q|| ||x_lo||  needs
+// (x_hi = s x_int, x_lo = x - x_hi): per row the scale, ||x_lo|| and ||x|| (queries), per 256-row tile the maxima of ||x_hi||
+// and ||x_lo|| (index rows; atomicMax on the bits of non-negative floats, interleaved [tile][2]).  Norms are rounded up (relative 2^-16) so that
+// fp32 rounding inside this kernel can never make the bound too tight.
+__global__ __launch_bounds__(256) void sketch_rows_kernel(const _Float16* __restrict__ tiled16, long long first, long long count,
+                                                          int KT16, int KT8, const float* tile_info, int8_t* __restrict__ out8,
+                                                          float* __restrict__ row_scale, float* __restrict__ row_lo,
+                                                          float* __restrict__ row_norm, unsigned* tile_max /* = tile_info */) {
+    typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+    const int lane = threadIdx.x & 63;
+    const long long ri = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ri >= count) return;
+    const long long row = first + ri;
+    const int units8 = KT8 * 4, units16 = KT16 * 4;
+    // this lane's int8 units u = lane, lane + 64, ...: 16 elements each = fp16 units 2 u and 2 u + 1 (zero past the fp16 padding)
+    constexpr int kMaxPer = 8;  // rows of up to 8 * 64 * 16 = 8192 elements
+    float x[kMaxPer][16];
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i) {
+        const int u = lane + 64 * i;
+#pragma unroll
+        for (int hlf = 0; hlf < 2; ++hlf) {
+            const int u16 = 2 * u + hlf;
+            half8v v = half8v{0, 0, 0, 0, 0, 0, 0, 0};
+            if (u < units8 && u16 < units16) v = *reinterpret_cast<const half8v*>(tiled16 + tiled_unit(row, u16 >> 2, u16 & 3, KT16) * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                x[i][8 * hlf + e] = (float)v[e];
+                amax = fmaxf(amax, fabsf((float)v[e]));
+            }
+        }
+    }
+    float s = tile_info ? tile_info[4 * (row >> 8) + 3] : 0.f;  // index rows: the scale of the row's tile
+    if (!(s > 0.f)) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+        s = amax > 0.f ? amax / 127.0f : 1.0f;
+    }
+    float hi2 = 0.f, lo2 = 0.f, n2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i) {
+        const int u = lane + 64 * i;
+        if (u >= units8) continue;
+        union {
+            int8_t b[16];
+            uint4 v;
+        } o;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float q = rintf(x[i][e] / s);
+            q = fminf(fmaxf(q, -127.f), 127.f);
+            o.b[e] = (int8_t)q;
+            const float hi = q * s, lo = x[i][e] - hi;
+            hi2 += hi * hi;
+            lo2 += lo * lo;
+            n2 += x[i][e] * x[i][e];
+        }
+        *reinterpret_cast<uint4*>(out8 + tiled_unit(row, u >> 2, u & 3, KT8) * 16) = o.v;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        hi2 += __shfl_xor(hi2, off, 64);
+        lo2 += __shfl_xor(lo2, off, 64);
+        n2 += __shfl_xor(n2, off, 64);
+    }
+    if (lane == 0) {
+        const float up = 1.0f + 1.0f / 65536.0f;
+        const float hi = sqrtf(hi2) * up, lo = sqrtf(lo2) * up + 1e-30f, nn = sqrtf(n2) * up;
+        if (row_scale) row_scale[ri] = s;
+        if (row_lo) row_lo[ri] = lo;
+        if (row_norm) row_norm[ri] = nn;
+        if (tile_max) {  // [tiles][4]: (max ||x_hi||, max ||x_lo||, 1 / scale, scale), read as float4 by the sketch scan
+            atomicMax(tile_max + 4 * (row >> 8), __builtin_bit_cast(unsigned, hi));
+            atomicMax(tile_max + 4 * (row >> 8) + 1, __builtin_bit_cast(unsigned, lo));
+        }
+    }
+}
+
+// one workgroup per tile of a TILED fp16 array: scale = max |x| over the tile's 256 rows / 127 (a tile of zeros: 1), written with
+// its reciprocal to tile_info[tile] = (0, 0, 1 / scale, scale) -- the two maxima are cleared for sketch_rows_kernel to fill
+__global__ __launch_bounds__(256) void tile_scale_kernel(const _Float16* __restrict__ tiled16, long long tile0, int KT16,
+                                                         float* __restrict__ tile_info) {
+    typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+    __shared__ float red[4];
+    const long long tile = tile0 + blockIdx.x;
+    const _Float16* base = tiled16 + (size_t)tile * KT16 * 1024 * 8;  // the tile's KT16 blocks of 16 KiB are contiguous
+    float m = 0.f;
+    for (int u = threadIdx.x; u < KT16 * 1024; u += 256) {
+        const half8v v = *reinterpret_cast<const half8v*>(base + (size_t)u * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf((float)v[e]));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const float s = (m > 0.f && m < INFINITY) ? m / 127.0f : 1.0f;
+        float* o = tile_info + 4 * tile;
+        o[0] = 0.f;
+        o[1] = 0.f;
+        o[2] = 1.0f / s;
+        o[3] = s;
+    }
+}
+
 }  // namespace
 
 template <typename SRC>
@@ -199,6 +310,26 @@ extern "C" int vqa_normalize_convert(const float* rows, int64_t n, int32_t d, in
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(normalize_convert_kernel, dim3((int)blocks), dim3(threads), 0, (hipStream_t)hip_stream, rows,
                        (long long)n, d, normalize, dtype, out);
+    VQA_HIP_CHECK(hipGetLastError());
+    return VQA_OK;
+}
+
+int vqa_launch_sketch_rows(const void* tiled16, int64_t first, int64_t count, int32_t d_pad16, int32_t d_pad8, const float* tile_info,
+                           void* out8, float* row_scale, float* row_lo, float* row_norm, hipStream_t stream) {
+    if (count == 0) return VQA_OK;
+    VQA_REQUIRE(d_pad8 / 16 <= 8 * 64, "sketch_rows: rows of %d elements are too long for the int8 sketch", d_pad8);
+    hipLaunchKernelGGL(sketch_rows_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, stream,
+                       reinterpret_cast<const _Float16*>(tiled16), (long long)first, (long long)count, d_pad16 / 32, d_pad8 / 64,
+                       tile_info, reinterpret_cast<int8_t*>(out8), row_scale, row_lo, row_norm,
+                       reinterpret_cast<unsigned*>(const_cast<float*>(tile_info)));
+    VQA_HIP_CHECK(hipGetLastError());
+    return VQA_OK;
+}
+
+int vqa_launch_tile_scales(const void* tiled16, int64_t tile0, int64_t ntiles, int32_t d_pad16, float* tile_info, hipStream_t stream) {
+    if (ntiles == 0) return VQA_OK;
+    hipLaunchKernelGGL(tile_scale_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, reinterpret_cast<const _Float16*>(tiled16),
+                       (long long)tile0, d_pad16 / 32, tile_info);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

@@ -45,14 +45,16 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
                                                                        float* __restrict__ out_thr, float score_scale,
                                                                        int out_stride, int out_offset,
                                                                        vqa_key* __restrict__ out_last_key, int query_major,
-                                                                       const int* __restrict__ gate, int row_lists) {
+                                                                       const int* __restrict__ gate, int row_lists,
+                                                                       const unsigned* __restrict__ counts) {
     if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     vqa_key* keys = reinterpret_cast<vqa_key*>(smem);    // [parts * list_len]
     vqa_key* red = keys + (size_t)parts * list_len;      // [4]
     int* fill = reinterpret_cast<int*>(red + 4);         // keys kept
     const int q = blockIdx.x;
-    const int m_all = parts * list_len;
+    int m_all = parts * list_len;
+    if (counts) m_all = (int)counts[q] < m_all ? (int)counts[q] : m_all;  // a sketch search's candidate list: the first counts[q] slots
     // Only the non-empty slots are kept: a workgroup's list of a query holds ~1-3 keys after a scan seeded with good
     // thresholds, so the 512 x k slots of a two-stage search shrink to a few hundred keys and the k selection rounds below
     // touch 2 instead of 20 keys per thread (final merge 31 -> 17 us).  The order in which the keys land is arbitrary; the
@@ -221,7 +223,8 @@ int vqa_launch_verify_wide(const vqa_key* partial, int32_t parts, int32_t list_l
 int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t list_len, int32_t nq, int32_t k,
                               const int64_t* ids, int64_t id_base, float* out_scores, int64_t* out_ids, int64_t* out_pos,
                               float* out_thr, float score_scale, int32_t out_stride, int32_t out_offset,
-                              vqa_key* out_last_key, bool query_major, const int* gate, hipStream_t stream, int32_t row_lists) {
+                              vqa_key* out_last_key, bool query_major, const int* gate, hipStream_t stream, int32_t row_lists,
+                              const unsigned* counts) {
     if (row_lists <= 0) row_lists = parts;
     VQA_REQUIRE(row_lists >= parts, "merge_partials: %d lists per row but %d to merge", row_lists, parts);
     VQA_REQUIRE(parts >= 1 && list_len >= 1 && nq >= 1 && nq <= VQA_QUERY_TILE && k >= 1,
@@ -237,7 +240,7 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
         });
         if (rc != VQA_OK) return rc;
     }
-    if (k > 32) {  // sort instead of k selection rounds
+    if (k > 32 && !counts) {  // sort instead of k selection rounds
         int m_pow2 = 1;
         while (m_pow2 < parts * list_len) m_pow2 <<= 1;
         const size_t lds_sort = (size_t)m_pow2 * sizeof(vqa_key);
@@ -253,7 +256,7 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
     hipLaunchKernelGGL(merge_partials_kernel, dim3(nq), dim3(kMergeThreads), lds, stream, partial, parts, list_len, k,
                        reinterpret_cast<const long long*>(ids), (long long)id_base, out_scores,
                        reinterpret_cast<long long*>(out_ids), reinterpret_cast<long long*>(out_pos), out_thr, score_scale,
-                       out_stride, out_offset, out_last_key, query_major ? 1 : 0, gate, row_lists);
+                       out_stride, out_offset, out_last_key, query_major ? 1 : 0, gate, row_lists, counts);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

@@ -71,6 +71,19 @@ struct MfmaTraits<VQA_F32> {
     }
 };
 
+// int8 sketch (MODE 2): v_mfma_i32_16x16x64_i8, 64 one-byte elements per 64-byte K-step at the cycles of the fp16 form, i.e.
+// twice its rate per row; the int32 accumulators live in the same registers (bit casts only)
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+template <>
+struct MfmaTraits<VQA_I8_SKETCH> {
+    static constexpr int kSub = 1;
+    template <int T>
+    static __device__ __forceinline__ f32x4 mma(frag_t a, frag_t b, f32x4 c) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(i32x4, a), __builtin_bit_cast(i32x4, b),
+                                                                               __builtin_bit_cast(i32x4, c), 0, 0, 0));
+    }
+};
+
 // fp8 at twice the fp16 MFMA rate: v_mfma_scale_f32_16x16x128_f8f6f4 with unit block scales (E8M0 127 = 2^0, byte 0 of
 // the scale register, op_sel 0).  One instruction consumes 32 bytes per lane and operand = the lane's fragments of TWO
 // consecutive K-steps; rows and queries are paired byte for byte (scripts/probes/mx_fp8_probe.hip: exact on integer
@@ -162,6 +175,7 @@ constexpr int kMaxK = kCap - 3;                                         // 12
 constexpr int kSeedsPerTile = 2;  // seed pass: sub-maxima kept per query and tile (one per row half; 8, one per 32 rows, for tiny shards)
 static_assert(kPipeBytes <= 144 * 1024, "ring sizes");
 
+constexpr int kSketchMaxTiles = (kLdsTotal - kPipeBytes - 4 * kQ * 4 - 16) / 16;  // tiles per workgroup of a sketch scan (LDS: 16 B each)
 constexpr int kOverBit = 1 << 30;  // "an append was refused" flag, kept in bit 30 of cnt[0] (LDS is fully used)
 constexpr int kCntMask = 0xFFFFFF;
 
@@ -350,7 +364,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
                                                               const vqa_key* __restrict__ upper,
                                                               vqa_key* __restrict__ out, long long N, int KT, int nq, int k,
                                                               int tile_begin, int tile_end, const int* __restrict__ gate,
-                                                              int row_lists, int list_offset, int seeds) {
+                                                              int row_lists, int list_offset, int seeds, SketchScanArgs sk) {
     // gated launch (fallback passes of a large-k search, capi.hip): nothing to do when the one-pass result was verified
     if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -377,10 +391,26 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         L.thr[tid] = tid < nq ? (thr_init ? thr_init[tid] : -INFINITY) : INFINITY;
         L.cnt[tid] = 0;
     }
+    // MODE 2 (sketch scan): per query theta, ||q_lo||, ||q||, 1 / (s_q s_x) in the list area (4 KiB) + one append counter
+    float* const sk_q = reinterpret_cast<float*>(smem + kPipeBytes);          // [4][256]
+    int* const sk_cnt = reinterpret_cast<int*>(smem + kPipeBytes + 4 * kQ * 4);
+    if (MODE == 2) {
+        if (tid < kQ) {
+            sk_q[tid] = tid < nq ? sk.qconst[tid] : INFINITY;
+            sk_q[kQ + tid] = sk.qconst[kQ + tid];
+            sk_q[2 * kQ + tid] = sk.qconst[2 * kQ + tid];
+            sk_q[3 * kQ + tid] = sk.qconst[3 * kQ + tid];
+        }
+        if (tid == 0) *sk_cnt = 0;
+    }
 
     const int first_tile = tile_begin + blockIdx.x;
     const int ntile = first_tile < tile_end ? (tile_end - first_tile + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     const int total = ntile * KT;  // K-steps of this workgroup, numbered kappa = ti * KT + kt
+    // MODE 2: (max ||x_hi||, max ||x_lo||, 1 / scale) of every tile this workgroup scans, in LDS (the launcher bounds ntile by kSketchMaxTiles)
+    float4* const sk_tm = reinterpret_cast<float4*>(smem + kPipeBytes + 4 * kQ * 4 + 16);
+    if (MODE == 2)
+        for (int t = tid; t < ntile; t += kThreads) sk_tm[t] = sk.tile_info[first_tile + t * (int)gridDim.x];
 
     // ---- LDS-DMA.  X and Q are stored in the TILED layout (convert.hip): the slice of one tile and K-step is a
     // contiguous 16 KiB block that already is the swizzled LDS image.  vmcnt retires in issue order per wave, so the
@@ -646,10 +676,68 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         return refused;
     };
 
+    // MODE 2: the accumulators are the int32 dot products D of the int8 sketches.  The exact score of (query q, row) obeys
+    //     s <= s_q s_t D + ||q_lo|| max_tile ||x_hi|| + ||q|| max_tile ||x_lo||                (Cauchy-Schwarz on the two residues)
+    // (s_t: the tile's scale) so a row can only belong to the top-k if D >= T_q = (theta_q - slack_q(tile)) / (s_q s_t): the test is the MODE 1 test on
+    // integer maxima, with a per-tile, per-query threshold; survivors go to this workgroup's region of candidate pairs as
+    // (query << 32 | row position) and are scored exactly afterwards (rescore_kernel, merge_topk.hip).  No list, no
+    // compaction, no workgroup barrier.
+    auto sketch_epilogue = [&](const f32x4 (&acc)[8][4], uint32_t row0, int ti) __attribute__((always_inline)) {
+        const float4 tmax = sk_tm[ti];
+        const float a_hi = tmax.x, b_lo = tmax.y, inv_sx = tmax.z;
+        float T[4];
+        int mi32[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            const int q = wn * 64 + ni * 16 + c;
+            // 2e-6: the exact scores (fp32 sums of exact products) against the real-number dot product the bound speaks of
+            const float num = sk_q[q] - sk_q[kQ + q] * a_hi - sk_q[2 * kQ + q] * b_lo - 2e-6f;
+            const float t = num * sk_q[3 * kQ + q] * inv_sx;
+            T[ni] = t - fabsf(t) * 4e-6f - 0.5f;  // every rounding of this line errs towards MORE candidates; D is an integer
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            int r[8];
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const i32x4 v = __builtin_bit_cast(i32x4, acc[mi][ni]);
+                r[mi] = max(max(max(v[0], v[1]), v[2]), v[3]);
+            }
+            mi32[ni] = max(max(max(max(r[0], r[1]), r[2]), max(max(r[3], r[4]), r[5])), max(r[6], r[7]));
+        }
+        if (((float)mi32[0] >= T[0]) | ((float)mi32[1] >= T[1]) | ((float)mi32[2] >= T[2]) | ((float)mi32[3] >= T[3])) {
+            unsigned long long* region = sk.regions + (size_t)blockIdx.x * sk.cap;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                if ((float)mi32[ni] >= T[ni]) {
+                    const unsigned long long qhi = (unsigned long long)(wn * 64 + ni * 16 + c) << 32;
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi) {
+                        const i32x4 v = __builtin_bit_cast(i32x4, acc[mi][ni]);
+                        if ((float)max(max(v[0], v[1]), max(v[2], v[3])) >= T[ni]) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const uint32_t pos = row0 + (uint32_t)(wm * 128 + mi * 16 + g * 4 + j);
+                                if ((float)v[j] >= T[ni] && (long long)pos < N) {
+                                    const int slot = atomicAdd(sk_cnt, 1);
+                                    if (slot < sk.cap) region[slot] = qhi | pos;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    };
+
     // ---- tile epilogue shared by the fp16 / fp32 loop forms: threshold test + appends (MODE 1) or sub-maxima (MODE 0).
     // `ext_stage`: an X ring stage that stays idle until every wave has passed the next workgroup barrier
     auto finish_tile = [&](f32x4 (&acc)[8][4], int ti, int ext_stage) __attribute__((always_inline)) {
         const uint32_t row0 = ((uint32_t)first_tile + (uint32_t)ti * gridDim.x) * kTileRows;  // n < 2^32 rows
+        if (MODE == 2) {
+            sketch_epilogue(acc, row0, ti);
+            return;
+        }
         mask_ragged(acc, row0);
         if (MODE == 0) {
             seed_epilogue(acc, row0, ti);
@@ -1070,7 +1158,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     if constexpr (kStagger) {
         if (grp) stagger_loop(std::false_type{});
         else stagger_loop(std::true_type{});
-    } else if constexpr (VQA_SLOT != 0 && DT == VQA_F16) {
+    } else if constexpr (VQA_SLOT != 0 && (DT == VQA_F16 || DT == VQA_I8_SKETCH)) {
         if (grp) slot_loop(std::false_type{});
         else slot_loop(std::true_type{});
     } else {
@@ -1082,6 +1170,15 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");
 #endif
     if (MODE == 0) return;
+    if (MODE == 2) {  // pairs written to this workgroup's region; a region that filled up sends the search to its exact fallback
+        __syncthreads();
+        if (tid == 0) {
+            const int cnt = *sk_cnt;
+            sk.counts[blockIdx.x] = (unsigned)(cnt < sk.cap ? cnt : sk.cap);
+            if (cnt > sk.cap) atomicExch(sk.overflow, 1);
+        }
+        return;
+    }
     // ---- flush: every list sorted best first, k keys per query (0 = empty) ------------------------------------
     __syncthreads();
     compact_pass(L, wave, lane, k, 1, kCap);
@@ -1125,12 +1222,39 @@ static int launch_dt(const ScoreTopkArgs& a, int KT, int lds, hipStream_t stream
                             : a.first_stage ? score_topk_kernel<1, DT, 1, LOOP> : score_topk_kernel<1, DT, 0, LOOP>;
     hipLaunchKernelGGL(kern, dim3(a.grid), dim3(kThreads), lds, stream, a.x, a.q, a.thr_init, a.upper, a.partial, (long long)a.n,
                        KT, a.nq, a.k, a.tile_begin, a.tile_end, a.gate, a.row_lists > 0 ? a.row_lists : a.grid, a.list_offset,
-                       a.seeds_per_tile);
+                       a.seeds_per_tile, SketchScanArgs{});
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }
 
+// MODE 2: the int8 sketch scan of a large fp16 shard
+static int launch_sketch(const ScoreTopkArgs& a, int KT, int lds, hipStream_t stream) {
+    static VqaPerDeviceOnce once;
+    int rc = once.run([&](int) -> int {
+        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<2, VQA_I8_SKETCH, 0, 0>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        return VQA_OK;
+    });
+    if (rc != VQA_OK) return rc;
+    hipLaunchKernelGGL((score_topk_kernel<2, VQA_I8_SKETCH, 0, 0>), dim3(a.grid), dim3(kThreads), lds, stream, a.x, a.q, nullptr, nullptr,
+                       nullptr, (long long)a.n, KT, a.nq, a.k, a.tile_begin, a.tile_end, a.gate, a.grid, 0, 2, *a.sketch);
+    VQA_HIP_CHECK(hipGetLastError());
+    return VQA_OK;
+}
+
+int vqa_score_topk_sketch_max_tiles() { return kSketchMaxTiles; }
+
 int vqa_launch_score_topk(int dtype, const ScoreTopkArgs& a, hipStream_t stream) {
+    if (a.sketch) {
+        VQA_REQUIRE(dtype == VQA_I8_SKETCH && a.d_pad % (2 * kRowBytes) == 0, "score_topk: sketch scan over %d-element rows", a.d_pad);
+        VQA_REQUIRE(a.nq >= 1 && a.nq <= kQ && a.grid >= 1 && a.tile_end > a.tile_begin && a.grid <= a.tile_end - a.tile_begin,
+                    "score_topk: bad sketch launch");
+        VQA_REQUIRE((a.tile_end - a.tile_begin + a.grid - 1) / a.grid <= kSketchMaxTiles, "score_topk: %d tiles per workgroup exceed the sketch scan's %d",
+                    (a.tile_end - a.tile_begin + a.grid - 1) / a.grid, kSketchMaxTiles);
+        VQA_REQUIRE(a.sketch->tile_info && a.sketch->qconst && a.sketch->regions && a.sketch->counts && a.sketch->overflow && a.sketch->cap > 0,
+                    "score_topk: incomplete sketch arguments");
+        return launch_sketch(a, a.d_pad / kRowBytes, vqa_score_topk_lds_bytes(dtype, a.k), stream);
+    }
     VQA_REQUIRE(dtype == VQA_F16 || dtype == VQA_FP8_E4M3 || dtype == VQA_F32, "score_topk: storage type %d", dtype);
     const int esize = dtype == VQA_F32 ? 4 : dtype == VQA_F16 ? 2 : 1;
     VQA_REQUIRE(a.d_pad > 0 && (a.d_pad * esize) % (2 * kRowBytes) == 0,

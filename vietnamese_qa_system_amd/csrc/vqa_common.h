@@ -65,6 +65,19 @@ __host__ __device__ __forceinline__ vqa_key vqa_make_key(float score, uint32_t p
 __host__ __device__ __forceinline__ float vqa_key_score(vqa_key k) { return vqa_ordered_f32((uint32_t)(k >> 32)); }
 __host__ __device__ __forceinline__ uint32_t vqa_key_pos(vqa_key k) { return 0xFFFFFFFFu - (uint32_t)k; }
 
+// internal storage code of the int8 sketch of a large fp16 shard (never a public index type: include/vqa_retrieval.h)
+#define VQA_I8_SKETCH 3
+
+// MODE 2 of the scoring kernel: the sketch scan's extra arguments
+struct SketchScanArgs {
+    const float4* tile_info = nullptr;  // [tiles] (max ||x_hi||, max ||x_lo||, 1 / scale, scale) of every 256-row tile of the sketch
+    const float* qconst = nullptr;      // [4][256]: theta (exact lower bound of the k-th best score), ||q_lo||, ||q||, 1 / s_q
+    unsigned long long* regions = nullptr;  // [grid][cap] candidate (query << 32 | row position) pairs, one region per workgroup
+    unsigned* counts = nullptr;         // [grid] pairs written per region
+    int* overflow = nullptr;            // set when a region filled up: the caller's exact fallback scan runs
+    int cap = 0;
+};
+
 // ---- kernel launchers implemented in the .hip files ---------------------------------------------------------
 struct ScoreTopkArgs {
     const void* x;        // index rows in TILED layout (convert.hip): ceil(n/256) tiles x (d_pad/32) blocks of 16 KiB
@@ -85,6 +98,7 @@ struct ScoreTopkArgs {
                                 // stage fills slots [0, grid), the main launch [grid, 2 grid) of rows of 2 grid lists)
     bool first_stage = false;   // the first-stage launch of a two-stage search: same code, its own kernel symbol
     int32_t loop = 0;           // fp16 only: 0 = anti-phase slot loop, 1 = K-step-pair stagger loop (the fp8 structure)
+    const SketchScanArgs* sketch = nullptr;  // not null: MODE 2 over the int8 sketch (x = sketch rows, q = sketch of the query tile)
     bool seed_only = false;  // MODE 0: writes seeds_per_tile sub-maxima per query and tile to `partial` as [query][tile - tile_begin][.]
     int32_t seeds_per_tile = 2;  // 2 (one per 128-row half) or 8 (one per 32-row group: shards of a few tiles, where 2 per tile
                                  // are fewer than k values and leave the thresholds at -inf)
@@ -93,6 +107,7 @@ int vqa_launch_score_topk(int dtype, const ScoreTopkArgs& a, hipStream_t stream)
 int vqa_score_topk_lds_bytes(int dtype, int k);
 int vqa_score_topk_max_k(int dtype);
 int vqa_score_topk_seeds_per_tile();
+int vqa_score_topk_sketch_max_tiles();  // tiles one workgroup of the sketch scan can take (its tile maxima sit in LDS)
 
 // `parts` key lists of `list_len` keys per query ([parts][256][list_len], or query-major) -> the k best per query:
 // final [nq, k] (scores, external ids, positions) and/or the k-th best score per query (-inf when fewer exist)
@@ -104,7 +119,9 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
                               bool query_major /* lists are [query][parts][list_len] instead of [parts][256][list_len] */,
                               const int* gate /* device flag or nullptr: no-op when *gate == 0 */, hipStream_t stream,
                               int32_t row_lists = 0 /* query-major only: lists per query row in memory (>= parts; 0 = parts):
-                                                       the first `parts` lists of every row are merged */);
+                                                       the first `parts` lists of every row are merged */,
+                              const unsigned* counts = nullptr /* [nq] or nullptr: only the first counts[q] slots of a query's row
+                                                                  hold keys (the candidate lists of a sketch search) */);
 // one-pass large-k check: sets *flag = 1 when some workgroup's list (list_len keys, full) ends ABOVE the query's k-th merged
 // key `kth` -- that list may have dropped a row of the true top-k (capi.hip, vqa_index_search)
 int vqa_launch_verify_wide(const vqa_key* partial, int32_t parts, int32_t list_len, int32_t nq, const vqa_key* kth, int* flag,
@@ -118,3 +135,18 @@ int vqa_launch_tile_rows(const void* rows, int32_t src_dtype, int64_t first, int
 // TILED rows [first, first + count) -> row-major [count, d] in the storage type (device)
 int vqa_launch_untile_rows(const void* tiled, int64_t first, int64_t count, int32_t d, int32_t d_pad, int32_t dtype, void* out,
                            hipStream_t stream);
+
+// ---- int8 sketch (large fp16 shards: the rigorous pruning pre-pass, score_topk.hip MODE 2) -------------------------------------
+// TILED fp16 rows [first, first + count) -> TILED int8 (K-blocks of 64 elements).  tile_info [tiles][4] floats = (max ||x_hi||,
+// max ||x_lo||, 1 / scale, scale) per 256-row tile: not null (index rows) -> the rows take their tile's scale and raise its two
+// maxima; null (the query tile) -> every row its own max|x| / 127, with per-row scale / ||x_lo|| / ||x|| outputs
+int vqa_launch_sketch_rows(const void* tiled16, int64_t first, int64_t count, int32_t d_pad16, int32_t d_pad8, const float* tile_info,
+                           void* out8, float* row_scale, float* row_lo, float* row_norm, hipStream_t stream);
+// scale (= max |x| / 127) of tiles [tile0, tile0 + ntiles) of a TILED fp16 array into tile_info; clears their two maxima
+int vqa_launch_tile_scales(const void* tiled16, int64_t tile0, int64_t ntiles, int32_t d_pad16, float* tile_info, hipStream_t stream);
+// sketch search: per-query constants of the scan + reset of the candidate counters; exact scores of the candidate pairs
+int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float* qlo, const float* qnorm, float* qconst,
+                             unsigned* cand_cnt, int* overflow, hipStream_t stream);
+int vqa_launch_rescore(const unsigned long long* regions, const unsigned* counts, int cap, int nregions, const long long* stage_pos,
+                       int nq, int k, const void* x16, const void* q16, int32_t d_pad16, vqa_key* cand_keys, unsigned* cand_cnt,
+                       int capq, int* overflow, hipStream_t stream);

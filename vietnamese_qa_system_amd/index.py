@@ -7,6 +7,7 @@ runs in ``libvqa_retrieval.so`` (hand-written HIP, gfx950); torch only owns devi
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import numpy as np
@@ -57,7 +58,7 @@ class DeviceIndex:
     """
 
     def __init__(self, vectors=None, ids=None, *, id_base: int = 0, dtype="fp16", device: int = 0, normalize: bool = False,
-                 n: Optional[int] = None, d: Optional[int] = None, with_ids: Optional[bool] = None):
+                 n: Optional[int] = None, d: Optional[int] = None, with_ids: Optional[bool] = None, sketch: Optional[bool] = None):
         self._handle = ctypes.c_void_p()
         self.device = int(device)
         _require_gpu(self.device)
@@ -71,18 +72,24 @@ class DeviceIndex:
         elif n is None or d is None:
             raise ValueError("either vectors or (n, d) must be given")
         has_ids = bool(with_ids) if with_ids is not None else ids is not None
+        # int8 sketch beside the fp16 rows of a large shard (include/vqa_retrieval.h VQA_INDEX_SKETCH): on by default, the
+        # library keeps one only where its two-stage search applies; VQA_SKETCH=0 or sketch=False: exact fp16 scan everywhere
+        if sketch is None:
+            sketch = os.environ.get("VQA_SKETCH", "1") != "0"
+        flags = (N.VQA_INDEX_HAS_IDS if has_ids else 0) | (N.VQA_INDEX_SKETCH if sketch and self.dtype == N.VQA_F16 else 0)
         with torch.cuda.device(self.device):
             N.check(self._lib.vqa_index_create(ctypes.byref(self._handle), self.device, int(n), int(d), self.dtype, None,
-                                               N.VQA_F16, None, int(id_base), N.VQA_INDEX_HAS_IDS if has_ids else 0),
+                                               N.VQA_F16, None, int(id_base), flags),
                     "vqa_index_create")
         self.n, self.d, self.id_base, self.has_ids = int(n), int(d), int(id_base), has_ids
         if vectors is not None and n:
             self.set_rows(0, v, ids, normalize=normalize)
 
     @classmethod
-    def empty(cls, n: int, d: int, *, id_base: int = 0, dtype="fp16", device: int = 0, with_ids: bool = False) -> "DeviceIndex":
+    def empty(cls, n: int, d: int, *, id_base: int = 0, dtype="fp16", device: int = 0, with_ids: bool = False,
+              sketch: Optional[bool] = None) -> "DeviceIndex":
         """A shard of ``n`` zero rows to be filled with :meth:`set_rows`."""
-        return cls(None, None, id_base=id_base, dtype=dtype, device=device, n=n, d=d, with_ids=with_ids)
+        return cls(None, None, id_base=id_base, dtype=dtype, device=device, n=n, d=d, with_ids=with_ids, sketch=sketch)
 
     # -- filling -------------------------------------------------------------------------------------------------
     def set_rows(self, first: int, vectors, ids=None, *, normalize: bool = False, chunk_rows: int = 1 << 20) -> None:
