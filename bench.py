@@ -304,6 +304,14 @@ def main():
             with open(tpath) as f:
                 traffic = json.load(f).get(f"{n}x{d}_{dt}_b{b}_k{k}")
         mode = {"fp16": 1, "fp8": 2, "fp32": 0}[args.dtype]
+        sketch = bool(info.sketch_scan)
+        esize = {"fp16": 2, "fp8": 1, "fp32": 4}[args.dtype]
+        kname = "score_topk_kernel<2, 3, 0, 0>" if sketch else f"score_topk_kernel<1, {mode}, 0, 0>"
+        if sketch:  # the PMC bytes of THAT launch (profiles/traffic.json keeps the exact main launch's under the plain key)
+            traffic = None
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get(f"{n}x{d}_{dt}_b{b}_k{k}_sketch")
         result = {
             "metric": "queries_per_sec", "value": round(qps, 1), "unit": "queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -314,7 +322,7 @@ def main():
                        "parallelism": f"row-shard x{world}"},
             # per-step event times on rank 0's stream (the bracketed wall clock above is what value / ms_per_step report)
             "step_ms": percentiles(np, step_ms),
-            "roofline": {"bound": "hbm", "kernel": f"score_topk_kernel<1, {mode}, 0, 0>", "achieved": round(achieved, 1) if achieved else None,
+            "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
                          "traffic": traffic, "kernel_ms": round(kern_ms, 4), "launches": launches,
                          "bytes_per_launch": info.bytes_per_launch, "flops_per_launch": info.flops_per_launch,
@@ -328,8 +336,15 @@ def main():
                          # flops, achieved and kernel_ms above are the dominant launch's alone.  whole_step_frac prices the
                          # WHOLE step (every launch, merges, gaps) as one read of the shard: shard bytes / median step / peak
                          "rows_per_launch": int(info.rows_per_launch), "first_stage_rows": int(info.first_stage_rows),
-                         "whole_step_frac": round(n * info.bytes_per_launch / max(int(info.rows_per_launch), 1)
-                                                  / (float(np.median(step_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         # sketch_scan: large fp16 shards run the dominant launch over an int8 sketch of the rows (one byte per
+                         # element: bytes_per_launch / achieved / frac price THAT launch on the bytes it has to read; the
+                         # multiply-adds are int8 x int8 -> int32, mfma_tflops counts them) and score exactly only the pairs
+                         # its rigorous bound cannot exclude.  whole_step_frac prices the WHOLE step as one read of the
+                         # shard AS STORED (index_bytes = rows x d x element size of the index type): queries/s over the
+                         # HBM-roofline queries/s of BASELINE.md -- a step that reads fewer bytes than the shard holds can
+                         # pass the rate of a plain scan
+                         "sketch_scan": sketch, "index_bytes": n * d * esize,
+                         "whole_step_frac": round(n * d * esize / (float(np.median(step_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          # the ceiling this box's HBM really gives a plain stream: a 1 GiB device-to-device copy (torch's copy
                          # kernel), bytes read + written over its event time, in this process
                          "hbm_copy_measured_gbs": copy_gbs},
@@ -378,6 +393,22 @@ def main():
         e2e = end_to_end(torch, np, searcher, device, dev_index, b, k, args.e2e_steps, sync)
         if rank == 0:
             result["end_to_end"] = e2e
+    if rank == 0 and world == 1 and not args.no_other and bool(info.sketch_scan):
+        # the same shard through the EXACT fp16 scan (no int8 sketch: what small shards, k > 12 and the overflow fallback run),
+        # beside the headline: step and main-launch time of the fused MFMA scoring + top-k kernel reading every fp16 byte
+        exact = DeviceIndex(shard, id_base=1 + rank * n, dtype=args.dtype, device=dev_index, sketch=False)
+        st_ms, kn_ms = timed_search(torch, exact, q, k, 30)
+        ei = exact.launch_info(b, k)
+        s_ex, _, p_ex = exact.search(q, k, return_positions=True)
+        s_sk, _, p_sk = index.search(q, k, return_positions=True)
+        torch.cuda.synchronize(device)
+        result["exact_scan"] = {"ms_per_step": round(st_ms, 4), "queries_per_s": round(b / (st_ms * 1e-3), 1), "kernel": f"score_topk_kernel<1, {mode}, 0, 0>",
+                                "kernel_ms": round(kn_ms, 4), "bytes_per_launch": int(ei.bytes_per_launch),
+                                "frac": round(ei.bytes_per_launch / (kn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "whole_step_frac": round(n * d * esize / (st_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "same_rows_as_sketch_search": bool(torch.equal(p_ex, p_sk)),
+                                "max_abs_score_diff": float((s_ex - s_sk).abs().max())}
+        exact.close()
     if rank == 0 and world == 1 and not args.no_other and not args.no_cpu:
         index.close()
         del shard

@@ -8,6 +8,9 @@ R=${1:-r03}
 cd $GRAFT_REPO_ROOT
 bash scripts/profile_round.sh ${R}_fp16 > gpurun_out/${R}_fp16.log 2>&1
 tail -4 gpurun_out/${R}_fp16.log
+# the same shard through the exact fp16 scan (no int8 sketch)
+VQA_SKETCH=0 bash scripts/profile_round.sh ${R}_fp16_exact --no-cpu --no-other > gpurun_out/${R}_fp16_exact.log 2>&1
+tail -4 gpurun_out/${R}_fp16_exact.log
 bash scripts/profile_round.sh ${R}_fp8 --dtype fp8 --no-cpu --no-other > gpurun_out/${R}_fp8.log 2>&1
 tail -2 gpurun_out/${R}_fp8.log
 O=$GRAFT_REPO_ROOT/gpurun_out/${R}_enc; rm -rf $O; mkdir -p $O

@@ -16,11 +16,16 @@ st = glob.glob(os.path.join(root, "stats", "*", "*kernel_stats.csv"))
 if st:
     shutil.copy(st[0], os.path.join(root, "kernel_stats.csv"))
 main_name = None
+# the dominant launch: the int8 sketch scan score_topk_kernel<2, 3, 0, 0> where a search has one, else the exact main launch
+# score_topk_kernel<1, DT, 0, L> (<1, DT, 1, L> is the first stage of a two-stage search, <0, ..> the seed pass)
+MAIN = r"score_topk_kernel<1, \d, 0(, \d)?>|score_topk_kernelILi1ELi\dELi0E"
+if any(re.search(r"score_topk_kernel<2, 3", r["Kernel_Name"]) for r in rows("pmc_fetch", "counter_collection.csv")):
+    MAIN = r"score_topk_kernel<2, 3, 0, 0>"
+    out["sketch_scan"] = True
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
     agg = collections.defaultdict(list)
     for r in rows(sub, "counter_collection.csv"):
-        # the main launch: score_topk_kernel<1, DT, 0> (<1, DT, 1> is the first stage of a two-stage search, <0, ..> the seed pass)
-        if re.search(r"score_topk_kernel<1, \d, 0(, \d)?>|score_topk_kernelILi1ELi\dELi0E", r["Kernel_Name"]):
+        if re.search(MAIN, r["Kernel_Name"]):
             main_name = re.search(r"score_topk_kernel(<[^>]*>|IL\w*E)", r["Kernel_Name"]).group(0)
             agg[r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     for name, v in agg.items():
