@@ -204,6 +204,33 @@ def main():
     assert all(g == gathered[0] for g in gathered), "hybrid results differ between ranks"
     checks.append("hybrid-limit-103")
 
+    # 10. shards large enough for the int8 sketch pre-pass (VQA_STAGE_MIN=2 brings the two-stage / sketch switch-over down to
+    #     131 072 rows per shard): every rank's main launch scans its sketch and re-scores the survivors; the merged result
+    #     equals the single-shard sketch search of the concatenated corpus bit for bit -- a row's exact score does not depend on
+    #     the shard it sits in, and ties astride shard AND stage boundaries resolve by global row position
+    os.environ["VQA_STAGE_MIN"] = "2"
+    n3 = 140_000 * world + 3
+    x3 = unit(rng, n3, 64)
+    b3 = [shard_bounds(n3, world, r) for r in range(world)]
+    for lo, _ in b3[1:]:
+        x3[lo - 1] = x3[lo] = x3[lo + 65_536] = x3[123]  # astride each shard boundary + astride the next shard's first stage
+    q3 = unit(rng, 24, 64)
+    q3[0] = x3[123]
+    q3t = torch.from_numpy(q3).to(device)
+    e10 = Embeddings(dtype="fp16", device=dev_index, min_score=None)
+    e10.index_vectors(None, x3)
+    assert e10._index.launch_info(24, k).sketch_scan == 1
+    one = DeviceIndex(x3, dtype="fp16", device=dev_index)
+    assert one.launch_info(24, k).sketch_scan == 1
+    s1, i1, _ = one.search(q3t, k)
+    torch.cuda.synchronize()
+    compare("sketch-shards", e10, q3t, k, (s1.clone(), i1.clone()))
+    tie = sorted({123} | {p for lo, _ in b3[1:] for p in (lo - 1, lo, lo + 65_536)})
+    assert i1[0, :min(k, len(tie))].cpu().numpy().tolist() == tie[:k], (i1[0].tolist(), tie)
+    one.close()
+    e10._index.close()
+    del os.environ["VQA_STAGE_MIN"]
+
     dist.barrier()
     with open(os.path.join(args.out, f"rank{rank}.json"), "w") as f:
         json.dump({"rank": rank, "world": world, "backend": args.backend, "device": dev_index, "checks": checks,

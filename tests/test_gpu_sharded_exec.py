@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXPECTED = {"id-vector", "pipelined", "k=300", "save-load", "local-slice", "producer", "short-shard", "short-shard-k12", "string-ids",
             "reindex", "fp8-shards", "fp8-k=40", "fp8-save-load", "fp32-shards", "fp32-k=40", "k=1024", "k=1024-short-shards",
-            "hybrid-limit-103"}
+            "hybrid-limit-103", "sketch-shards"}
 
 
 def _free_port() -> int:
