@@ -494,7 +494,8 @@ def other_configs(torch, np, device, dev_index, n, d, b, k):
                        "recall_check": f"{nv} queries x the first {pre_rows} rows (a prefix-only index), oracle on the same e4m3 codes / on the fp32 rows",
                        "seconds": round(time.perf_counter() - t0, 1)}
     del prefix
-    # ---- configs[1]: fp32 index (exact f32 MFMA) of 1M rows + the encoder over all B x L positions (padded form)
+    # ---- configs[1]: fp32 index of 1M rows + the encoder over all B x L positions (padded form).  Default path: the int8 sketch
+    # scan + exact fp32 re-scoring (shards of >= 524k rows); beside it the exact scan on the f32 MFMA (VQA_SKETCH=0)
     t0 = time.perf_counter()
     n32 = min(n, 1_000_000)
     ix32 = DeviceIndex.empty(n32, d, id_base=1, dtype="fp32", device=dev_index)
@@ -502,14 +503,26 @@ def other_configs(torch, np, device, dev_index, n, d, b, k):
     prefix = fill(ix32, n32, pre_rows)
     step_ms, kern_ms = timed_search(torch, ix32, q32, k, 20)
     info = ix32.launch_info(b, k)
-    tf = info.flops_per_launch / (kern_ms * 1e-3) / 1e12
+    ex32 = DeviceIndex.empty(n32, d, id_base=1, dtype="fp32", device=dev_index, sketch=False)
+    fill(ex32, n32, 0)
+    ex_step, ex_kern = timed_search(torch, ex32, q32, k, 20)
+    ex_info = ex32.launch_info(b, k)
+    tf = ex_info.flops_per_launch / (ex_kern * 1e-3) / 1e12
+    _, _, p_a = ix32.search(q32, k, return_positions=True)
+    _, _, p_b = ex32.search(q32, k, return_positions=True)
+    torch.cuda.synchronize(device)
+    same_rows = bool(torch.equal(p_a, p_b))
+    ex32.close()
     pre = DeviceIndex(prefix, id_base=1, dtype="fp32", device=dev_index)
     _, _, p_gpu = pre.search(q32, k, return_positions=True)
     torch.cuda.synchronize(device)
     pre.close()
     _, _, ref_32 = R.search(q32[:nv].cpu().numpy(), prefix.cpu().numpy(), k, dtype=R.DTYPE_F32)
     c1 = {"rows": n32, "queries_per_s": round(b / (step_ms * 1e-3), 1), "step_ms": round(step_ms, 4), "kernel_ms": round(kern_ms, 4),
-          "bound": "mfma", "mfma_tflops": round(tf, 1), "frac_of_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+          "sketch_scan": bool(info.sketch_scan),
+          "exact_scan": {"queries_per_s": round(b / (ex_step * 1e-3), 1), "step_ms": round(ex_step, 4), "kernel_ms": round(ex_kern, 4),
+                         "bound": "mfma", "mfma_tflops": round(tf, 1), "frac_of_f32_mfma_peak": round(tf / F32_MFMA_PEAK_TFLOPS, 4),
+                         "same_rows_as_default_path": same_rows},
           "recall_at_10": R.recall_at_k(p_gpu[:nv].cpu().numpy(), ref_32)}
     if d == 768:
         enc, ids, mask, _, _ = make_encoder(torch, device, dev_index, b, 32)

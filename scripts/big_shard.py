@@ -16,7 +16,7 @@ gen = torch.Generator(device=dev); gen.manual_seed(7)
 q = torch.randn((b, d), generator=gen, device=dev); q = (q / q.norm(dim=1, keepdim=True)).half()
 rng = np.random.default_rng(3)
 needles = np.sort(rng.choice(n, size=64, replace=False))  # query i is planted at row needles[i]
-ix = DeviceIndex.empty(n, d, id_base=1, dtype="fp16", device=0)
+ix = DeviceIndex.empty(n, d, id_base=1, dtype="fp16", device=0)  # VQA_SKETCH=0 in the environment: the exact scan
 chunk = 1 << 20
 t0 = time.perf_counter()
 for c0 in range(0, n, chunk):
@@ -40,4 +40,5 @@ ms = (time.perf_counter() - t0) / args.steps * 1e3
 ok = bool(np.array_equal(p[:64, 0].cpu().numpy(), needles)) and bool((s[:64, 0] > 0.99).all())
 print(json.dumps({"rows": n, "index_gb": round(n * d * 2 / 1e9, 1), "build_s": round(build_s, 1), "ms_per_batch": round(ms, 3),
                   "queries_per_s": round(b / ms * 1e3, 1), "hbm_gbs": round(n * d * 2 / ms / 1e6, 1), "needles_found_first": ok,
-                  "hbm_allocated_gb": round(torch.cuda.memory_allocated() / 1e9, 1)}))
+                  "sketch_scan": int(ix.launch_info(b, k).sketch_scan), "hbm_allocated_gb": round(torch.cuda.memory_allocated() / 1e9, 1),
+                  "hbm_in_use_gb": round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9, 1)}))

@@ -4,14 +4,16 @@ import numpy as np, torch
 from vietnamese_qa_system_amd.index import DeviceIndex
 dev = torch.device("cuda", 0)
 def unit(gen, n, d):
-    x = torch.randn((n, d), generator=gen, device=dev); return (x / x.norm(dim=1, keepdim=True)).half()
+    x = torch.randn((n, d), generator=gen, device=dev); x = x / x.norm(dim=1, keepdim=True)
+    return x.half() if dtype == "fp16" else x
 gen = torch.Generator(device=dev); gen.manual_seed(1)
 n, d = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000, int(sys.argv[2]) if len(sys.argv) > 2 else 768
-x = torch.empty((n, d), dtype=torch.float16, device=dev)
+dtype = sys.argv[3] if len(sys.argv) > 3 else "fp16"
+x = torch.empty((n, d), dtype=torch.float16 if dtype == 'fp16' else torch.float32, device=dev)
 for c0 in range(0, n, 1 << 18): x[c0:c0 + (1 << 18)] = unit(gen, min(n, c0 + (1 << 18)) - c0, d)
 q = unit(gen, 256, d)
 x[n // 3] = x[5]; x[n - 7] = x[5]; q[0] = x[5]
-a = DeviceIndex(x, sketch=False); b = DeviceIndex(x, sketch=True)
+a = DeviceIndex(x, sketch=False, dtype=dtype); b = DeviceIndex(x, sketch=True, dtype=dtype)
 ia, ib = a.launch_info(256, 10), b.launch_info(256, 10)
 print("sketch_scan", ia.sketch_scan, ib.sketch_scan, "first_stage_rows", ib.first_stage_rows)
 sa, _, pa = a.search(q, 10, return_positions=True); sb, _, pb = b.search(q, 10, return_positions=True)

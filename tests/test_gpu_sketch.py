@@ -20,10 +20,10 @@ def _unit(rng, n, d):
     return R.l2_normalize(rng.standard_normal((n, d)).astype(np.float32)).astype(np.float16)
 
 
-def _index(x, monkeypatch, sketch, stage_min="2", ids=None, id_base=0):
+def _index(x, monkeypatch, sketch, stage_min="2", ids=None, id_base=0, dtype="fp16"):
     from vietnamese_qa_system_amd.index import DeviceIndex
     monkeypatch.setenv("VQA_STAGE_MIN", stage_min)
-    return DeviceIndex(x, ids=ids, id_base=id_base, dtype="fp16", device=0, sketch=sketch)
+    return DeviceIndex(x, ids=ids, id_base=id_base, dtype=dtype, device=0, sketch=sketch)
 
 
 def _search(ix, q, k):
@@ -122,3 +122,28 @@ def test_shard_filled_in_unaligned_chunks_has_a_consistent_sketch(native_lib, mo
     whole.close()
     parts.close()
     assert np.array_equal(p0, p1) and np.array_equal(s0, s1)
+
+
+def test_fp32_shards_take_the_sketch_too(native_lib, monkeypatch):
+    """BASELINE configs[1]'s storage type: the exact scan runs on the f32 MFMA (1/16 of the fp16 rate), the sketch scan on the same
+    int8 MFMA as for fp16 shards; survivors are re-scored in fp32 from the stored fp32 rows.  Same rows as the exact scan, scores
+    within fp32 rounding of a different summation order, duplicates bit-equal in position order."""
+    n, d, b, k = 200_000, 768, 48, 10
+    rng = np.random.default_rng(21)
+    x = R.l2_normalize(rng.standard_normal((n, d)).astype(np.float32))
+    q = R.l2_normalize(rng.standard_normal((b, d)).astype(np.float32))
+    dup = [9, 65_535, 65_536, 150_000]
+    for r in dup[1:]:
+        x[r] = x[dup[0]]
+    q[0] = x[dup[0]]
+    ref = _index(x, monkeypatch, sketch=False, dtype="fp32")
+    ske = _index(x, monkeypatch, sketch=True, dtype="fp32")
+    assert ref.launch_info(b, k).sketch_scan == 0 and ske.launch_info(b, k).sketch_scan == 1
+    s0, _, p0 = _search(ref, q, k)
+    s1, _, p1 = _search(ske, q, k)
+    ref.close()
+    ske.close()
+    s_full = R.full_scores(q, x, R.DTYPE_F32)
+    R.check_topk(s1, p1, s_full, k, score_tol=SCORE_TOL, tie_tol=TIE_TOL)
+    assert np.array_equal(p1, p0) and np.abs(s1 - s0).max() <= 2e-6
+    assert p1[0, :4].tolist() == dup and len(set(s1[0, :4].tolist())) == 1

@@ -228,11 +228,11 @@ extern "C" int vqa_index_set_rows(vqa_index* ix, int64_t first, int64_t count, c
         // several calls always ends up consistent
         VQA_HIP_CHECK(hipStreamSynchronize(nullptr));
         const int64_t t0 = first >> 8, t1 = (first + count - 1) >> 8;
-        int rc = vqa_launch_tile_scales(ix->rows, t0, t1 - t0 + 1, ix->d_pad, ix->tile_info, nullptr);
+        int rc = vqa_launch_tile_scales(ix->rows, ix->dtype, t0, t1 - t0 + 1, ix->d_pad, ix->tile_info, nullptr);
         if (rc != VQA_OK) return rc;
         const int64_t r0 = t0 * 256, r1 = std::min<int64_t>(ix->n, (t1 + 1) * 256);
-        rc = vqa_launch_sketch_rows(ix->rows, r0, r1 - r0, ix->d_pad, ix->d_pad8, ix->tile_info, ix->rows8, nullptr, nullptr, nullptr,
-                                    nullptr);
+        rc = vqa_launch_sketch_rows(ix->rows, ix->dtype, r0, r1 - r0, ix->d_pad, ix->d_pad8, ix->tile_info, ix->rows8, nullptr, nullptr,
+                                    nullptr, nullptr);
         if (rc != VQA_OK) return rc;
     }
     if (ids_or_null) VQA_HIP_CHECK(hipMemcpy(ix->ids + first, ids_or_null, (size_t)count * 8, hipMemcpyDefault));
@@ -331,7 +331,10 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
         }
         // int8 sketch: fp16 shards only, and only where a workgroup's tile maxima fit the scan's LDS
         // (and only for shards large enough for the two-stage search, whose main launch the sketch scan replaces)
-        ix->sketch = (flags & VQA_INDEX_SKETCH) && dtype == VQA_F16 && n > 0 && ix->stage_min_tiles > 0 &&
+        // fp32 shards: the exact scan runs at 1/16 of the fp16 matrix rate, the sketch scan at the same int8 rate: the
+        // two-stage / sketch plan pays from 8 tiles per compute unit (524k rows) on
+        if ((flags & VQA_INDEX_SKETCH) && dtype == VQA_F32 && !sg && ix->stage_min_tiles > 8) ix->stage_min_tiles = 8;
+        ix->sketch = (flags & VQA_INDEX_SKETCH) && (dtype == VQA_F16 || dtype == VQA_F32) && n > 0 && ix->stage_min_tiles > 0 &&
                      tiles >= (int64_t)ix->stage_min_tiles * ix->max_grid &&
                      (tiles + ix->max_grid - 1) / ix->max_grid <= vqa_score_topk_sketch_max_tiles() && d <= 8192;
         if (ix->sketch) {
@@ -557,7 +560,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
         if (rc != VQA_OK) return rc;
         const bool use_sketch = sketch_active(ix, p, k);
         if (use_sketch) {  // the query tile's int8 sketch (every query its own scale) + ||q_lo||, ||q||
-            rc = vqa_launch_sketch_rows(ix->q_stage, 0, VQA_QUERY_TILE, ix->d_pad, ix->d_pad8, nullptr, ix->q8_stage, ix->qrow,
+            rc = vqa_launch_sketch_rows(ix->q_stage, ix->dtype, 0, VQA_QUERY_TILE, ix->d_pad, ix->d_pad8, nullptr, ix->q8_stage, ix->qrow,
                                         ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, stream);
             if (rc != VQA_OK) return rc;
         }
@@ -666,8 +669,8 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
                     // first stage's k rows are scored exactly and the k best of each query's list are the result.  Should a
                     // candidate buffer fill up (adversarial data: the bound prunes nothing), sketch_flag sends the search through
                     // the exact main launch below, gated on the flag.
-                    rc = vqa_launch_sketch_qconst(ix->thr0, ix->qrow, ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, ix->qconst,
-                                                  ix->cand_cnt, ix->sketch_flag, stream);
+                    rc = vqa_launch_sketch_qconst(ix->thr0, ix->qrow, ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, ix->d_pad,
+                                                  ix->qconst, ix->cand_cnt, ix->sketch_flag, stream);
                     if (rc != VQA_OK) return rc;
                     SketchScanArgs sk;
                     sk.tile_info = reinterpret_cast<const float4*>(ix->tile_info);
@@ -694,7 +697,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
                     if (rc != VQA_OK) return rc;
                     if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
                     rc = vqa_launch_rescore(ix->regions, ix->region_cnt, kSketchCap, p.grid1, ix->stage_pos, nq, kk, ix->rows, ix->q_stage,
-                                            ix->d_pad, ix->cand_keys, ix->cand_cnt, kSketchCap, ix->sketch_flag, stream);
+                                            ix->dtype, ix->d_pad, ix->cand_keys, ix->cand_cnt, kSketchCap, ix->sketch_flag, stream);
                     if (rc != VQA_OK) return rc;
                     rc = vqa_launch_merge_partials(ix->cand_keys, 1, kSketchCap, nq, kk, ix->ids, ix->id_base, os, oi, op, nullptr, 1.0f, k, 0,
                                                    nullptr, true, nullptr, stream, 1, ix->cand_cnt);

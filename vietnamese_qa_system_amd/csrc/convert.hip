@@ -131,41 +131,57 @@ __global__ __launch_bounds__(256) void normalize_convert_kernel(const float* __r
     }
 }
 
-// ---- int8 sketch of fp16 rows (the pruning pre-pass of a large fp16 shard, score_topk.hip MODE 2).  One wave per row of a
-// TILED fp16 array (index rows or the staged query tile): the stored values x -> x_int = clamp(rint(x / s), -127, 127) in the
+// ---- int8 sketch of fp16 / fp32 rows (the pruning pre-pass of a large shard, score_topk.hip MODE 2).  One wave per row of a
+// TILED array (index rows or the staged query tile): the stored values x -> x_int = clamp(rint(x / s), -127, 127) in the
 // TILED int8 layout (K-blocks of 64 elements), with s the scale of the row's 256-row TILE (index rows: max|x| of the tile
-// / 127, tile_scale_kernel) or the row's own max|x| / 127 (queries), plus what the bound  |q . x - s_q s_x (q_int . x_int)| <= ||q_lo|| ||x_hi|| + ||q|| ||x_lo||  needs
+// / 127, tile_scale_kernel) or the row's own max|x| / 127 (queries), plus what the bound
+// |q . x - s_q s_x (q_int . x_int)| <= ||q_lo|| ||x_hi|| + ||q|| ||x_lo||  needs
 // (x_hi = s x_int, x_lo = x - x_hi): per row the scale, ||x_lo|| and ||x|| (queries), per 256-row tile the maxima of ||x_hi||
-// and ||x_lo|| (index rows; atomicMax on the bits of non-negative floats, interleaved [tile][2]).  Norms are rounded up (relative 2^-16) so that
+// and ||x_lo|| (index rows; atomicMax on the bits of non-negative floats, interleaved [tile][4]).  Norms are rounded up (relative 2^-16) so that
 // fp32 rounding inside this kernel can never make the bound too tight.
-__global__ __launch_bounds__(256) void sketch_rows_kernel(const _Float16* __restrict__ tiled16, long long first, long long count,
-                                                          int KT16, int KT8, const float* tile_info, int8_t* __restrict__ out8,
+// 16 consecutive elements (one int8 unit u) of a row of a TILED array of SRC: two fp16 units (2 u, 2 u + 1) or four fp32 units
+// (4 u .. 4 u + 3 = the four slots of K-block u); zero past the source's padding
+template <typename SRC>
+__device__ __forceinline__ void load_sketch_unit(const SRC* __restrict__ tiled, long long row, int u, int KTS, float (&x)[16]) {
+    constexpr int EPU = 16 / (int)sizeof(SRC);  // elements per 16-byte source unit: 8 or 4
+    constexpr int NU = 16 / EPU;                 // source units per int8 unit
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        const int us = NU * u + i;
+        if (us < KTS * 4) {
+            const SRC* p = tiled + tiled_unit(row, us >> 2, us & 3, KTS) * EPU;
+#pragma unroll
+            for (int e = 0; e < EPU; ++e) x[i * EPU + e] = (float)p[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < EPU; ++e) x[i * EPU + e] = 0.f;
+        }
+    }
+}
+
+template <typename SRC>
+__global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict__ tiled, long long first, long long count,
+                                                          int KTS, int KT8, const float* tile_info, int8_t* __restrict__ out8,
                                                           float* __restrict__ row_scale, float* __restrict__ row_lo,
                                                           float* __restrict__ row_norm, unsigned* tile_max /* = tile_info */) {
-    typedef _Float16 half8v __attribute__((ext_vector_type(8)));
     const int lane = threadIdx.x & 63;
     const long long ri = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ri >= count) return;
     const long long row = first + ri;
-    const int units8 = KT8 * 4, units16 = KT16 * 4;
-    // this lane's int8 units u = lane, lane + 64, ...: 16 elements each = fp16 units 2 u and 2 u + 1 (zero past the fp16 padding)
+    const int units8 = KT8 * 4;
+    // this lane's int8 units u = lane, lane + 64, ...
     constexpr int kMaxPer = 8;  // rows of up to 8 * 64 * 16 = 8192 elements
     float x[kMaxPer][16];
     float amax = 0.f;
 #pragma unroll
     for (int i = 0; i < kMaxPer; ++i) {
         const int u = lane + 64 * i;
+        if (u < units8) load_sketch_unit<SRC>(tiled, row, u, KTS, x[i]);
+        else
 #pragma unroll
-        for (int hlf = 0; hlf < 2; ++hlf) {
-            const int u16 = 2 * u + hlf;
-            half8v v = half8v{0, 0, 0, 0, 0, 0, 0, 0};
-            if (u < units8 && u16 < units16) v = *reinterpret_cast<const half8v*>(tiled16 + tiled_unit(row, u16 >> 2, u16 & 3, KT16) * 8);
+            for (int e = 0; e < 16; ++e) x[i][e] = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                x[i][8 * hlf + e] = (float)v[e];
-                amax = fmaxf(amax, fabsf((float)v[e]));
-            }
-        }
+        for (int e = 0; e < 16; ++e) amax = fmaxf(amax, fabsf(x[i][e]));
     }
     float s = tile_info ? tile_info[4 * (row >> 8) + 3] : 0.f;  // index rows: the scale of the row's tile
     if (!(s > 0.f)) {
@@ -213,19 +229,20 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const _Float16* __rest
     }
 }
 
-// one workgroup per tile of a TILED fp16 array: scale = max |x| over the tile's 256 rows / 127 (a tile of zeros: 1), written with
-// its reciprocal to tile_info[tile] = (0, 0, 1 / scale, scale) -- the two maxima are cleared for sketch_rows_kernel to fill
-__global__ __launch_bounds__(256) void tile_scale_kernel(const _Float16* __restrict__ tiled16, long long tile0, int KT16,
+// one workgroup per tile of a TILED fp16 / fp32 array: scale = max |x| over the tile's 256 rows / 127 (a tile of zeros: 1), written
+// with its reciprocal to tile_info[tile] = (0, 0, 1 / scale, scale) -- the two maxima are cleared for sketch_rows_kernel to fill
+template <typename SRC>
+__global__ __launch_bounds__(256) void tile_scale_kernel(const SRC* __restrict__ tiled, long long tile0, int KTS,
                                                          float* __restrict__ tile_info) {
-    typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+    constexpr int EPU = 16 / (int)sizeof(SRC);
     __shared__ float red[4];
     const long long tile = tile0 + blockIdx.x;
-    const _Float16* base = tiled16 + (size_t)tile * KT16 * 1024 * 8;  // the tile's KT16 blocks of 16 KiB are contiguous
+    const SRC* base = tiled + (size_t)tile * KTS * 1024 * EPU;  // the tile's KTS blocks of 16 KiB are contiguous
     float m = 0.f;
-    for (int u = threadIdx.x; u < KT16 * 1024; u += 256) {
-        const half8v v = *reinterpret_cast<const half8v*>(base + (size_t)u * 8);
+    for (int u = threadIdx.x; u < KTS * 1024; u += 256) {
+        const SRC* p = base + (size_t)u * EPU;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) m = fmaxf(m, fabsf((float)v[e]));
+        for (int e = 0; e < EPU; ++e) m = fmaxf(m, fabsf((float)p[e]));
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
@@ -314,22 +331,34 @@ extern "C" int vqa_normalize_convert(const float* rows, int64_t n, int32_t d, in
     return VQA_OK;
 }
 
-int vqa_launch_sketch_rows(const void* tiled16, int64_t first, int64_t count, int32_t d_pad16, int32_t d_pad8, const float* tile_info,
-                           void* out8, float* row_scale, float* row_lo, float* row_norm, hipStream_t stream) {
+int vqa_launch_sketch_rows(const void* tiled, int32_t src_dtype, int64_t first, int64_t count, int32_t d_pad_src, int32_t d_pad8,
+                           const float* tile_info, void* out8, float* row_scale, float* row_lo, float* row_norm, hipStream_t stream) {
     if (count == 0) return VQA_OK;
+    VQA_REQUIRE(src_dtype == VQA_F16 || src_dtype == VQA_F32, "sketch_rows: source type %d", src_dtype);
     VQA_REQUIRE(d_pad8 / 16 <= 8 * 64, "sketch_rows: rows of %d elements are too long for the int8 sketch", d_pad8);
-    hipLaunchKernelGGL(sketch_rows_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, stream,
-                       reinterpret_cast<const _Float16*>(tiled16), (long long)first, (long long)count, d_pad16 / 32, d_pad8 / 64,
-                       tile_info, reinterpret_cast<int8_t*>(out8), row_scale, row_lo, row_norm,
-                       reinterpret_cast<unsigned*>(const_cast<float*>(tile_info)));
+    const dim3 grid((unsigned)((count + 3) / 4));
+    unsigned* tmax = reinterpret_cast<unsigned*>(const_cast<float*>(tile_info));
+    if (src_dtype == VQA_F16)
+        hipLaunchKernelGGL(sketch_rows_kernel<_Float16>, grid, dim3(256), 0, stream, reinterpret_cast<const _Float16*>(tiled),
+                           (long long)first, (long long)count, d_pad_src / 32, d_pad8 / 64, tile_info, reinterpret_cast<int8_t*>(out8),
+                           row_scale, row_lo, row_norm, tmax);
+    else
+        hipLaunchKernelGGL(sketch_rows_kernel<float>, grid, dim3(256), 0, stream, reinterpret_cast<const float*>(tiled),
+                           (long long)first, (long long)count, d_pad_src / 16, d_pad8 / 64, tile_info, reinterpret_cast<int8_t*>(out8),
+                           row_scale, row_lo, row_norm, tmax);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }
 
-int vqa_launch_tile_scales(const void* tiled16, int64_t tile0, int64_t ntiles, int32_t d_pad16, float* tile_info, hipStream_t stream) {
+int vqa_launch_tile_scales(const void* tiled, int32_t src_dtype, int64_t tile0, int64_t ntiles, int32_t d_pad_src, float* tile_info,
+                           hipStream_t stream) {
     if (ntiles == 0) return VQA_OK;
-    hipLaunchKernelGGL(tile_scale_kernel, dim3((unsigned)ntiles), dim3(256), 0, stream, reinterpret_cast<const _Float16*>(tiled16),
-                       (long long)tile0, d_pad16 / 32, tile_info);
+    if (src_dtype == VQA_F16)
+        hipLaunchKernelGGL(tile_scale_kernel<_Float16>, dim3((unsigned)ntiles), dim3(256), 0, stream,
+                           reinterpret_cast<const _Float16*>(tiled), (long long)tile0, d_pad_src / 32, tile_info);
+    else
+        hipLaunchKernelGGL(tile_scale_kernel<float>, dim3((unsigned)ntiles), dim3(256), 0, stream, reinterpret_cast<const float*>(tiled),
+                           (long long)tile0, d_pad_src / 16, tile_info);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

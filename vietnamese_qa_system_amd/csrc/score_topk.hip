@@ -690,8 +690,9 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int q = wn * 64 + ni * 16 + c;
-            // 2e-6: the exact scores (fp32 sums of exact products) against the real-number dot product the bound speaks of
-            const float num = sk_q[q] - sk_q[kQ + q] * a_hi - sk_q[2 * kQ + q] * b_lo - 2e-6f;
+            // (the fp32 summation error of the exact scores against the real-number dot product the bound speaks of rides in the two
+            // per-query factors: sketch_qconst_kernel)
+            const float num = sk_q[q] - sk_q[kQ + q] * a_hi - sk_q[2 * kQ + q] * b_lo;
             const float t = num * sk_q[3 * kQ + q] * inv_sx;
             T[ni] = t - fabsf(t) * 4e-6f - 0.5f;  // every rounding of this line errs towards MORE candidates; D is an integer
         }

@@ -26,13 +26,17 @@ __device__ __forceinline__ size_t unit_of(long long row, int u, int KT) {  // 16
 // consumed (the rows are 64-byte pieces at 16 KiB strides of the tiled index: latency, not bandwidth, is what a one-pair-at-a-time
 // loop pays).  grid (x, regions + 1): y < regions walks that workgroup's region of the sketch scan, y == regions the rows of
 // the exact first stage (stage_pos [nq][k] positions, -1 = none).
-constexpr int kRescoreUnitsMax = 8;  // 16-byte units per lane and pair: rows of up to 32 * 8 * 8 = 2048 elements take the fast path
+constexpr int kRescoreUnitsMax = 8;  // 16-byte units per lane and pair: rows of up to 32 * 8 * 8 = 2048 fp16 / 1024 fp32 elements take the fast path
 
+// T = _Float16 (8 elements per 16-byte unit; products exact in fp32) or float (4 per unit: fp32 index, fp32 fma chain)
+template <typename T>
 __global__ __launch_bounds__(256) void rescore_kernel(const unsigned long long* __restrict__ regions, const unsigned* __restrict__ counts,
                                                       int cap, int nregions, const long long* __restrict__ stage_pos, int nq, int k,
-                                                      const _Float16* __restrict__ X, const _Float16* __restrict__ Q, int KT,
+                                                      const T* __restrict__ X, const T* __restrict__ Q, int KT,
                                                       vqa_key* __restrict__ cand_keys, unsigned* __restrict__ cand_cnt, int capq,
                                                       int* __restrict__ overflow) {
+    constexpr int EPU = 16 / (int)sizeof(T);
+    typedef T unit_t __attribute__((ext_vector_type(EPU)));
     const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const int y = blockIdx.y;
@@ -58,16 +62,16 @@ __global__ __launch_bounds__(256) void rescore_kernel(const unsigned long long* 
         pair_of(i0 + 2 + half, q[1], pos[1]);
         float acc[2] = {0.f, 0.f};
         if (units <= 32 * kRescoreUnitsMax) {
-            half8 xv[2][kRescoreUnitsMax], qv[2][kRescoreUnitsMax];
+            unit_t xv[2][kRescoreUnitsMax], qv[2][kRescoreUnitsMax];
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
                 for (int j = 0; j < kRescoreUnitsMax; ++j) {
                     const int u = hl + 32 * j;
-                    xv[p][j] = qv[p][j] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                    xv[p][j] = qv[p][j] = unit_t{};
                     if (u < units && pos[p] >= 0) {
-                        xv[p][j] = *reinterpret_cast<const half8*>(X + unit_of(pos[p], u, KT) * 8);
-                        qv[p][j] = *reinterpret_cast<const half8*>(Q + unit_of(q[p], u, KT) * 8);
+                        xv[p][j] = *reinterpret_cast<const unit_t*>(X + unit_of(pos[p], u, KT) * EPU);
+                        qv[p][j] = *reinterpret_cast<const unit_t*>(Q + unit_of(q[p], u, KT) * EPU);
                     }
                 }
 #pragma unroll
@@ -75,14 +79,14 @@ __global__ __launch_bounds__(256) void rescore_kernel(const unsigned long long* 
 #pragma unroll
                 for (int j = 0; j < kRescoreUnitsMax; ++j)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[p] = __builtin_fmaf((float)xv[p][j][e], (float)qv[p][j][e], acc[p]);
+                    for (int e = 0; e < EPU; ++e) acc[p] = __builtin_fmaf((float)xv[p][j][e], (float)qv[p][j][e], acc[p]);
         } else {
             for (int p = 0; p < 2; ++p)
                 for (int u = hl; u < units && pos[p] >= 0; u += 32) {
-                    const half8 xw = *reinterpret_cast<const half8*>(X + unit_of(pos[p], u, KT) * 8);
-                    const half8 qw = *reinterpret_cast<const half8*>(Q + unit_of(q[p], u, KT) * 8);
+                    const unit_t xw = *reinterpret_cast<const unit_t*>(X + unit_of(pos[p], u, KT) * EPU);
+                    const unit_t qw = *reinterpret_cast<const unit_t*>(Q + unit_of(q[p], u, KT) * EPU);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[p] = __builtin_fmaf((float)xw[e], (float)qw[e], acc[p]);
+                    for (int e = 0; e < EPU; ++e) acc[p] = __builtin_fmaf((float)xw[e], (float)qw[e], acc[p]);
                 }
         }
 #pragma unroll
@@ -98,15 +102,19 @@ __global__ __launch_bounds__(256) void rescore_kernel(const unsigned long long* 
     }
 }
 
-// per query: theta (the exact k-th best score of the first stage), ||q_lo||, ||q||, 1 / s_q -> qconst [4][256]; clears the
+// per query: theta (the exact k-th best score of the first stage), ||q_lo||, ||q|| (1 + fp margin), 1 / s_q -> qconst [4][256]; clears the
 // candidate counters and the overflow flag of this search
 __global__ void sketch_qconst_kernel(const float* __restrict__ thr, const float* __restrict__ qscale, const float* __restrict__ qlo,
-                                     const float* __restrict__ qnorm, float* __restrict__ qconst,
+                                     const float* __restrict__ qnorm, float fp_margin, float* __restrict__ qconst,
                                      unsigned* __restrict__ cand_cnt, int* __restrict__ overflow) {
     const int q = threadIdx.x;
     qconst[q] = thr[q];
-    qconst[256 + q] = qlo[q];
-    qconst[512 + q] = qnorm[q];
+    // The scores a search returns -- and theta -- are fp32 sums, the bound speaks of the real-number dot product: both differ
+    // from it by at most gamma_d ||q|| ||x|| (d terms, unit roundoff 2^-24 per fma; for the MFMA's internal order as well),
+    // ||x|| <= ||x_hi|| + ||x_lo||.  fp_margin = 2 gamma_d rides on BOTH slack terms: ||q_lo|| A + ||q|| B + fp_margin ||q|| (A + B)
+    // = (||q_lo|| + fp_margin ||q||) A + ||q|| (1 + fp_margin) B.
+    qconst[256 + q] = qlo[q] + fp_margin * qnorm[q];
+    qconst[512 + q] = qnorm[q] * (1.0f + fp_margin);
     qconst[768 + q] = 1.0f / qscale[q];
     cand_cnt[q] = 0u;
     if (q == 0) *overflow = 0;
@@ -114,19 +122,26 @@ __global__ void sketch_qconst_kernel(const float* __restrict__ thr, const float*
 
 }  // namespace
 
-int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float* qlo, const float* qnorm, float* qconst,
+int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float* qlo, const float* qnorm, int32_t d, float* qconst,
                              unsigned* cand_cnt, int* overflow, hipStream_t stream) {
-    hipLaunchKernelGGL(sketch_qconst_kernel, dim3(1), dim3(256), 0, stream, thr, qscale, qlo, qnorm, qconst, cand_cnt, overflow);
+    const float fp_margin = 2.0f * (float)d * 1.2e-7f;  // 2 gamma_d with gamma_d <= d 2^-24 / (1 - d 2^-24) < 1.2e-7 d / 2 ... kept at twice that
+    hipLaunchKernelGGL(sketch_qconst_kernel, dim3(1), dim3(256), 0, stream, thr, qscale, qlo, qnorm, fp_margin, qconst, cand_cnt, overflow);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }
 
 int vqa_launch_rescore(const unsigned long long* regions, const unsigned* counts, int cap, int nregions, const long long* stage_pos,
-                       int nq, int k, const void* x16, const void* q16, int32_t d_pad16, vqa_key* cand_keys, unsigned* cand_cnt,
+                       int nq, int k, const void* x, const void* q, int32_t dtype, int32_t d_pad, vqa_key* cand_keys, unsigned* cand_cnt,
                        int capq, int* overflow, hipStream_t stream) {
-    hipLaunchKernelGGL(rescore_kernel, dim3(32, nregions + 1), dim3(256), 0, stream, regions, counts, cap, nregions, stage_pos, nq, k,
-                       reinterpret_cast<const _Float16*>(x16), reinterpret_cast<const _Float16*>(q16), d_pad16 / 32, cand_keys, cand_cnt,
-                       capq, overflow);
+    VQA_REQUIRE(dtype == VQA_F16 || dtype == VQA_F32, "rescore: storage type %d", dtype);
+    if (dtype == VQA_F16)
+        hipLaunchKernelGGL(rescore_kernel<_Float16>, dim3(32, nregions + 1), dim3(256), 0, stream, regions, counts, cap, nregions, stage_pos,
+                           nq, k, reinterpret_cast<const _Float16*>(x), reinterpret_cast<const _Float16*>(q), d_pad / 32, cand_keys, cand_cnt,
+                           capq, overflow);
+    else
+        hipLaunchKernelGGL(rescore_kernel<float>, dim3(32, nregions + 1), dim3(256), 0, stream, regions, counts, cap, nregions, stage_pos, nq,
+                           k, reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(q), d_pad / 16, cand_keys, cand_cnt, capq,
+                           overflow);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

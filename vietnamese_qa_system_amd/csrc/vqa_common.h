@@ -137,16 +137,17 @@ int vqa_launch_untile_rows(const void* tiled, int64_t first, int64_t count, int3
                            hipStream_t stream);
 
 // ---- int8 sketch (large fp16 shards: the rigorous pruning pre-pass, score_topk.hip MODE 2) -------------------------------------
-// TILED fp16 rows [first, first + count) -> TILED int8 (K-blocks of 64 elements).  tile_info [tiles][4] floats = (max ||x_hi||,
+// TILED fp16 / fp32 rows [first, first + count) -> TILED int8 (K-blocks of 64 elements).  tile_info [tiles][4] floats = (max ||x_hi||,
 // max ||x_lo||, 1 / scale, scale) per 256-row tile: not null (index rows) -> the rows take their tile's scale and raise its two
 // maxima; null (the query tile) -> every row its own max|x| / 127, with per-row scale / ||x_lo|| / ||x|| outputs
-int vqa_launch_sketch_rows(const void* tiled16, int64_t first, int64_t count, int32_t d_pad16, int32_t d_pad8, const float* tile_info,
-                           void* out8, float* row_scale, float* row_lo, float* row_norm, hipStream_t stream);
-// scale (= max |x| / 127) of tiles [tile0, tile0 + ntiles) of a TILED fp16 array into tile_info; clears their two maxima
-int vqa_launch_tile_scales(const void* tiled16, int64_t tile0, int64_t ntiles, int32_t d_pad16, float* tile_info, hipStream_t stream);
+int vqa_launch_sketch_rows(const void* tiled, int32_t src_dtype, int64_t first, int64_t count, int32_t d_pad_src, int32_t d_pad8,
+                           const float* tile_info, void* out8, float* row_scale, float* row_lo, float* row_norm, hipStream_t stream);
+// scale (= max |x| / 127) of tiles [tile0, tile0 + ntiles) of a TILED fp16 / fp32 array into tile_info; clears their two maxima
+int vqa_launch_tile_scales(const void* tiled, int32_t src_dtype, int64_t tile0, int64_t ntiles, int32_t d_pad_src, float* tile_info,
+                           hipStream_t stream);
 // sketch search: per-query constants of the scan + reset of the candidate counters; exact scores of the candidate pairs
-int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float* qlo, const float* qnorm, float* qconst,
+int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float* qlo, const float* qnorm, int32_t d, float* qconst,
                              unsigned* cand_cnt, int* overflow, hipStream_t stream);
 int vqa_launch_rescore(const unsigned long long* regions, const unsigned* counts, int cap, int nregions, const long long* stage_pos,
-                       int nq, int k, const void* x16, const void* q16, int32_t d_pad16, vqa_key* cand_keys, unsigned* cand_cnt,
-                       int capq, int* overflow, hipStream_t stream);
+                       int nq, int k, const void* x, const void* q, int32_t dtype /* VQA_F16 | VQA_F32: both tiled */, int32_t d_pad,
+                       vqa_key* cand_keys, unsigned* cand_cnt, int capq, int* overflow, hipStream_t stream);

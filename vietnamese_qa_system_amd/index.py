@@ -76,7 +76,7 @@ class DeviceIndex:
         # library keeps one only where its two-stage search applies; VQA_SKETCH=0 or sketch=False: exact fp16 scan everywhere
         if sketch is None:
             sketch = os.environ.get("VQA_SKETCH", "1") != "0"
-        flags = (N.VQA_INDEX_HAS_IDS if has_ids else 0) | (N.VQA_INDEX_SKETCH if sketch and self.dtype == N.VQA_F16 else 0)
+        flags = (N.VQA_INDEX_HAS_IDS if has_ids else 0) | (N.VQA_INDEX_SKETCH if sketch and self.dtype in (N.VQA_F16, N.VQA_F32) else 0)
         with torch.cuda.device(self.device):
             N.check(self._lib.vqa_index_create(ctypes.byref(self._handle), self.device, int(n), int(d), self.dtype, None,
                                                N.VQA_F16, None, int(id_base), flags),
