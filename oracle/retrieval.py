@@ -306,3 +306,57 @@ def check_topk(got_scores: np.ndarray, got_pos: np.ndarray, s_full: np.ndarray, 
         mask[gp] = False
         if mask.any():
             assert s_full[i, mask].max() <= ref_sc[-1] + tie_tol, f"query {i}: a better row was left out"
+
+
+# ---- int8 sketch of large fp16 / fp32 shards: CPU restatement of the pruning bound (checker only) ------------------
+# The build's large shards run their main launch over an int8 sketch (csrc/score_topk.hip MODE 2, csrc/convert.hip
+# sketch_rows_kernel) and score exactly only the (query, row) pairs whose upper bound reaches the threshold.  What is
+# restated here is the arithmetic that decides it, so that CPU tests can hold the bound itself to float64 truth:
+#   rows:    one scale per 256-row tile, s_t = max|x| over the tile / 127;  x_int = clip(rint(x / s_t), -127, 127)
+#   queries: one scale per query,        s_q = max|q| / 127
+#   q . x  <=  s_q s_t (q_int . x_int) + ||q_lo|| max_tile ||x_hi|| + ||q|| max_tile ||x_lo||     (Cauchy-Schwarz on the residues)
+# Reference interface: the scoring inside `embeddings.search` (heavy_ranker.py:98-101) -- the sketch only decides which rows
+# need the exact inner product.
+
+def sketch_rows(x: np.ndarray, tile: int = 256):
+    """Stored rows [n, d] -> (x_int int8 [n, d], scale per tile [tiles], max ||x_hi|| per tile, max ||x_lo|| per tile)."""
+    x = np.asarray(x, dtype=np.float32)
+    n = x.shape[0]
+    tiles = (n + tile - 1) // tile
+    xi = np.zeros(x.shape, dtype=np.int8)
+    scale = np.ones(tiles, dtype=np.float32)
+    hi_max = np.zeros(tiles, dtype=np.float32)
+    lo_max = np.zeros(tiles, dtype=np.float32)
+    for t in range(tiles):
+        rows = x[t * tile:(t + 1) * tile]
+        m = np.float32(np.abs(rows).max()) if rows.size else np.float32(0)
+        s = np.float32(m / np.float32(127.0)) if np.isfinite(m) and m > 0 else np.float32(1.0)
+        q = np.clip(np.rint(rows / s), -127, 127).astype(np.float32)
+        hi = q * s
+        xi[t * tile:(t + 1) * tile] = q.astype(np.int8)
+        scale[t] = s
+        hi_max[t] = np.sqrt((hi.astype(np.float32) ** 2).sum(axis=1, dtype=np.float32)).max() * np.float32(1 + 2.0 ** -16)
+        lo_max[t] = np.sqrt(((rows - hi) ** 2).sum(axis=1, dtype=np.float32)).max() * np.float32(1 + 2.0 ** -16)
+    return xi, scale, hi_max, lo_max
+
+
+def sketch_queries(q: np.ndarray):
+    """Query rows [b, d] -> (q_int int8, scale [b], ||q_lo|| [b], ||q|| [b])."""
+    q = np.asarray(q, dtype=np.float32)
+    m = np.abs(q).max(axis=1)
+    s = np.where(m > 0, m / np.float32(127.0), np.float32(1.0)).astype(np.float32)
+    qi = np.clip(np.rint(q / s[:, None]), -127, 127).astype(np.float32)
+    lo = q - qi * s[:, None]
+    up = np.float32(1 + 2.0 ** -16)
+    return qi.astype(np.int8), s, np.sqrt((lo ** 2).sum(axis=1, dtype=np.float32)) * up, np.sqrt((q ** 2).sum(axis=1, dtype=np.float32)) * up
+
+
+def sketch_upper_bounds(q: np.ndarray, x: np.ndarray, tile: int = 256) -> np.ndarray:
+    """[b, n] rigorous upper bounds of q . x (the stored values, real-number dot product) from the int8 sketches."""
+    xi, sx, hi_max, lo_max = sketch_rows(x, tile)
+    qi, sq, qlo, qn = sketch_queries(q)
+    d_int = qi.astype(np.int64) @ xi.astype(np.int64).T  # exact, as the int32 MFMA accumulators are
+    t_of = np.arange(x.shape[0]) // tile
+    main = sq[:, None].astype(np.float64) * sx[t_of][None, :].astype(np.float64) * d_int
+    slack = qlo[:, None].astype(np.float64) * hi_max[t_of][None, :] + qn[:, None].astype(np.float64) * lo_max[t_of][None, :]
+    return main + slack

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Sweeps away from the headline configuration (search step over rows / k / batch / dimension, encoder forward over batch and
-# sequence length): the place where mis-tuned thresholds show (round 2 found three).  GPU box -> gpurun_out/r02_sweeps.txt
+# sequence length): the place where mis-tuned thresholds show (round 2 found three).  GPU box -> gpurun_out/<tag>_sweeps.txt (usage: sweeps.sh [tag])
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r02_sweeps.txt; : > $O
+O=gpurun_out/${1:-r03}_sweeps.txt; : > $O
 kb() { python scripts/kbench.py "$@" 2>&1 | grep step | sed 's/.*step/step/' | cut -c1-75; }
 echo "== search step, fp16, B=256, k=10, d=768, rows:" >> $O
 for n in 1000 5000 20000 65536 300000 1000000 3000000 10000000; do echo -n "rows=$n: " >> $O; kb --n $n --steps 30 >> $O; done

@@ -1,0 +1,68 @@
+"""The pruning bound of the int8 sketch search, held to float64 truth on the CPU (oracle/retrieval.py: sketch_*).
+
+The GPU path prunes a (query, row) pair only when this bound stays below the running threshold, so the bound must never fall
+below the true score -- for unit vectors, for tiles whose scale one outlier component sets, for unnormalised and zero rows, for
+values that clip, for fp16 and fp32 stored values alike -- and it must be tight enough to prune (otherwise the sketch search
+degenerates into its exact fallback)."""
+import numpy as np
+import pytest
+
+from oracle import retrieval as R
+
+
+def _cases():
+    rng = np.random.default_rng(0)
+    unit = R.l2_normalize(rng.standard_normal((1500, 96)).astype(np.float32))
+    out = [("unit fp16", unit.astype(np.float16).astype(np.float32)), ("unit fp32", unit)]
+    x = unit.copy()
+    x[300, 7] = 800.0          # one component sets the scale of its tile
+    x[301] *= 40               # a row of norm 40
+    x[600:700] = 0             # zero rows (a zero tile among them: rows 512..767 are not all zero, 600..700 are)
+    x[1400:] = 0
+    out.append(("outliers, zero rows", x.astype(np.float16).astype(np.float32)))
+    out.append(("tiny values", (unit * 1e-4).astype(np.float16).astype(np.float32)))
+    out.append(("heavy tails", (rng.standard_t(2, size=(1500, 96)) * 0.05).astype(np.float16).astype(np.float32)))
+    return out
+
+
+@pytest.mark.parametrize("name,x", _cases(), ids=[c[0] for c in _cases()])
+def test_sketch_bound_never_falls_below_the_true_score(name, x):
+    rng = np.random.default_rng(1)
+    q = R.l2_normalize(rng.standard_normal((33, x.shape[1])).astype(np.float32)).astype(np.float16).astype(np.float32)
+    q[0] = x[300] / max(np.linalg.norm(x[300]), 1e-9)   # along the outlier row
+    q[1] = 0
+    q[2] = x[5]
+    ub = R.sketch_upper_bounds(q, x)
+    true = q.astype(np.float64) @ x.astype(np.float64).T
+    assert np.all(ub >= true), (name, float((true - ub).max()))
+    assert np.all(np.isfinite(ub))
+
+
+def test_sketch_bound_prunes_unit_vectors():
+    """d = 768 unit vectors: the slack is about half a standard deviation of the scores.  At this toy size the threshold (10th
+    best of 410 rows: 2 sigma) still lets 8 % of the pairs through; at 10M rows it sits at 4.3 sigma and 1e-4 of them survive
+    (220 000 of 2.3e9: the GPU path's regime)."""
+    rng = np.random.default_rng(2)
+    n, d, b = 4096, 768, 16
+    x = R.l2_normalize(rng.standard_normal((n, d)).astype(np.float32)).astype(np.float16).astype(np.float32)
+    q = R.l2_normalize(rng.standard_normal((b, d)).astype(np.float32)).astype(np.float16).astype(np.float32)
+    ub = R.sketch_upper_bounds(q, x)
+    true = q.astype(np.float64) @ x.astype(np.float64).T
+    slack = ub - true
+    sigma = 1 / np.sqrt(d)
+    assert 0 <= slack.min() and slack.max() < 1.2 * sigma and 0.3 * sigma < np.median(slack) < 0.8 * sigma
+    theta = np.sort(true[:, :n // 10], axis=1)[:, -10]            # exact 10th best of the first tenth of the rows
+    survivors = (ub[:, n // 10:] >= theta[:, None]).mean()
+    assert survivors < 0.15
+    # every row of the true top-10 survives
+    top = np.argsort(-true, axis=1)[:, :10]
+    assert all(ub[i, j] >= theta[i] for i in range(b) for j in top[i])
+
+
+def test_sketch_rows_layout_and_scales():
+    x = np.zeros((300, 8), dtype=np.float32)
+    x[0, 0] = 1.27
+    x[299, 3] = -2.54
+    xi, s, hi, lo = R.sketch_rows(x)
+    assert s.shape == (2,) and np.isclose(s[0], 0.01) and np.isclose(s[1], 0.02)
+    assert xi[0, 0] == 127 and xi[299, 3] == -127 and hi[0] >= 1.27 and lo.max() < 1e-6

@@ -218,7 +218,11 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
     }
     if (lane == 0) {
         const float up = 1.0f + 1.0f / 65536.0f;
-        const float hi = sqrtf(hi2) * up, lo = sqrtf(lo2) * up + 1e-30f, nn = sqrtf(n2) * up;
+        float hi = sqrtf(hi2) * up, lo = sqrtf(lo2) * up + 1e-30f, nn = sqrtf(n2) * up;
+        // a row holding NaN / Inf cannot be bounded: an infinite norm sends its whole tile (or query) to the candidates
+        if (!(hi < INFINITY)) hi = INFINITY;
+        if (!(lo < INFINITY)) lo = INFINITY;
+        if (!(nn < INFINITY)) nn = INFINITY;
         if (row_scale) row_scale[ri] = s;
         if (row_lo) row_lo[ri] = lo;
         if (row_norm) row_norm[ri] = nn;
