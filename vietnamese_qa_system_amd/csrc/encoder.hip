@@ -1620,6 +1620,9 @@ int launch_gemm_fold(const _Float16* A, const _Float16* W, const float* bias, co
                      const FoldArgs& fa, hipStream_t s) {
     int cu = 0;
     const int best = tile_choice(M, N, K, &cu);
+    // the 128 x 128 tile (64-deep K-steps: the packed N = 768 projections) runs the one-barrier K loop -- its two fragment sets fit
+    // beside 64 accumulators and the folded epilogue without spilling (VQA_GEMM_ONEBAR=0: the slot loop, dev / A-B switch)
+    static const bool onebar6 = !(getenv("VQA_GEMM_ONEBAR") && atoi(getenv("VQA_GEMM_ONEBAR")) == 0);
     switch (best) {
         case 0: return launch_tile<EPI, 256, 288, 4, 2, 32, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
         case 1: return launch_tile<EPI, 256, 192, 4, 2, 32, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
@@ -1627,7 +1630,9 @@ int launch_gemm_fold(const _Float16* A, const _Float16* W, const float* bias, co
         case 3: return launch_tile<EPI, 128, 192, 2, 4, 64, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
         case 4: return launch_tile<EPI, 256, 128, 4, 2, 32, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
         case 5: return launch_tile<EPI, 256, 256, 4, 2, 32, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
-        case 6: return launch_tile<EPI, 128, 128, 4, 2, 64, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
+        case 6:
+            if (onebar6) return launch_tile<EPI, 128, 128, 4, 2, 64, 1, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
+            return launch_tile<EPI, 128, 128, 4, 2, 64, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
         default: break;
     }
     if (best != -2) vqa_set_error("launch_gemm_fold: no tile shape for M=%d N=%d K=%d", M, N, K);
