@@ -32,7 +32,7 @@ python scripts/probes/blaslt_shapes.py 2>&1 | grep -v amdgpu > gpurun_out/${R}_b
   python scripts/gemm_bench.py --no-build --stamps --problems FFN2 --shapes=3
   python scripts/gemm_bench.py --no-build --stamps --problems FFN1 --shapes=7 --names start,mma1,reads,dma,mma2,lgkm,vmcnt,bar; } 2>&1 | grep -v amdgpu > gpurun_out/${R}_encoder_gemm_variants.txt
 tail -3 gpurun_out/${R}_encoder_gemm_variants.txt
-python scripts/ab_loops.py VQA_F16_LOOP=0 VQA_F16_LOOP=1 VQA_F16_LOOP=2 VQA_STAGE_MIN=0 2>&1 | grep -v amdgpu > gpurun_out/${R}_k1_loop_ab.txt
+python scripts/ab_loops.py VQA_SKETCH=1 VQA_SKETCH=0,VQA_F16_LOOP=0 VQA_SKETCH=0,VQA_F16_LOOP=1 VQA_SKETCH=0,VQA_F16_LOOP=2 VQA_SKETCH=0,VQA_STAGE_MIN=0 2>&1 | grep -v amdgpu > gpurun_out/${R}_k1_loop_ab.txt
 cat gpurun_out/${R}_k1_loop_ab.txt
 # the real N = 2 and N = 8 programs on ONE device (ranks share cuda:0 over gloo: HIP search + all-gather + HIP merge as one program)
 for N in 2 8; do
