@@ -77,6 +77,10 @@ struct vqa_index {
     unsigned* cand_cnt = nullptr;           // [256]
     int* sketch_flag = nullptr;             // 1 = a candidate buffer filled up: the exact fallback scan runs
     long long* stage_pos = nullptr;         // [256][max_k] row positions of the first stage's top-k
+    int* sketch_flag_host = nullptr;        // pinned mirror of sketch_flag, copied behind every sketch search (read by the NEXT call)
+    int sketch_cooldown = 0;                // searches left that skip the sketch: data the bound cannot prune would pay the sketch scan
+                                            // AND the exact fallback every time (VQA_SKETCH_COOLDOWN searches, default 64, then it tries again)
+    int sketch_cooldown_len = 64;
     // opt-in kernel timing (bench.py): event pairs around the main scoring kernel
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -124,6 +128,7 @@ extern "C" void vqa_index_destroy(vqa_index* ix) {
                     (void*)ix->regions, (void*)ix->region_cnt, (void*)ix->cand_keys, (void*)ix->cand_cnt, (void*)ix->sketch_flag,
                     (void*)ix->stage_pos})
         if (p) (void)hipFree(p);
+    if (ix->sketch_flag_host) (void)hipHostFree(ix->sketch_flag_host);
     if (ix->partial) (void)hipFree(ix->partial);
     if (ix->thr0) (void)hipFree(ix->thr0);
     if (ix->upper) (void)hipFree(ix->upper);
@@ -348,11 +353,14 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
                 hipMalloc((void**)&ix->region_cnt, (size_t)ix->max_grid * 4) != hipSuccess ||
                 hipMalloc((void**)&ix->cand_keys, (size_t)VQA_QUERY_TILE * kSketchCap * sizeof(vqa_key)) != hipSuccess ||
                 hipMalloc((void**)&ix->cand_cnt, VQA_QUERY_TILE * 4) != hipSuccess || hipMalloc((void**)&ix->sketch_flag, 4) != hipSuccess ||
-                hipMalloc((void**)&ix->stage_pos, (size_t)VQA_QUERY_TILE * max_k * 8) != hipSuccess) {
+                hipMalloc((void**)&ix->stage_pos, (size_t)VQA_QUERY_TILE * max_k * 8) != hipSuccess ||
+                hipHostMalloc((void**)&ix->sketch_flag_host, sizeof(int), hipHostMallocDefault) != hipSuccess) {
                 vqa_set_error("vqa_index_create: allocating the int8 sketch (%zu bytes) failed", ix->rows8_bytes);
                 rc = VQA_ENOMEM;
                 break;
             }
+            *ix->sketch_flag_host = 0;
+            if (const char* cd = getenv("VQA_SKETCH_COOLDOWN")) ix->sketch_cooldown_len = atoi(cd) > 0 ? atoi(cd) : 0;
             if (hipMemset(ix->rows8, 0, ix->rows8_bytes) != hipSuccess || hipMemset(ix->tile_info, 0, (size_t)tiles * 16) != hipSuccess ||
                 hipMemset(ix->q8_stage, 0, (size_t)VQA_QUERY_TILE * ix->d_pad8) != hipSuccess) {
                 vqa_set_error("vqa_index_create: clearing the int8 sketch failed");
@@ -558,7 +566,17 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
         int rc = vqa_launch_tile_rows(reinterpret_cast<const char*>(q) + (size_t)q0 * ix->d * qeb, q_dtype, 0, VQA_QUERY_TILE, nq,
                                       ix->d, ix->d_pad, ix->dtype, ix->scale, ix->q_stage, stream);
         if (rc != VQA_OK) return rc;
-        const bool use_sketch = sketch_active(ix, p, k);
+        // An earlier sketch search of this handle that overflowed into its exact fallback (its flag arrives in the pinned mirror
+        // some time after that call; a stale read only delays the reaction by a search) switches the sketch off for a while
+        if (ix->sketch && q0 == 0) {
+            if (__atomic_load_n(ix->sketch_flag_host, __ATOMIC_RELAXED) != 0) {
+                __atomic_store_n(ix->sketch_flag_host, 0, __ATOMIC_RELAXED);
+                ix->sketch_cooldown = ix->sketch_cooldown_len;
+            } else if (ix->sketch_cooldown > 0) {
+                --ix->sketch_cooldown;
+            }
+        }
+        const bool use_sketch = sketch_active(ix, p, k) && ix->sketch_cooldown == 0;
         if (use_sketch) {  // the query tile's int8 sketch (every query its own scale) + ||q_lo||, ||q||
             rc = vqa_launch_sketch_rows(ix->q_stage, ix->dtype, 0, VQA_QUERY_TILE, ix->d_pad, ix->d_pad8, nullptr, ix->q8_stage, ix->qrow,
                                         ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, stream);
@@ -703,6 +721,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
                                                    nullptr, true, nullptr, stream, 1, ix->cand_cnt);
                     if (rc != VQA_OK) return rc;
                     a.gate = ix->sketch_flag;  // the exact main launch + merge below: only when the flag is up
+                    VQA_HIP_CHECK(hipMemcpyAsync(ix->sketch_flag_host, ix->sketch_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
                 }
             }
             const bool time_it = ix->timing && !(staged && use_sketch);  // a sketch search times its sketch scan instead
