@@ -37,7 +37,18 @@ g = torch.Generator(device=dev); g.manual_seed(0)
 M = args.m
 PROBLEMS = {"QKV": (M, 2304, 768, 0), "out": (M, 768, 768, 2), "FFN1": (M, 3072, 768, 1), "FFN2": (M, 768, 3072, 2)}
 SHAPES = {-1: "auto", 0: "256x288/32", 1: "256x192/32", 2: "256x128/64", 3: "128x192/64", 4: "256x128/32", 5: "256x256/32", 6: "128x128/64",
-          7: "256x192/32 1bar", 8: "256x256/32 1bar", 9: "256x128/64 1bar", 10: "128x192/64 1bar", 11: "128x128/64 1bar"}
+          7: "256x192/32 1bar", 8: "256x256/32 1bar", 9: "256x128/64 1bar", 10: "128x192/64 1bar", 11: "128x128/64 1bar",
+          12: "256x288/32 tiled", 13: "256x192/32 tiled", 14: "256x128/64 tiled", 15: "128x192/64 tiled", 16: "256x256/32 tiled",
+          17: "128x128/64 1bar tiled"}
+
+
+def tiled(t):
+    """[rows, k] fp16 -> the tiled operand layout: 256-row tiles x 64-byte K-blocks (rows padded to 256)"""
+    rows, k = t.shape
+    rp = (rows + 255) // 256 * 256
+    p = torch.zeros((rp, k), device=t.device, dtype=t.dtype)
+    p[:rows] = t
+    return p.view(rp // 256, 256, k // 32, 32).permute(0, 2, 1, 3).contiguous()
 stream = torch.cuda.current_stream().cuda_stream
 for name in args.problems.split(","):
     m, n, k, epi = PROBLEMS[name]
@@ -54,12 +65,14 @@ for name in args.problems.split(","):
         ref = torch.nn.functional.gelu(ref)
     if epi == 2:
         ref = ref + r[:m].float()
+    at, wt = tiled(a), tiled(w)
+    ops = lambda sh: (at.data_ptr(), wt.data_ptr()) if sh >= 12 else (a.data_ptr(), w.data_ptr())
     for _ in range(5):
         torch.mm(a[:m], w.t())
     times = {}
     for sh in [int(x) for x in args.shapes.split(",")]:
         c.zero_()
-        rc = lib.vqa_dev_gemm(a.data_ptr(), w.data_ptr(), bias.data_ptr(), r.data_ptr(), c.data_ptr(), m, n, k, epi, sh, stream)
+        rc = lib.vqa_dev_gemm(*ops(sh), bias.data_ptr(), r.data_ptr(), c.data_ptr(), m, n, k, epi, sh, stream)
         if rc != 0:
             print(f"{name} shape {SHAPES.get(sh, sh)}: rc {rc} {lib.vqa_last_error().decode()}")
             continue
@@ -75,7 +88,7 @@ for name in args.problems.split(","):
                 if sh == "mm":
                     torch.mm(a[:m], w.t())
                 else:
-                    lib.vqa_dev_gemm(a.data_ptr(), w.data_ptr(), bias.data_ptr(), r.data_ptr(), c.data_ptr(), m, n, k, epi, sh, stream)
+                    lib.vqa_dev_gemm(*ops(sh), bias.data_ptr(), r.data_ptr(), c.data_ptr(), m, n, k, epi, sh, stream)
             e1.record()
             torch.cuda.synchronize()
             times[sh][1].append(e0.elapsed_time(e1) / args.reps * 1e3)

@@ -60,6 +60,58 @@ def test_sketch_search_equals_the_exact_scan(native_lib, monkeypatch, n, d, b, k
     assert p1[0, :nd].tolist() == dup[:nd] and len(set(s1[0, :nd].tolist())) == 1  # bit-equal scores, position order
 
 
+@pytest.mark.parametrize("n,d,b,k", [(300_001, 64, 41, 30), (200_000, 128, 256, 13), (180_000, 768, 32, 32)])
+def test_wide_sketch_search_equals_the_exact_scan(native_lib, monkeypatch, n, d, b, k):
+    """12 < k <= 32 (the dense leg of a hybrid search asks for 10 x limit rows): theta = the k-th largest key of the first
+    stage's 12-deep workgroup lists, the sketch scan covers EVERY row, survivors are scored exactly.  Same rows as the exact
+    large-k path, duplicates (inside the first stage, astride its end, in the last tile) bit-equal in position order."""
+    rng = np.random.default_rng(n + d + k)
+    x, q = _unit(rng, n, d), _unit(rng, b, d)
+    dup = [3, 40_000, 65_535, 65_536, n - 1]
+    for r in dup[1:]:
+        x[r] = x[dup[0]]
+    q[0] = x[dup[0]]
+    ids = np.arange(n, dtype=np.int64) * 3 + 1
+    ref = _index(x, monkeypatch, sketch=False, ids=ids)
+    ske = _index(x, monkeypatch, sketch=True, ids=ids)
+    li = ske.launch_info(b, k)
+    assert ref.launch_info(b, k).sketch_scan == 0 and li.sketch_scan == 1 and ske.launch_info(b, 33).sketch_scan == 0
+    assert li.rows_per_launch == n and li.bytes_per_launch == n * d and li.first_stage_rows == 256 * 256
+    s0, i0, p0 = _search(ref, q, k)
+    s1, i1, p1 = _search(ske, q, k)
+    s2, _, p2 = _search(ske, q, k)
+    s3, _, p3 = _search(ske, q, 10)  # the narrow form on the same handle, then the wide one again
+    s4, _, p4 = _search(ske, q, k)
+    ref.close()
+    ske.close()
+    assert np.array_equal(p1, p2) and np.array_equal(s1, s2) and np.array_equal(p1, p4) and np.array_equal(s1, s4)
+    assert np.array_equal(p3, p1[:, :10]) and np.array_equal(s3, s1[:, :10])
+    s_full = R.full_scores(q.astype(np.float32), x, R.DTYPE_F16)
+    R.check_topk(s1, p1, s_full, k, score_tol=SCORE_TOL, tie_tol=TIE_TOL)
+    assert np.array_equal(p1, p0), "the wide sketch search returns other rows than the exact scan"
+    assert np.array_equal(i1, ids[p1]) and np.abs(s1 - s0).max() <= 3e-7
+    assert p1[0, :5].tolist() == dup and len(set(s1[0, :5].tolist())) == 1
+
+
+def test_wide_sketch_overflow_takes_the_exact_passes(native_lib, monkeypatch):
+    """k = 30 on rows the bound cannot prune: the gated exact passes (three of them) overwrite the result -- the exact path's bits."""
+    n, d, b, k = 200_000, 64, 24, 30
+    rng = np.random.default_rng(2)
+    v = _unit(rng, 1, d)
+    x = np.repeat(v, n, axis=0)
+    x[5] = _unit(rng, 1, d)[0]
+    q = np.repeat(v, b, axis=0)
+    monkeypatch.setenv("VQA_WIDE_K", "0")  # the reference handle: plain exact passes
+    ref = _index(x, monkeypatch, sketch=False)
+    ske = _index(x, monkeypatch, sketch=True)
+    s0, _, p0 = _search(ref, q, k)
+    s1, _, p1 = _search(ske, q, k)
+    ref.close()
+    ske.close()
+    assert np.array_equal(p1, p0) and np.array_equal(s1, s0)
+    assert p1[0].tolist() == [r for r in range(k + 1) if r != 5]  # ties by position
+
+
 def test_rows_the_bound_cannot_prune_take_the_exact_fallback(native_lib, monkeypatch):
     """Every row equal to every query: each (query, row) pair is a candidate, the scan's regions fill up, the overflow flag
     sends the search through the exact main launch (gated on the flag, no host round trip) -- same bits as the exact scan."""

@@ -476,9 +476,13 @@ static LaunchPlan plan_launch(const vqa_index* ix, int k = 0) {
     return p;
 }
 
-// the sketch path serves exactly the searches the two-stage plan serves (one exact pass, k <= 12, a large shard)
+// The sketch path serves the searches the two-stage plan serves (one exact pass, k <= 12, a large shard) and, in its wide form,
+// k up to kSketchWideMaxK on the same shards (txtai's hybrid search asks the dense index for 10 x limit rows: 30 at its default
+// limit): there the candidates of a query number ~2300 at k = 30 against ~860 at k = 10 and the exact re-scoring (random 64-byte
+// pieces of the tiled index) grows with them -- past 32 the one-pass exact scan is as fast.
+constexpr int kSketchWideMaxK = 32;
 static bool sketch_active(const vqa_index* ix, const LaunchPlan& p, int k) {
-    return ix->sketch && p.stage_tiles > 0 && p.grid0 > 0 && k <= vqa_score_topk_max_k(ix->dtype);
+    return ix->sketch && p.stage_tiles > 0 && p.grid0 > 0 && k <= kSketchWideMaxK;
 }
 
 extern "C" int vqa_index_launch_info(const vqa_index* ix, int32_t B, int32_t k, vqa_launch_info* out) {
@@ -489,9 +493,10 @@ extern "C" int vqa_index_launch_info(const vqa_index* ix, int32_t B, int32_t k, 
     out->block = 512;
     out->lds_bytes = vqa_score_topk_lds_bytes(ix->dtype, k);
     out->rows_per_tile = 256;
-    out->first_stage_rows = k <= vqa_score_topk_max_k(ix->dtype) ? (int64_t)p.stage_tiles * 256 : 0;
-    out->rows_per_launch = ix->n - out->first_stage_rows;
     out->sketch_scan = sketch_active(ix, p, k) ? 1 : 0;
+    const bool wide_sketch = out->sketch_scan && k > vqa_score_topk_max_k(ix->dtype);  // its sketch scan covers every row
+    out->first_stage_rows = (k <= vqa_score_topk_max_k(ix->dtype) || wide_sketch) ? (int64_t)p.stage_tiles * 256 : 0;
+    out->rows_per_launch = wide_sketch ? ix->n : ix->n - out->first_stage_rows;
     out->pad_ = 0;
     out->bytes_per_launch = out->rows_per_launch * (int64_t)ix->d * (out->sketch_scan ? 1 : elem_bytes(ix->dtype));
     out->flops_per_launch = 2 * (int64_t)VQA_QUERY_TILE * out->rows_per_launch * (int64_t)ix->d;
@@ -576,8 +581,9 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
                 --ix->sketch_cooldown;
             }
         }
-        const bool use_sketch = sketch_active(ix, p, k) && ix->sketch_cooldown == 0;
-        if (use_sketch) {  // the query tile's int8 sketch (every query its own scale) + ||q_lo||, ||q||
+        const bool any_sketch = sketch_active(ix, p, k) && ix->sketch_cooldown == 0;
+        const bool use_sketch = any_sketch && k <= max_k, use_sketch_wide = any_sketch && k > max_k;
+        if (any_sketch) {  // the query tile's int8 sketch (every query its own scale) + ||q_lo||, ||q||
             rc = vqa_launch_sketch_rows(ix->q_stage, ix->dtype, 0, VQA_QUERY_TILE, ix->d_pad, ix->d_pad8, nullptr, ix->q8_stage, ix->qrow,
                                         ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, stream);
             if (rc != VQA_OK) return rc;
@@ -589,7 +595,80 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
         // the device and raises wide_flag.  The exact continuation passes below are then launched GATED on the flag: they
         // return at once when the one-pass result stands (no host round trip), and overwrite it when it does not.
         const int* gate = nullptr;
-        if (k > max_k && ix->wide && k <= 3 * p.grid1 && p.seed_tiles > 0) {
+        if (use_sketch_wide) {
+            // 12 < k <= 32 on a sketch shard.  theta = the k-th largest of ANY k distinct exact scores is a valid lower bound of
+            // the k-th best: seeds -> a first-stage launch over stage_tiles tiles in which every workgroup keeps its best 12 above
+            // the seeds' threshold -> the k-th largest key of the union of those lists (-inf when they hold fewer than k: the
+            // sketch scan then overflows into the fallback).  The sketch scan covers EVERY tile (the first stage's too: nothing
+            // needs to be known about which of its rows the 12-deep lists dropped), its candidates are scored exactly and the k
+            // best of each query's list are the result.  An overflow raises sketch_flag: the exact passes below run gated on it.
+            ScoreTopkArgs a;
+            a.x = ix->rows;
+            a.q = ix->q_stage;
+            a.n = ix->n;
+            a.d_pad = ix->d_pad;
+            a.nq = nq;
+            a.k = max_k;
+            a.upper = nullptr;
+            a.loop = ix->f16_loop == 1 ? 1 : 0;
+            a.thr_init = nullptr;
+            a.partial = ix->partial;
+            a.tile_begin = 0;
+            a.tile_end = p.seed_tiles;
+            a.grid = p.grid0;
+            a.seed_only = true;
+            a.seeds_per_tile = p.seeds_per_tile;
+            rc = vqa_launch_score_topk(ix->dtype, a, stream);
+            if (rc != VQA_OK) return rc;
+            rc = vqa_launch_merge_partials(ix->partial, p.seed_tiles, p.seeds_per_tile, nq, k, nullptr, 0, nullptr, nullptr, nullptr,
+                                           ix->thr0, 1.0f, k, 0, nullptr, true, nullptr, stream);
+            if (rc != VQA_OK) return rc;
+            a.thr_init = ix->thr0;
+            a.tile_end = p.stage_tiles;
+            a.grid = p.grid1;
+            a.seed_only = false;
+            a.first_stage = true;
+            rc = vqa_launch_score_topk(ix->dtype, a, stream);
+            if (rc != VQA_OK) return rc;
+            rc = vqa_launch_merge_partials(ix->partial, p.grid1, max_k, nq, k, nullptr, 0, nullptr, nullptr, nullptr, ix->thr0, 1.0f, k, 0,
+                                           nullptr, true, nullptr, stream);
+            if (rc != VQA_OK) return rc;
+            rc = vqa_launch_sketch_qconst(ix->thr0, ix->qrow, ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, ix->d_pad, ix->qconst,
+                                          ix->cand_cnt, ix->sketch_flag, stream);
+            if (rc != VQA_OK) return rc;
+            SketchScanArgs sk;
+            sk.tile_info = reinterpret_cast<const float4*>(ix->tile_info);
+            sk.qconst = ix->qconst;
+            sk.regions = ix->regions;
+            sk.counts = ix->region_cnt;
+            sk.overflow = ix->sketch_flag;
+            sk.cap = kSketchCap;
+            ScoreTopkArgs b;
+            b.x = ix->rows8;
+            b.q = ix->q8_stage;
+            b.n = ix->n;
+            b.d_pad = ix->d_pad8;
+            b.nq = nq;
+            b.k = max_k;
+            b.thr_init = nullptr;
+            b.partial = nullptr;
+            b.tile_begin = 0;
+            b.tile_end = p.tiles;
+            b.grid = p.grid1;
+            b.sketch = &sk;
+            if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
+            rc = vqa_launch_score_topk(VQA_I8_SKETCH, b, stream);
+            if (rc != VQA_OK) return rc;
+            if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
+            rc = vqa_launch_rescore(ix->regions, ix->region_cnt, kSketchCap, p.grid1, nullptr, nq, 0, ix->rows, ix->q_stage, ix->dtype,
+                                    ix->d_pad, ix->cand_keys, ix->cand_cnt, kSketchCap, ix->sketch_flag, stream);
+            if (rc != VQA_OK) return rc;
+            rc = vqa_launch_merge_partials(ix->cand_keys, 1, kSketchCap, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr, 1.0f, k, 0, nullptr,
+                                           true, nullptr, stream, 1, ix->cand_cnt);
+            if (rc != VQA_OK) return rc;
+            VQA_HIP_CHECK(hipMemcpyAsync(ix->sketch_flag_host, ix->sketch_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+            gate = ix->sketch_flag;
+        } else if (k > max_k && ix->wide && k <= 3 * p.grid1 && p.seed_tiles > 0) {
             ScoreTopkArgs a;
             a.x = ix->rows;
             a.q = ix->q_stage;
@@ -724,7 +803,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
                     VQA_HIP_CHECK(hipMemcpyAsync(ix->sketch_flag_host, ix->sketch_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
                 }
             }
-            const bool time_it = ix->timing && !(staged && use_sketch);  // a sketch search times its sketch scan instead
+            const bool time_it = ix->timing && !(staged && use_sketch) && !use_sketch_wide;  // a sketch search times its sketch scan instead
             if (time_it && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
             rc = vqa_launch_score_topk(ix->dtype, a, stream);
             if (rc != VQA_OK) return rc;

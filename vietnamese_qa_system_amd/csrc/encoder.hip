@@ -516,7 +516,7 @@ __device__ unsigned long long g_gstamps[8 * 64 * kGStampSlots];
 #define VQA_GSTAMP_FLUSH(KT) (void)0
 #endif
 
-template <int EPI, int BM, int BN, int WM, int WN, int BK, int FOLD = 0, int ONEBAR = 0>
+template <int EPI, int BM, int BN, int WM, int WN, int BK, int FOLD = 0, int ONEBAR = 0, int TIL = 0>
 __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                                                         const float* __restrict__ bias, const _Float16* __restrict__ R,
                                                         _Float16* __restrict__ C, int M, int N, int K, int tiles_n,
@@ -561,7 +561,11 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
     // 64-byte rows, row & 7 for 128-byte rows (both conflict-free for ds_read_b128)
     const size_t row_bytes = (size_t)K * 2;
     const int prow = lane / SP, pslot = lane % SP;
-    const uint32_t voff = (uint32_t)(prow * row_bytes + ((pslot ^ (BK == 32 ? 3 * ((prow >> 3) & 1) : (prow & 7))) << 4));
+    const int lslot = pslot ^ (BK == 32 ? 3 * ((prow >> 3) & 1) : (prow & 7));
+    // TIL: both operands in the TILED layout (256-row tiles x 64-byte K-blocks, 16 KiB blocks: kActBlock) -- a piece is 1 KiB
+    // (32-deep K-steps) or two 512-byte runs (64-deep) of whole 128-byte lines instead of 16 half lines
+    const uint32_t voff = TIL ? (uint32_t)(prow * 64 + (lslot >> 2) * 16384 + ((lslot & 3) << 4)) : (uint32_t)(prow * row_bytes + (lslot << 4));
+    const size_t kadv = TIL ? (size_t)(BK / 32) * 16384 : (size_t)kTileRowB;
     // this wave's pieces of every K-step: the contiguous range [p0, p0 + n_mine) (NJ or NJ - 1 of them), so that their LDS
     // destinations are 1 KiB apart and one M0 write serves them all (tile_dma_pieces)
     const int p0 = G::kPieces * wave / 8;
@@ -577,6 +581,11 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int p = p0 + j < G::kPieces ? p0 + j : G::kPieces - 1;
+                if constexpr (TIL) {
+                    const size_t row0 = p < PA ? bm + PR * p : bn + PR * (p - PA);
+                    src[j] = reinterpret_cast<const char*>(p < PA ? A : W) + (row0 >> 8) * (size_t)(K / 32) * 16384 + (row0 & 255) * 64 -
+                             1024 * (j & 3);
+                } else
                 src[j] = (p < PA ? reinterpret_cast<const char*>(A) + (bm + PR * p) * row_bytes
                                  : reinterpret_cast<const char*>(W) + (bn + PR * (p - PA)) * row_bytes) - 1024 * (j & 3);
             }
@@ -584,7 +593,7 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
         const uint32_t dst = lds_base + is_stage * G::kStageB + p0 * 1024;
         const char* at[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) at[j] = src[j] + (size_t)is_kt * kTileRowB;
+        for (int j = 0; j < NJ; ++j) at[j] = src[j] + (size_t)is_kt * kadv;
         if (n_mine == NJ) tile_dma_pieces<NJ, NJ>(at, voff, dst);
         else if constexpr (NJ > 1) tile_dma_pieces<NJ - 1, NJ>(at, voff, dst);
         ++is_n;
@@ -1519,13 +1528,13 @@ int upload_folded(const float* src, int N, int K, const float* gamma, const floa
 
 constexpr int kTokenPad = 256;  // activation buffers are padded to this many rows (the tallest tile)
 
-template <int EPI, int BM, int BN, int WM, int WN, int BK, int FOLD = 0, int ONEBAR = 0>
+template <int EPI, int BM, int BN, int WM, int WN, int BK, int FOLD = 0, int ONEBAR = 0, int TIL = 0>
 int launch_tile(const _Float16* A, const _Float16* W, const float* bias, const _Float16* R, _Float16* C, int M, int N, int K,
                 int num_cu, hipStream_t s, const FoldArgs& fa = FoldArgs{}) {
     using G = TileGeom<BM, BN, BK>;
     static VqaPerDeviceOnce once;
     int rc = once.run([&](int) -> int {
-        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<EPI, BM, BN, WM, WN, BK, FOLD, ONEBAR>),
+        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<EPI, BM, BN, WM, WN, BK, FOLD, ONEBAR, TIL>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::kLds));
         return VQA_OK;
     });
@@ -1543,7 +1552,7 @@ int launch_tile(const _Float16* A, const _Float16* W, const float* bias, const _
         if (nb_force >= 0 && (nb_force == 0 || (tiles_n % nb_force == 0 && per % nb_force == 0 && rows % (per / nb_force) == 0)))
             nb = nb_force;
     }
-    hipLaunchKernelGGL((gemm_tile_kernel<EPI, BM, BN, WM, WN, BK, FOLD, ONEBAR>), dim3(grid), dim3(512), G::kLds, s, A, W, bias, R, C, M, N,
+    hipLaunchKernelGGL((gemm_tile_kernel<EPI, BM, BN, WM, WN, BK, FOLD, ONEBAR, TIL>), dim3(grid), dim3(512), G::kLds, s, A, W, bias, R, C, M, N,
                        K, tiles_n, tiles, nb, fa);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
@@ -1711,6 +1720,12 @@ extern "C" int vqa_dev_gemm(const void* A, const void* W, const float* bias, con
         case 9: return launch_tile<E, 256, 128, 4, 2, 64, 0, 1>(a, w, bias, r, c, M, N, K, cu, s);      \
         case 10: return launch_tile<E, 128, 192, 2, 4, 64, 0, 1>(a, w, bias, r, c, M, N, K, cu, s);     \
         case 11: return launch_tile<E, 128, 128, 4, 2, 64, 0, 1>(a, w, bias, r, c, M, N, K, cu, s);     \
+        case 12: return launch_tile<E, 256, 288, 4, 2, 32, 0, 0, 1>(a, w, bias, r, c, M, N, K, cu, s);  \
+        case 13: return launch_tile<E, 256, 192, 4, 2, 32, 0, 0, 1>(a, w, bias, r, c, M, N, K, cu, s);  \
+        case 14: return launch_tile<E, 256, 128, 4, 2, 64, 0, 0, 1>(a, w, bias, r, c, M, N, K, cu, s);  \
+        case 15: return launch_tile<E, 128, 192, 2, 4, 64, 0, 0, 1>(a, w, bias, r, c, M, N, K, cu, s);  \
+        case 16: return launch_tile<E, 256, 256, 4, 2, 32, 0, 0, 1>(a, w, bias, r, c, M, N, K, cu, s);  \
+        case 17: return launch_tile<E, 128, 128, 4, 2, 64, 0, 1, 1>(a, w, bias, r, c, M, N, K, cu, s);  \
         default: return launch_gemm<E>(a, w, bias, r, c, M, N, K, s);                                   \
     }
     if (epi == 0) { VQA_DEV_SHAPE(0) }
