@@ -538,6 +538,77 @@ static int timing_event(vqa_index* ix, hipStream_t stream) {
     return VQA_OK;
 }
 
+// arguments every exact launch of a search shares (the caller sets k, the tile range, the grid and the list layout)
+static ScoreTopkArgs exact_launch_args(const vqa_index* ix, int nq, int k) {
+    ScoreTopkArgs a;
+    a.x = ix->rows;
+    a.q = ix->q_stage;
+    a.n = ix->n;
+    a.d_pad = ix->d_pad;
+    a.nq = nq;
+    a.k = k;
+    a.loop = ix->f16_loop == 1 ? 1 : 0;
+    a.partial = ix->partial;
+    return a;
+}
+
+// Seed pass: the plan's first seed_tiles tiles scored by the MODE 0 kernel (sub-maxima per query and tile) and the `rank`-th
+// largest of them per query -> ix->thr0, the starting threshold of the launches behind it (`a` carries upper / gate)
+static int seed_pass(vqa_index* ix, const LaunchPlan& p, ScoreTopkArgs a, int rank, const int* gate, hipStream_t stream) {
+    a.thr_init = nullptr;
+    a.tile_begin = 0;
+    a.tile_end = p.seed_tiles;
+    a.grid = p.grid0;
+    a.seed_only = true;
+    a.seeds_per_tile = p.seeds_per_tile;
+    int rc = vqa_launch_score_topk(ix->dtype, a, stream);
+    if (rc != VQA_OK) return rc;
+    return vqa_launch_merge_partials(ix->partial, p.seed_tiles, p.seeds_per_tile, a.nq, rank, nullptr, 0, nullptr, nullptr, nullptr, ix->thr0,
+                                     1.0f, rank, 0, nullptr, true, gate, stream);
+}
+
+// The tail both sketch forms share: theta (ix->thr0) -> per-query constants -> the int8 scan of tiles [tile_begin, tiles) ->
+// exact scores of its candidate pairs (and of `stage_k` first-stage rows per query, ix->stage_pos) -> the k best of every query's
+// list -> the overflow flag to its pinned mirror.  The caller enqueues its exact fallback behind, gated on ix->sketch_flag.
+static int sketch_scan_and_select(vqa_index* ix, const LaunchPlan& p, int tile_begin, int nq, int k, int stage_k, float* os, int64_t* oi,
+                                  int64_t* op, hipStream_t stream) {
+    int rc = vqa_launch_sketch_qconst(ix->thr0, ix->qrow, ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, ix->d_pad, ix->qconst,
+                                      ix->cand_cnt, ix->sketch_flag, stream);
+    if (rc != VQA_OK) return rc;
+    SketchScanArgs sk;
+    sk.tile_info = reinterpret_cast<const float4*>(ix->tile_info);
+    sk.qconst = ix->qconst;
+    sk.regions = ix->regions;
+    sk.counts = ix->region_cnt;
+    sk.overflow = ix->sketch_flag;
+    sk.cap = kSketchCap;
+    ScoreTopkArgs b;
+    b.x = ix->rows8;
+    b.q = ix->q8_stage;
+    b.n = ix->n;
+    b.d_pad = ix->d_pad8;
+    b.nq = nq;
+    b.k = vqa_score_topk_max_k(ix->dtype);
+    b.thr_init = nullptr;
+    b.partial = nullptr;
+    b.tile_begin = tile_begin;
+    b.tile_end = p.tiles;
+    b.grid = p.grid1;
+    b.sketch = &sk;
+    if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
+    rc = vqa_launch_score_topk(VQA_I8_SKETCH, b, stream);
+    if (rc != VQA_OK) return rc;
+    if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
+    rc = vqa_launch_rescore(ix->regions, ix->region_cnt, kSketchCap, p.grid1, stage_k > 0 ? ix->stage_pos : nullptr, nq, stage_k, ix->rows,
+                            ix->q_stage, ix->dtype, ix->d_pad, ix->cand_keys, ix->cand_cnt, kSketchCap, ix->sketch_flag, stream);
+    if (rc != VQA_OK) return rc;
+    rc = vqa_launch_merge_partials(ix->cand_keys, 1, kSketchCap, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr, 1.0f, k, 0, nullptr, true,
+                                   nullptr, stream, 1, ix->cand_cnt);
+    if (rc != VQA_OK) return rc;
+    VQA_HIP_CHECK(hipMemcpyAsync(ix->sketch_flag_host, ix->sketch_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+    return VQA_OK;
+}
+
 extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, int32_t B, int32_t k, float* out_scores,
                                 int64_t* out_ids, int64_t* out_pos_or_null, void* hip_stream) {
     VQA_REQUIRE(ix, "vqa_index_search: index is null");
@@ -602,28 +673,11 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             // sketch scan then overflows into the fallback).  The sketch scan covers EVERY tile (the first stage's too: nothing
             // needs to be known about which of its rows the 12-deep lists dropped), its candidates are scored exactly and the k
             // best of each query's list are the result.  An overflow raises sketch_flag: the exact passes below run gated on it.
-            ScoreTopkArgs a;
-            a.x = ix->rows;
-            a.q = ix->q_stage;
-            a.n = ix->n;
-            a.d_pad = ix->d_pad;
-            a.nq = nq;
-            a.k = max_k;
-            a.upper = nullptr;
-            a.loop = ix->f16_loop == 1 ? 1 : 0;
-            a.thr_init = nullptr;
-            a.partial = ix->partial;
-            a.tile_begin = 0;
-            a.tile_end = p.seed_tiles;
-            a.grid = p.grid0;
-            a.seed_only = true;
-            a.seeds_per_tile = p.seeds_per_tile;
-            rc = vqa_launch_score_topk(ix->dtype, a, stream);
-            if (rc != VQA_OK) return rc;
-            rc = vqa_launch_merge_partials(ix->partial, p.seed_tiles, p.seeds_per_tile, nq, k, nullptr, 0, nullptr, nullptr, nullptr,
-                                           ix->thr0, 1.0f, k, 0, nullptr, true, nullptr, stream);
+            ScoreTopkArgs a = exact_launch_args(ix, nq, max_k);
+            rc = seed_pass(ix, p, a, k, nullptr, stream);
             if (rc != VQA_OK) return rc;
             a.thr_init = ix->thr0;
+            a.tile_begin = 0;
             a.tile_end = p.stage_tiles;
             a.grid = p.grid1;
             a.seed_only = false;
@@ -633,65 +687,16 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             rc = vqa_launch_merge_partials(ix->partial, p.grid1, max_k, nq, k, nullptr, 0, nullptr, nullptr, nullptr, ix->thr0, 1.0f, k, 0,
                                            nullptr, true, nullptr, stream);
             if (rc != VQA_OK) return rc;
-            rc = vqa_launch_sketch_qconst(ix->thr0, ix->qrow, ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, ix->d_pad, ix->qconst,
-                                          ix->cand_cnt, ix->sketch_flag, stream);
+            rc = sketch_scan_and_select(ix, p, 0, nq, k, 0, os, oi, op, stream);
             if (rc != VQA_OK) return rc;
-            SketchScanArgs sk;
-            sk.tile_info = reinterpret_cast<const float4*>(ix->tile_info);
-            sk.qconst = ix->qconst;
-            sk.regions = ix->regions;
-            sk.counts = ix->region_cnt;
-            sk.overflow = ix->sketch_flag;
-            sk.cap = kSketchCap;
-            ScoreTopkArgs b;
-            b.x = ix->rows8;
-            b.q = ix->q8_stage;
-            b.n = ix->n;
-            b.d_pad = ix->d_pad8;
-            b.nq = nq;
-            b.k = max_k;
-            b.thr_init = nullptr;
-            b.partial = nullptr;
-            b.tile_begin = 0;
-            b.tile_end = p.tiles;
-            b.grid = p.grid1;
-            b.sketch = &sk;
-            if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
-            rc = vqa_launch_score_topk(VQA_I8_SKETCH, b, stream);
-            if (rc != VQA_OK) return rc;
-            if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
-            rc = vqa_launch_rescore(ix->regions, ix->region_cnt, kSketchCap, p.grid1, nullptr, nq, 0, ix->rows, ix->q_stage, ix->dtype,
-                                    ix->d_pad, ix->cand_keys, ix->cand_cnt, kSketchCap, ix->sketch_flag, stream);
-            if (rc != VQA_OK) return rc;
-            rc = vqa_launch_merge_partials(ix->cand_keys, 1, kSketchCap, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr, 1.0f, k, 0, nullptr,
-                                           true, nullptr, stream, 1, ix->cand_cnt);
-            if (rc != VQA_OK) return rc;
-            VQA_HIP_CHECK(hipMemcpyAsync(ix->sketch_flag_host, ix->sketch_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
             gate = ix->sketch_flag;
         } else if (k > max_k && ix->wide && k <= 3 * p.grid1 && p.seed_tiles > 0) {
-            ScoreTopkArgs a;
-            a.x = ix->rows;
-            a.q = ix->q_stage;
-            a.n = ix->n;
-            a.d_pad = ix->d_pad;
-            a.nq = nq;
-            a.k = max_k;
-            a.upper = nullptr;
-            a.loop = ix->f16_loop == 1 ? 1 : 0;
-            a.thr_init = nullptr;
-            a.partial = ix->partial;
-            a.tile_begin = 0;
-            a.tile_end = p.seed_tiles;
-            a.grid = p.grid0;
-            a.seed_only = true;
-            a.seeds_per_tile = p.seeds_per_tile;
+            ScoreTopkArgs a = exact_launch_args(ix, nq, max_k);
             VQA_HIP_CHECK(hipMemsetAsync(ix->wide_flag, 0, sizeof(int), stream));
-            rc = vqa_launch_score_topk(ix->dtype, a, stream);
-            if (rc != VQA_OK) return rc;
-            rc = vqa_launch_merge_partials(ix->partial, p.seed_tiles, p.seeds_per_tile, nq, k, nullptr, 0, nullptr,
-                                           nullptr, nullptr, ix->thr0, 1.0f, k, 0, nullptr, true, nullptr, stream);
+            rc = seed_pass(ix, p, a, k, nullptr, stream);
             if (rc != VQA_OK) return rc;
             a.thr_init = ix->thr0;
+            a.tile_begin = 0;
             a.tile_end = p.tiles;
             a.grid = p.grid1;
             a.seed_only = false;
@@ -709,32 +714,11 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
         for (int done = 0; done < k; done += max_k) {
             const int kk = k - done < max_k ? k - done : max_k;
             const vqa_key* upper = done > 0 ? ix->upper : nullptr;
-            ScoreTopkArgs a;
-            a.x = ix->rows;
-            a.q = ix->q_stage;
-            a.n = ix->n;
-            a.d_pad = ix->d_pad;
-            a.nq = nq;
-            a.k = kk;
+            ScoreTopkArgs a = exact_launch_args(ix, nq, kk);
             a.upper = upper;
             a.gate = gate;
-            a.loop = ix->f16_loop == 1 ? 1 : 0;
-            if (p.grid0 > 0) {
-                a.thr_init = nullptr;
-                a.partial = ix->partial;
-                a.tile_begin = 0;
-                a.tile_end = p.seed_tiles;
-                a.grid = p.grid0;
-                a.seed_only = true;
-                a.seeds_per_tile = p.seeds_per_tile;
-                rc = vqa_launch_score_topk(ix->dtype, a, stream);
-                if (rc != VQA_OK) return rc;
-                rc = vqa_launch_merge_partials(ix->partial, p.seed_tiles, p.seeds_per_tile, nq, kk, nullptr, 0, nullptr,
-                                               nullptr, nullptr, ix->thr0, 1.0f, kk, 0, nullptr, true, gate, stream);
-                if (rc != VQA_OK) return rc;
-            }
+            if (p.grid0 > 0 && (rc = seed_pass(ix, p, a, kk, gate, stream)) != VQA_OK) return rc;
             a.thr_init = p.grid0 > 0 ? ix->thr0 : nullptr;
-            a.partial = ix->partial;
             a.tile_begin = 0;
             a.tile_end = p.tiles;
             a.grid = p.grid1;
@@ -766,41 +750,9 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
                     // first stage's k rows are scored exactly and the k best of each query's list are the result.  Should a
                     // candidate buffer fill up (adversarial data: the bound prunes nothing), sketch_flag sends the search through
                     // the exact main launch below, gated on the flag.
-                    rc = vqa_launch_sketch_qconst(ix->thr0, ix->qrow, ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, ix->d_pad,
-                                                  ix->qconst, ix->cand_cnt, ix->sketch_flag, stream);
-                    if (rc != VQA_OK) return rc;
-                    SketchScanArgs sk;
-                    sk.tile_info = reinterpret_cast<const float4*>(ix->tile_info);
-                    sk.qconst = ix->qconst;
-                    sk.regions = ix->regions;
-                    sk.counts = ix->region_cnt;
-                    sk.overflow = ix->sketch_flag;
-                    sk.cap = kSketchCap;
-                    ScoreTopkArgs b;
-                    b.x = ix->rows8;
-                    b.q = ix->q8_stage;
-                    b.n = ix->n;
-                    b.d_pad = ix->d_pad8;
-                    b.nq = nq;
-                    b.k = kk;
-                    b.thr_init = nullptr;
-                    b.partial = nullptr;
-                    b.tile_begin = p.stage_tiles;
-                    b.tile_end = p.tiles;
-                    b.grid = p.grid1;
-                    b.sketch = &sk;
-                    if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
-                    rc = vqa_launch_score_topk(VQA_I8_SKETCH, b, stream);
-                    if (rc != VQA_OK) return rc;
-                    if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
-                    rc = vqa_launch_rescore(ix->regions, ix->region_cnt, kSketchCap, p.grid1, ix->stage_pos, nq, kk, ix->rows, ix->q_stage,
-                                            ix->dtype, ix->d_pad, ix->cand_keys, ix->cand_cnt, kSketchCap, ix->sketch_flag, stream);
-                    if (rc != VQA_OK) return rc;
-                    rc = vqa_launch_merge_partials(ix->cand_keys, 1, kSketchCap, nq, kk, ix->ids, ix->id_base, os, oi, op, nullptr, 1.0f, k, 0,
-                                                   nullptr, true, nullptr, stream, 1, ix->cand_cnt);
+                    rc = sketch_scan_and_select(ix, p, p.stage_tiles, nq, kk, kk, os, oi, op, stream);
                     if (rc != VQA_OK) return rc;
                     a.gate = ix->sketch_flag;  // the exact main launch + merge below: only when the flag is up
-                    VQA_HIP_CHECK(hipMemcpyAsync(ix->sketch_flag_host, ix->sketch_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
                 }
             }
             const bool time_it = ix->timing && !(staged && use_sketch) && !use_sketch_wide;  // a sketch search times its sketch scan instead

@@ -80,18 +80,18 @@ struct SketchScanArgs {
 
 // ---- kernel launchers implemented in the .hip files ---------------------------------------------------------
 struct ScoreTopkArgs {
-    const void* x;        // index rows in TILED layout (convert.hip): ceil(n/256) tiles x (d_pad/32) blocks of 16 KiB
-    const void* q;        // staged query tile, same layout (one tile), zero padded
-    const float* thr_init; // [VQA_QUERY_TILE] starting thresholds or nullptr (-inf)
+    const void* x = nullptr;  // index rows in TILED layout (convert.hip): ceil(n/256) tiles x (d_pad/32) blocks of 16 KiB
+    const void* q = nullptr;  // staged query tile, same layout (one tile), zero padded
+    const float* thr_init = nullptr;  // [VQA_QUERY_TILE] starting thresholds or nullptr (-inf)
     const vqa_key* upper = nullptr;  // [VQA_QUERY_TILE] exclusive upper bound keys (continuation passes) or nullptr
-    vqa_key* partial;     // main pass: [VQA_QUERY_TILE, grid, k] per-workgroup sorted partial lists, query-major (output)
-    int64_t n;            // rows in the shard
-    int32_t d_pad;        // padded row length in elements (multiple of 64)
-    int32_t nq;           // valid queries in the tile (1..VQA_QUERY_TILE)
-    int32_t k;
-    int32_t tile_begin;   // first corpus tile (of 256 rows) this launch covers
-    int32_t tile_end;     // one past the last
-    int32_t grid;         // workgroups
+    vqa_key* partial = nullptr;  // main pass: [VQA_QUERY_TILE, grid, k] per-workgroup sorted partial lists, query-major (output)
+    int64_t n = 0;        // rows in the shard
+    int32_t d_pad = 0;    // padded row length in elements (multiple of 64)
+    int32_t nq = 0;       // valid queries in the tile (1..VQA_QUERY_TILE)
+    int32_t k = 0;
+    int32_t tile_begin = 0;  // first corpus tile (of 256 rows) this launch covers
+    int32_t tile_end = 0;  // one past the last
+    int32_t grid = 0;     // workgroups
     const int* gate = nullptr;  // device flag or nullptr: the kernel returns at once when *gate == 0
     int32_t row_lists = 0;      // main pass flush: lists per query row of `partial` (0 = grid) ...
     int32_t list_offset = 0;    // ... and the slot of this launch's workgroup 0 inside the row (two-stage search: the first
