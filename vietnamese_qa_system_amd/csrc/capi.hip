@@ -435,6 +435,12 @@ struct LaunchPlan {
                              // thresholds at -inf and every list flooding: 0.43 ms per search instead of 0.08)
 };
 
+// The sketch path serves the searches the two-stage plan serves (one exact pass, k <= 12, a large shard) and, in its wide form,
+// k up to kSketchWideMaxK on the same shards (txtai's hybrid search asks the dense index for 10 x limit rows: 30 at its default
+// limit): there the candidates of a query number ~2300 at k = 30 against ~860 at k = 10 and the exact re-scoring (random 64-byte
+// pieces of the tiled index) grows with them -- past 32 the one-pass exact scan is as fast.
+constexpr int kSketchWideMaxK = 32;
+
 static LaunchPlan plan_launch(const vqa_index* ix, int k = 0) {
     LaunchPlan p;
     p.tiles = (int)((ix->n + 255) / 256);
@@ -466,7 +472,11 @@ static LaunchPlan plan_launch(const vqa_index* ix, int k = 0) {
         // bound than the seeds' for the main launch over the remaining tiles, and the first stage only needs seeds from
         // half as many tiles.  Both launches flush into one array of 2 x grid lists per query for the final merge.
         if (ix->stage_min_tiles > 0 && p.grid1 == ix->max_grid && p.tiles >= (long long)ix->stage_min_tiles * p.grid1) {
-            const int per_wg = (int)((long long)p.tiles * ix->stage_pct / 100 / p.grid1);
+            // (the wide sketch form: theta sits at rank k > 12 of the first stage's rows, a larger sample pays -- 10M rows, k = 30:
+            // 3.00 / 2.92 / 2.97 ms at 10 / 14 / 20 %)
+            const bool wide_sketch = ix->sketch && k > vqa_score_topk_max_k(ix->dtype) && k <= kSketchWideMaxK;
+            const int pct = wide_sketch ? ix->stage_pct * 7 / 5 : ix->stage_pct;
+            const int per_wg = (int)((long long)p.tiles * pct / 100 / p.grid1);
             p.stage_tiles = (per_wg > 0 ? per_wg : 1) * p.grid1;
             const int half = p.seed_tiles / 2 > 0 ? p.seed_tiles / 2 : 1;
             p.seed_tiles = half;
@@ -476,11 +486,6 @@ static LaunchPlan plan_launch(const vqa_index* ix, int k = 0) {
     return p;
 }
 
-// The sketch path serves the searches the two-stage plan serves (one exact pass, k <= 12, a large shard) and, in its wide form,
-// k up to kSketchWideMaxK on the same shards (txtai's hybrid search asks the dense index for 10 x limit rows: 30 at its default
-// limit): there the candidates of a query number ~2300 at k = 30 against ~860 at k = 10 and the exact re-scoring (random 64-byte
-// pieces of the tiled index) grows with them -- past 32 the one-pass exact scan is as fast.
-constexpr int kSketchWideMaxK = 32;
 static bool sketch_active(const vqa_index* ix, const LaunchPlan& p, int k) {
     return ix->sketch && p.stage_tiles > 0 && p.grid0 > 0 && k <= kSketchWideMaxK;
 }
