@@ -1198,12 +1198,15 @@ __global__ __launch_bounds__(64 * NQB * HPW) void attention_mfma_kernel(const _F
     const size_t row0 = cu ? (size_t)cu[seq] : (size_t)seq * Lmax;
     const int L = cu ? cu[seq + 1] - cu[seq] : Lmax;
     const _Float16* base = qkv + row0 * row_stride + head * kAttDh;
-    // V -> LDS by the NQB waves of this head, 16 bytes per lane and step (keys beyond L are zero)
-    for (int i = tid - hw * 64 * NQB; i < Lp * 8; i += 64 * NQB) {
+    // V -> registers now (the NQB waves of this head: 4 x 16 bytes per lane; keys beyond L are zero), -> LDS behind the softmax:
+    // the loads travel while Q . K^T and the softmax run
+    half8 vreg[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int i = tid - hw * 64 * NQB + t * 64 * NQB;
         const int key = i >> 3, ch = i & 7;
-        half8 v = half8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (key < L) v = *reinterpret_cast<const half8*>(base + (size_t)key * row_stride + 2 * H + ch * 8);
-        *reinterpret_cast<half8*>(vimg + key * 128 + (((ch >> 2) ^ ((key >> 1) & 1)) << 6) + ((ch & 3) << 4)) = v;
+        vreg[t] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (key < L) vreg[t] = *reinterpret_cast<const half8*>(base + (size_t)key * row_stride + 2 * H + ch * 8);
     }
     const int qrow = qb * 32 + li < L ? qb * 32 + li : L - 1;  // padded query rows recompute the last row, never stored
     half8 qf[4];
@@ -1247,6 +1250,12 @@ __global__ __launch_bounds__(64 * NQB * HPW) void attention_mfma_kernel(const _F
         }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int i = tid - hw * 64 * NQB + t * 64 * NQB;
+        const int key = i >> 3, ch = i & 7;
+        *reinterpret_cast<half8*>(vimg + key * 128 + (((ch >> 2) ^ ((key >> 1) & 1)) << 6) + ((ch & 3) << 4)) = vreg[t];
+    }
     __syncthreads();  // V images complete
     // transposed read of this lane: block row q_ = (lane & 15) >> 2 (+ the key base), columns 4 p_ .. 4 p_ + 3 of the 16-lane
     // group's 16 dimensions 16 (group & 1) ..; rows k0 + q_ with k0 a multiple of 4, so the half swap of a row is (q_ >> 1) & 1
@@ -1271,16 +1280,24 @@ __global__ __launch_bounds__(64 * NQB * HPW) void attention_mfma_kernel(const _F
                 const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(at + 8 * 128));   // keys k0 + 8 .. k0 + 11
                 typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
                 const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pf, __builtin_bit_cast(half8, both), o[db], 0, 0, 0);
+                // O^T = V^T . P^T: the transposed V fragment is the A operand (lane = head dimension), P the B operand (lane = query,
+                // its accumulator registers as they are), so the lane that holds a query's probabilities also receives its output row
+                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8, both), pf, o[db], 0, 0, 0);
             }
         }
+    // o[db][r] = O[query qb 32 + li][dimension 32 db + 8 (r >> 2) + 4 h + (r & 3)]: four consecutive dimensions per register quad,
+    // one 8-byte store each (the first form -- lane = dimension -- wrote 32 two-byte values per lane)
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    const int qo = qb * 32 + li;
+    if (qo < L) {
+        _Float16* orow = ctx + (row0 + qo) * H + head * kAttDh + 4 * h;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < 2; ++db)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int q = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (q < L) ctx[(row0 + q) * H + head * kAttDh + db * 32 + li] = (_Float16)o[db][r];
-        }
+            for (int g4 = 0; g4 < 4; ++g4)
+                *reinterpret_cast<half4*>(orow + db * 32 + 8 * g4) =
+                    half4{(_Float16)o[db][4 * g4], (_Float16)o[db][4 * g4 + 1], (_Float16)o[db][4 * g4 + 2], (_Float16)o[db][4 * g4 + 3]};
+    }
 }
 
 // CLS pooling reads one row per sequence, and after the last layer's attention nothing mixes rows any more: the last layer's
