@@ -93,7 +93,12 @@ int32_t vqa_index_dtype(const vqa_index* index);
  * the shard holds fewer than k rows the tail is padded with (-inf, -1).  out_pos_or_null [B, k] int64 receives
  * the row positions inside this shard (or NULL).  1 <= k <= VQA_MAX_K_TOTAL (k <= VQA_MAX_K: one pass over the index;
  * beyond that one verified pass, with ceil(k / VQA_MAX_K) gated exact passes as the fallback); any B >= 1 (processed in
- * tiles of VQA_QUERY_TILE queries). */
+ * tiles of VQA_QUERY_TILE queries).
+ * Asynchronous: the launches are queued on hip_stream and the call returns.  A handle owns ONE set of workspaces (query
+ * staging, candidate lists, the sketch search's buffers): its searches must be ordered on the device -- the same stream, or
+ * streams joined by events -- and one host thread at a time may be inside a call on it (a second one gets VQA_EINVAL).
+ * (A scan already fills the device, so concurrent searches of one shard would gain nothing; batches are pipelined by
+ * queueing them one behind the other.) */
 int vqa_index_search(vqa_index* index, const void* q, int32_t q_dtype, int32_t B, int32_t k, float* out_scores,
                      int64_t* out_ids, int64_t* out_pos_or_null, void* hip_stream);
 
