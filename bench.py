@@ -273,6 +273,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     info = index.launch_info(b, k)
+    device_bytes = index.device_bytes()
     # multi-batch steady state through search_pipelined (the all-gather of batch i hidden under the scan of batch i + 1;
     # at N = 1 the same four scans back to back): S = 4 resident query batches per call, outside the headline's timed region
     S = 4
@@ -344,6 +345,9 @@ def main():
                          # HBM-roofline queries/s of BASELINE.md -- a step that reads fewer bytes than the shard holds can
                          # pass the rate of a plain scan
                          "sketch_scan": sketch, "index_bytes": n * d * esize,
+                         # what the shard holds on the device: the rows as stored + the int8 sketch (+50 %) + the row-major copy the
+                         # sketch search re-scores its survivors from (+100 %; VQA_RESCORE_COPY=0 does without: re-scoring 3x slower)
+                         "device_bytes": device_bytes,
                          "whole_step_frac": round(n * d * esize / (float(np.median(step_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          # the ceiling this box's HBM really gives a plain stream: a 1 GiB device-to-device copy (torch's copy
                          # kernel), bytes read + written over its event time, in this process

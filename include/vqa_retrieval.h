@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VQA_VERSION 103 /* 0.1.3: VQA_INDEX_SKETCH, vqa_launch_info.sketch_scan; host rows upload through pinned staging */
+#define VQA_VERSION 104 /* 0.1.4: VQA_INDEX_RESCORE_ROWS, vqa_index_device_bytes (0.1.3: VQA_INDEX_SKETCH, vqa_launch_info.sketch_scan) */
 
 /* error codes */
 #define VQA_OK 0
@@ -47,6 +47,11 @@ extern "C" {
                              * row -- with a rigorous upper bound on every (query, row) score, and score exactly (stored rows, fp32
                              * accumulation) only the pairs the bound cannot exclude: the results are those of the exact scan.
                              * Ignored for fp8 storage. */
+#define VQA_INDEX_RESCORE_ROWS 4 /* with VQA_INDEX_SKETCH, where the sketch is kept: a second, ROW-MAJOR copy of the stored rows (+100 %
+                             * of the rows' memory).  The sketch search scores its surviving (query, row) pairs exactly from the
+                             * stored rows; in the scan's tiled layout a row is 2 d / 64 pieces of 64 bytes, 16 KiB apart (random
+                             * half cache lines), in the copy one contiguous run -- the same values added in the same order, so
+                             * the results are bit-equal with and without it.  Ignored where no sketch is kept. */
 
 /* limits of the fused scoring + top-k kernel */
 #define VQA_MAX_K 12       /* top-k per query found by ONE exact pass over the index (LDS candidate lists; BASELINE k = 10) */
@@ -85,6 +90,8 @@ void vqa_index_destroy(vqa_index* index);
 int64_t vqa_index_size(const vqa_index* index);
 int32_t vqa_index_dim(const vqa_index* index);
 int32_t vqa_index_dtype(const vqa_index* index);
+/* device memory the shard holds: rows + id vector + sketch + re-scoring copy (workspaces of a few MB not counted); -1: null */
+int64_t vqa_index_device_bytes(const vqa_index* index);
 
 /* ---- search: replaces the scoring + top-k inside Embeddings.search / batchsearch (heavy_ranker.py:98,100) ---
  * q: [B, d] DEVICE pointer, element type q_dtype (VQA_F32 or VQA_F16; converted to the index storage type with

@@ -20,10 +20,10 @@ def _unit(rng, n, d):
     return R.l2_normalize(rng.standard_normal((n, d)).astype(np.float32)).astype(np.float16)
 
 
-def _index(x, monkeypatch, sketch, stage_min="2", ids=None, id_base=0, dtype="fp16"):
+def _index(x, monkeypatch, sketch, stage_min="2", ids=None, id_base=0, dtype="fp16", rescore_copy=None):
     from vietnamese_qa_system_amd.index import DeviceIndex
     monkeypatch.setenv("VQA_STAGE_MIN", stage_min)
-    return DeviceIndex(x, ids=ids, id_base=id_base, dtype=dtype, device=0, sketch=sketch)
+    return DeviceIndex(x, ids=ids, id_base=id_base, dtype=dtype, device=0, sketch=sketch, rescore_copy=rescore_copy)
 
 
 def _search(ix, q, k):
@@ -258,3 +258,34 @@ def test_random_geometries_against_the_exact_scan(native_lib, monkeypatch):
         assert np.all(np.abs(s1[diff] - s0[diff]) <= TIE_TOL) and diff.mean() < 0.01, (case, n, d, k, b, dtype, int(diff.sum()))
         nd = min(k, len(set(planted.tolist())))
         assert sorted(p1[0, :nd].tolist()) == sorted(set(planted.tolist()))[:nd], (case, n, d, k, b, dtype)
+
+
+@pytest.mark.parametrize("dtype,d,k", [("fp16", 200, 10), ("fp16", 768, 30), ("fp32", 96, 12)])
+def test_row_major_rescoring_copy_changes_no_bit(native_lib, monkeypatch, dtype, d, k):
+    """VQA_INDEX_RESCORE_ROWS: the sketch search scores its surviving pairs from a row-major copy of the stored rows (whole
+    cache lines) instead of the scan's tiled layout (64-byte pieces) -- same values, same summation order, so positions AND
+    scores are bit-equal with and without it; a shard filled in unaligned chunks keeps the copy consistent."""
+    from vietnamese_qa_system_amd.index import DeviceIndex
+    n, b = 170_003, 96
+    rng = np.random.default_rng(77 + d)
+    x = R.l2_normalize(rng.standard_normal((n, d)).astype(np.float32))
+    q = R.l2_normalize(rng.standard_normal((b, d)).astype(np.float32))
+    if dtype == "fp16":
+        x, q = x.astype(np.float16), q.astype(np.float16)
+    x[[5, 70_000, n - 1]] = x[5]
+    q[0] = x[5]
+    plain = _index(x, monkeypatch, sketch=True, dtype=dtype, rescore_copy=False)
+    monkeypatch.setenv("VQA_STAGE_MIN", "2")
+    copy = DeviceIndex.empty(n, d, dtype=dtype, device=0, sketch=True, rescore_copy=True)
+    for lo, hi in ((90_001, n), (0, 513), (513, 90_001)):
+        copy.set_rows(lo, x[lo:hi])
+    esize = 2 if dtype == "fp16" else 4
+    d_pad = (d * esize + 127) // 128 * 128 // esize
+    assert copy.device_bytes() - plain.device_bytes() == (n + 255) // 256 * 256 * d_pad * esize
+    assert copy.launch_info(b, k).sketch_scan == 1 and plain.launch_info(b, k).sketch_scan == 1
+    s0, _, p0 = _search(plain, q, k)
+    s1, _, p1 = _search(copy, q, k)
+    plain.close()
+    copy.close()
+    assert np.array_equal(p0, p1) and np.array_equal(s0, s1)
+    assert p1[0, :3].tolist() == [5, 70_000, n - 1] and len(set(s1[0, :3].tolist())) == 1

@@ -67,6 +67,7 @@ struct vqa_index {
     int32_t d_pad8 = 0;             // sketch row length (multiple of 128 elements)
     void* rows8 = nullptr;          // TILED int8: ceil(n/256) tiles x (d_pad8/64) blocks of 16 KiB
     size_t rows8_bytes = 0;
+    void* rows_rm = nullptr;     // VQA_INDEX_RESCORE_ROWS: row-major copy of the stored rows (rows_bytes), read by the sketch search's re-scoring
     float* tile_info = nullptr;     // [tiles][4]: max ||x_hi||, max ||x_lo||, 1 / scale, scale of every 256-row tile (x_int = rint(x / scale))
     void* q8_stage = nullptr;       // sketch of the staged query tile
     float* qrow = nullptr;          // [3][256] per query: scale, ||q_lo||, ||q||
@@ -74,7 +75,7 @@ struct vqa_index {
     unsigned long long* regions = nullptr;  // [max_grid][kSketchCap] candidate pairs per workgroup of the scan
     unsigned* region_cnt = nullptr;         // [max_grid]
     vqa_key* cand_keys = nullptr;           // [256][kSketchCap] exact (score, position) keys per query
-    unsigned* cand_cnt = nullptr;           // [256]
+    unsigned* cand_cnt = nullptr;           // [256][kSketchSubLists]: keys in every sub-list of a query's list
     int* sketch_flag = nullptr;             // 1 = a candidate buffer filled up: the exact fallback scan runs
     long long* stage_pos = nullptr;         // [256][max_k] row positions of the first stage's top-k
     int* sketch_flag_host = nullptr;        // pinned mirror of sketch_flag, copied behind every sketch search (read by the NEXT call)
@@ -128,6 +129,7 @@ extern "C" void vqa_index_destroy(vqa_index* ix) {
                     (void*)ix->regions, (void*)ix->region_cnt, (void*)ix->cand_keys, (void*)ix->cand_cnt, (void*)ix->sketch_flag,
                     (void*)ix->stage_pos})
         if (p) (void)hipFree(p);
+    if (ix->rows_rm) (void)hipFree(ix->rows_rm);
     if (ix->sketch_flag_host) (void)hipHostFree(ix->sketch_flag_host);
     if (ix->partial) (void)hipFree(ix->partial);
     if (ix->thr0) (void)hipFree(ix->thr0);
@@ -239,6 +241,10 @@ extern "C" int vqa_index_set_rows(vqa_index* ix, int64_t first, int64_t count, c
         rc = vqa_launch_sketch_rows(ix->rows, ix->dtype, r0, r1 - r0, ix->d_pad, ix->d_pad8, ix->tile_info, ix->rows8, nullptr, nullptr,
                                     nullptr, nullptr);
         if (rc != VQA_OK) return rc;
+        if (ix->rows_rm) {  // the same stored values, row-major
+            rc = vqa_launch_rows_to_rowmajor(ix->rows, first, count, ix->d_pad * elem_bytes(ix->dtype), ix->rows_rm, nullptr);
+            if (rc != VQA_OK) return rc;
+        }
     }
     if (ids_or_null) VQA_HIP_CHECK(hipMemcpy(ix->ids + first, ids_or_null, (size_t)count * 8, hipMemcpyDefault));
     VQA_HIP_CHECK(hipStreamSynchronize(nullptr));
@@ -252,7 +258,7 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
     VQA_REQUIRE(n >= 0 && n < 0xFFFFFFFFll, "vqa_index_create: n=%lld outside [0, 2^32-1) rows per shard", (long long)n);
     VQA_REQUIRE(d >= 1 && d <= 65536, "vqa_index_create: d=%d", d);
     VQA_REQUIRE(dtype == VQA_F32 || dtype == VQA_F16 || dtype == VQA_FP8_E4M3, "vqa_index_create: dtype %d", dtype);
-    VQA_REQUIRE((flags & ~(uint32_t)(VQA_INDEX_HAS_IDS | VQA_INDEX_SKETCH)) == 0, "vqa_index_create: unknown flags 0x%x", flags);
+    VQA_REQUIRE((flags & ~(uint32_t)(VQA_INDEX_HAS_IDS | VQA_INDEX_SKETCH | VQA_INDEX_RESCORE_ROWS)) == 0, "vqa_index_create: unknown flags 0x%x", flags);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         vqa_set_error("vqa_index_create: no HIP device visible");
@@ -352,7 +358,7 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
                 hipMalloc((void**)&ix->regions, (size_t)ix->max_grid * kSketchCap * 8) != hipSuccess ||
                 hipMalloc((void**)&ix->region_cnt, (size_t)ix->max_grid * 4) != hipSuccess ||
                 hipMalloc((void**)&ix->cand_keys, (size_t)VQA_QUERY_TILE * kSketchCap * sizeof(vqa_key)) != hipSuccess ||
-                hipMalloc((void**)&ix->cand_cnt, VQA_QUERY_TILE * 4) != hipSuccess || hipMalloc((void**)&ix->sketch_flag, 4) != hipSuccess ||
+                hipMalloc((void**)&ix->cand_cnt, VQA_QUERY_TILE * kSketchSubLists * 4) != hipSuccess || hipMalloc((void**)&ix->sketch_flag, 4) != hipSuccess ||
                 hipMalloc((void**)&ix->stage_pos, (size_t)VQA_QUERY_TILE * max_k * 8) != hipSuccess ||
                 hipHostMalloc((void**)&ix->sketch_flag_host, sizeof(int), hipHostMallocDefault) != hipSuccess) {
                 vqa_set_error("vqa_index_create: allocating the int8 sketch (%zu bytes) failed", ix->rows8_bytes);
@@ -366,6 +372,18 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
                 vqa_set_error("vqa_index_create: clearing the int8 sketch failed");
                 rc = VQA_EHIP;
                 break;
+            }
+            if (flags & VQA_INDEX_RESCORE_ROWS) {  // the sketch search's re-scoring then reads whole rows instead of 64-byte pieces
+                if (hipMalloc(&ix->rows_rm, ix->rows_bytes) != hipSuccess) {
+                    vqa_set_error("vqa_index_create: hipMalloc of %zu bytes for the row-major re-scoring copy failed", ix->rows_bytes);
+                    rc = VQA_ENOMEM;
+                    break;
+                }
+                if (hipMemset(ix->rows_rm, 0, ix->rows_bytes) != hipSuccess) {
+                    vqa_set_error("vqa_index_create: clearing the row-major copy failed");
+                    rc = VQA_EHIP;
+                    break;
+                }
             }
         }
         if (rows && n > 0) rc = vqa_index_set_rows(ix, 0, n, rows, rows_dtype, ids_or_null);
@@ -424,6 +442,13 @@ extern "C" int vqa_index_get_rows(vqa_index* ix, int64_t first, int64_t count, v
 extern "C" int64_t vqa_index_size(const vqa_index* ix) { return ix ? ix->n : -1; }
 extern "C" int32_t vqa_index_dim(const vqa_index* ix) { return ix ? ix->d : -1; }
 extern "C" int32_t vqa_index_dtype(const vqa_index* ix) { return ix ? ix->dtype : -1; }
+extern "C" int64_t vqa_index_device_bytes(const vqa_index* ix) {
+    if (!ix) return -1;
+    int64_t b = (int64_t)ix->rows_bytes + (ix->ids ? ix->n * 8 : 0);
+    if (ix->sketch) b += (int64_t)ix->rows8_bytes + ((ix->n + 255) / 256) * 16;
+    if (ix->rows_rm) b += (int64_t)ix->rows_bytes;
+    return b;
+}
 
 struct LaunchPlan {
     int tiles = 0;  // corpus tiles of 256 rows
@@ -605,10 +630,10 @@ static int sketch_scan_and_select(vqa_index* ix, const LaunchPlan& p, int tile_b
     if (rc != VQA_OK) return rc;
     if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
     rc = vqa_launch_rescore(ix->regions, ix->region_cnt, kSketchCap, p.grid1, stage_k > 0 ? ix->stage_pos : nullptr, nq, stage_k, ix->rows,
-                            ix->q_stage, ix->dtype, ix->d_pad, ix->cand_keys, ix->cand_cnt, kSketchCap, ix->sketch_flag, stream);
+                            ix->rows_rm, ix->q_stage, ix->dtype, ix->d_pad, ix->cand_keys, ix->cand_cnt, kSketchCap, ix->sketch_flag, stream);
     if (rc != VQA_OK) return rc;
-    rc = vqa_launch_merge_partials(ix->cand_keys, 1, kSketchCap, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr, 1.0f, k, 0, nullptr, true,
-                                   nullptr, stream, 1, ix->cand_cnt);
+    rc = vqa_launch_merge_partials(ix->cand_keys, kSketchSubLists, kSketchCap / kSketchSubLists, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr,
+                                   1.0f, k, 0, nullptr, true, nullptr, stream, kSketchSubLists, ix->cand_cnt);
     if (rc != VQA_OK) return rc;
     VQA_HIP_CHECK(hipMemcpyAsync(ix->sketch_flag_host, ix->sketch_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
     return VQA_OK;
@@ -781,7 +806,7 @@ extern "C" int vqa_dev_sketch_stats(vqa_index* ix, long long* out) {
     VQA_REQUIRE(ix && out && ix->sketch, "vqa_dev_sketch_stats: no sketch");
     DeviceGuard guard(ix->device);
     VQA_HIP_CHECK(hipDeviceSynchronize());
-    std::vector<unsigned> rc(ix->max_grid), cc(VQA_QUERY_TILE);
+    std::vector<unsigned> rc(ix->max_grid), cc(VQA_QUERY_TILE * kSketchSubLists);  // (out[2]: the longest SUB-list)
     int flag = 0;
     VQA_HIP_CHECK(hipMemcpy(rc.data(), ix->region_cnt, rc.size() * 4, hipMemcpyDeviceToHost));
     VQA_HIP_CHECK(hipMemcpy(cc.data(), ix->cand_cnt, cc.size() * 4, hipMemcpyDeviceToHost));

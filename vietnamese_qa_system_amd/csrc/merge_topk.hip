@@ -53,8 +53,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
     vqa_key* red = keys + (size_t)parts * list_len;      // [4]
     int* fill = reinterpret_cast<int*>(red + 4);         // keys kept
     const int q = blockIdx.x;
-    int m_all = parts * list_len;
-    if (counts) m_all = (int)counts[q] < m_all ? (int)counts[q] : m_all;  // a sketch search's candidate list: the first counts[q] slots
+    const int m_all = parts * list_len;
     // Only the non-empty slots are kept: a workgroup's list of a query holds ~1-3 keys after a scan seeded with good
     // thresholds, so the 512 x k slots of a two-stage search shrink to a few hundred keys and the k selection rounds below
     // touch 2 instead of 20 keys per thread (final merge 31 -> 17 us).  The order in which the keys land is arbitrary; the
@@ -63,6 +62,18 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
     const bool dense = out_scores == nullptr && list_len <= 8;
     if (threadIdx.x == 0) *fill = dense ? m_all : 0;
     __syncthreads();
+    if (counts) {
+        // a sketch search's candidate list: `parts` sub-lists of list_len slots, the first counts[q][part] of each are this search's
+        // (the slots behind hold keys of earlier searches)
+        for (int p = 0; p < parts; ++p) {
+            const int c = (int)counts[q * parts + p] < list_len ? (int)counts[q * parts + p] : list_len;
+            const vqa_key* src = partial + ((size_t)q * row_lists + p) * list_len;
+            for (int j = threadIdx.x; j < c; j += kMergeThreads) {
+                const vqa_key v = src[j];
+                if (v != 0ull) keys[atomicAdd(fill, 1)] = v;
+            }
+        }
+    } else
     for (int i = threadIdx.x; i < m_all; i += kMergeThreads) {
         vqa_key v;
         if (query_major) {  // a query's row holds row_lists lists; the first `parts` of them are merged

@@ -26,10 +26,15 @@ __device__ __forceinline__ size_t unit_of(long long row, int u, int KT) {  // 16
 // consumed (the rows are 64-byte pieces at 16 KiB strides of the tiled index: latency, not bandwidth, is what a one-pair-at-a-time
 // loop pays).  grid (x, regions + 1): y < regions walks that workgroup's region of the sketch scan, y == regions the rows of
 // the exact first stage (stage_pos [nq][k] positions, -1 = none).
-constexpr int kRescoreUnitsMax = 8;  // 16-byte units per lane and pair: rows of up to 32 * 8 * 8 = 2048 fp16 / 1024 fp32 elements take the fast path
+// UM = 16-byte units per lane and pair held in registers (2, 3, 4, 6 or 8: rows of up to 32 * 8 units = 2048 fp16 / 1024 fp32 elements;
+// 0 = the loop form for longer rows).  The launcher picks the smallest that covers the row: at d = 768 fp16 (3 units) the kernel
+// takes 80 instead of 210 registers of the 8-unit form, i.e. 6 instead of 2 waves per SIMD to hide the row fetches behind.
 
 // T = _Float16 (8 elements per 16-byte unit; products exact in fp32) or float (4 per unit: fp32 index, fp32 fma chain)
-template <typename T>
+// RM: X is the shard's ROW-MAJOR copy (VQA_INDEX_RESCORE_ROWS: rows of KT * 64 bytes, the same stored values) -- a pair's row is one
+// contiguous run of whole 128-byte lines instead of 4 KT pieces of 64 bytes at 16 KiB strides.  Unit u holds the same elements in
+// both layouts, so the two forms add the same products in the same order: bit-equal scores.
+template <typename T, bool RM, int UM>
 __global__ __launch_bounds__(256) void rescore_kernel(const unsigned long long* __restrict__ regions, const unsigned* __restrict__ counts,
                                                       int cap, int nregions, const long long* __restrict__ stage_pos, int nq, int k,
                                                       const T* __restrict__ X, const T* __restrict__ Q, int KT,
@@ -42,6 +47,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(const unsigned long long* 
     const int y = blockIdx.y;
     const int total = y < nregions ? (int)counts[y] : nq * k;
     const int units = KT * 4;
+    const int sub_cap = capq / kSketchSubLists;
     auto pair_of = [&](int i, int& q, long long& pos) {
         q = 0;
         pos = -1;
@@ -56,34 +62,35 @@ __global__ __launch_bounds__(256) void rescore_kernel(const unsigned long long* 
         }
     };
     for (int i0 = wave * 4; i0 < total; i0 += nwaves * 4) {
+        const unsigned sub = (unsigned)(i0 >> 2) % kSketchSubLists;  // the four pairs of this iteration share a sub-list index
         int q[2];
         long long pos[2];
         pair_of(i0 + half, q[0], pos[0]);
         pair_of(i0 + 2 + half, q[1], pos[1]);
         float acc[2] = {0.f, 0.f};
-        if (units <= 32 * kRescoreUnitsMax) {
-            unit_t xv[2][kRescoreUnitsMax], qv[2][kRescoreUnitsMax];
+        if constexpr (UM > 0) {
+            unit_t xv[2][UM], qv[2][UM];
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int j = 0; j < kRescoreUnitsMax; ++j) {
+                for (int j = 0; j < UM; ++j) {
                     const int u = hl + 32 * j;
                     xv[p][j] = qv[p][j] = unit_t{};
                     if (u < units && pos[p] >= 0) {
-                        xv[p][j] = *reinterpret_cast<const unit_t*>(X + unit_of(pos[p], u, KT) * EPU);
+                        xv[p][j] = *reinterpret_cast<const unit_t*>(X + (RM ? (size_t)pos[p] * units + u : unit_of(pos[p], u, KT)) * EPU);
                         qv[p][j] = *reinterpret_cast<const unit_t*>(Q + unit_of(q[p], u, KT) * EPU);
                     }
                 }
 #pragma unroll
             for (int p = 0; p < 2; ++p)
 #pragma unroll
-                for (int j = 0; j < kRescoreUnitsMax; ++j)
+                for (int j = 0; j < UM; ++j)
 #pragma unroll
                     for (int e = 0; e < EPU; ++e) acc[p] = __builtin_fmaf((float)xv[p][j][e], (float)qv[p][j][e], acc[p]);
         } else {
             for (int p = 0; p < 2; ++p)
                 for (int u = hl; u < units && pos[p] >= 0; u += 32) {
-                    const unit_t xw = *reinterpret_cast<const unit_t*>(X + unit_of(pos[p], u, KT) * EPU);
+                    const unit_t xw = *reinterpret_cast<const unit_t*>(X + (RM ? (size_t)pos[p] * units + u : unit_of(pos[p], u, KT)) * EPU);
                     const unit_t qw = *reinterpret_cast<const unit_t*>(Q + unit_of(q[p], u, KT) * EPU);
 #pragma unroll
                     for (int e = 0; e < EPU; ++e) acc[p] = __builtin_fmaf((float)xw[e], (float)qw[e], acc[p]);
@@ -94,12 +101,24 @@ __global__ __launch_bounds__(256) void rescore_kernel(const unsigned long long* 
 #pragma unroll
             for (int off = 16; off >= 1; off >>= 1) acc[p] += __shfl_xor(acc[p], off, 64);  // inside the half wave
             if (hl == 0 && pos[p] >= 0) {
-                const unsigned slot = atomicAdd(cand_cnt + q[p], 1u);
-                if (slot < (unsigned)capq) cand_keys[(size_t)q[p] * capq + slot] = vqa_make_key(acc[p], (uint32_t)pos[p]);
+                // sub-list `sub` of the query's list ([query][kSketchSubLists][capq / kSketchSubLists]): the appends of one search spread over
+                // 16x the counters and cache lines
+                const unsigned lane_list = (unsigned)q[p] * kSketchSubLists + sub;
+                const unsigned slot = atomicAdd(cand_cnt + lane_list, 1u);
+                if (slot < (unsigned)sub_cap) cand_keys[(size_t)lane_list * sub_cap + slot] = vqa_make_key(acc[p], (uint32_t)pos[p]);
                 else atomicExch(overflow, 1);
             }
         }
     }
+}
+
+// rows [first, first + count) of the tiled shard -> the row-major re-scoring copy (rows of KT * 64 bytes, zero padded as stored);
+// one wave per row, 16 bytes per lane and step
+__global__ __launch_bounds__(256) void rows_to_rowmajor_kernel(const uint4* __restrict__ tiled, long long first, long long count, int KT,
+                                                                uint4* __restrict__ out) {
+    const long long r = first + (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= first + count) return;
+    for (int u = threadIdx.x & 63; u < KT * 4; u += 64) out[(size_t)r * (KT * 4) + u] = tiled[unit_of(r, u, KT)];
 }
 
 // per query: theta (the exact k-th best score of the first stage), ||q_lo||, ||q|| (1 + fp margin), 1 / s_q -> qconst [4][256]; clears the
@@ -116,7 +135,8 @@ __global__ void sketch_qconst_kernel(const float* __restrict__ thr, const float*
     qconst[256 + q] = qlo[q] + fp_margin * qnorm[q];
     qconst[512 + q] = qnorm[q] * (1.0f + fp_margin);
     qconst[768 + q] = 1.0f / qscale[q];
-    cand_cnt[q] = 0u;
+#pragma unroll
+    for (int j = 0; j < kSketchSubLists; ++j) cand_cnt[q * kSketchSubLists + j] = 0u;
     if (q == 0) *overflow = 0;
 }
 
@@ -130,18 +150,42 @@ int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float*
     return VQA_OK;
 }
 
+int vqa_launch_rows_to_rowmajor(const void* tiled, int64_t first, int64_t count, int32_t row_bytes, void* out, hipStream_t stream) {
+    if (count <= 0) return VQA_OK;
+    VQA_REQUIRE(row_bytes % 64 == 0, "rows_to_rowmajor: rows of %d bytes", row_bytes);
+    hipLaunchKernelGGL(rows_to_rowmajor_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, stream, reinterpret_cast<const uint4*>(tiled),
+                       (long long)first, (long long)count, row_bytes / 64, reinterpret_cast<uint4*>(out));
+    VQA_HIP_CHECK(hipGetLastError());
+    return VQA_OK;
+}
+
 int vqa_launch_rescore(const unsigned long long* regions, const unsigned* counts, int cap, int nregions, const long long* stage_pos,
-                       int nq, int k, const void* x, const void* q, int32_t dtype, int32_t d_pad, vqa_key* cand_keys, unsigned* cand_cnt,
-                       int capq, int* overflow, hipStream_t stream) {
+                       int nq, int k, const void* x, const void* x_rowmajor, const void* q, int32_t dtype, int32_t d_pad, vqa_key* cand_keys,
+                       unsigned* cand_cnt, int capq, int* overflow, hipStream_t stream) {
     VQA_REQUIRE(dtype == VQA_F16 || dtype == VQA_F32, "rescore: storage type %d", dtype);
-    if (dtype == VQA_F16)
-        hipLaunchKernelGGL(rescore_kernel<_Float16>, dim3(32, nregions + 1), dim3(256), 0, stream, regions, counts, cap, nregions, stage_pos,
-                           nq, k, reinterpret_cast<const _Float16*>(x), reinterpret_cast<const _Float16*>(q), d_pad / 32, cand_keys, cand_cnt,
-                           capq, overflow);
-    else
-        hipLaunchKernelGGL(rescore_kernel<float>, dim3(32, nregions + 1), dim3(256), 0, stream, regions, counts, cap, nregions, stage_pos, nq,
-                           k, reinterpret_cast<const float*>(x), reinterpret_cast<const float*>(q), d_pad / 16, cand_keys, cand_cnt, capq,
-                           overflow);
+    const dim3 grid(32, nregions + 1), block(256);
+#define VQA_RESCORE_UM(T, RM, UMV, XP, KTV)                                                                                          \
+    hipLaunchKernelGGL((rescore_kernel<T, RM, UMV>), grid, block, 0, stream, regions, counts, cap, nregions, stage_pos, nq, k,       \
+                       reinterpret_cast<const T*>(XP), reinterpret_cast<const T*>(q), KTV, cand_keys, cand_cnt, capq, overflow)
+#define VQA_RESCORE(T, RM, XP, KTV)                                                                                                  \
+    do {                                                                                                                             \
+        const int per = ((KTV) * 4 + 31) / 32; /* units per lane */                                                                  \
+        if (per <= 2) VQA_RESCORE_UM(T, RM, 2, XP, KTV);                                                                             \
+        else if (per <= 3) VQA_RESCORE_UM(T, RM, 3, XP, KTV);                                                                        \
+        else if (per <= 4) VQA_RESCORE_UM(T, RM, 4, XP, KTV);                                                                        \
+        else if (per <= 6) VQA_RESCORE_UM(T, RM, 6, XP, KTV);                                                                        \
+        else if (per <= 8) VQA_RESCORE_UM(T, RM, 8, XP, KTV);                                                                        \
+        else VQA_RESCORE_UM(T, RM, 0, XP, KTV);                                                                                      \
+    } while (0)
+    if (dtype == VQA_F16) {
+        if (x_rowmajor) VQA_RESCORE(_Float16, true, x_rowmajor, d_pad / 32);
+        else VQA_RESCORE(_Float16, false, x, d_pad / 32);
+    } else {
+        if (x_rowmajor) VQA_RESCORE(float, true, x_rowmajor, d_pad / 16);
+        else VQA_RESCORE(float, false, x, d_pad / 16);
+    }
+#undef VQA_RESCORE
+#undef VQA_RESCORE_UM
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

@@ -69,6 +69,12 @@ __host__ __device__ __forceinline__ uint32_t vqa_key_pos(vqa_key k) { return 0xF
 #define VQA_I8_SKETCH 3
 
 // MODE 2 of the scoring kernel: the sketch scan's extra arguments
+// A query's candidate list of a sketch search is kept as kSketchSubLists sub-lists with a counter each; the re-scoring kernel picks
+// the sub-list by the pair's index in its scan region, so the pairs of one region (near-duplicates stored side by side) spread
+// over all of them.  One counter per query took every append of a search through 8 cache lines of L2 atomics: 110-130 us of a
+// 290 us kernel at 10M rows.
+constexpr int kSketchSubLists = 16;
+
 struct SketchScanArgs {
     const float4* tile_info = nullptr;  // [tiles] (max ||x_hi||, max ||x_lo||, 1 / scale, scale) of every 256-row tile of the sketch
     const float* qconst = nullptr;      // [4][256]: theta (exact lower bound of the k-th best score), ||q_lo||, ||q||, 1 / s_q
@@ -120,8 +126,9 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
                               const int* gate /* device flag or nullptr: no-op when *gate == 0 */, hipStream_t stream,
                               int32_t row_lists = 0 /* query-major only: lists per query row in memory (>= parts; 0 = parts):
                                                        the first `parts` lists of every row are merged */,
-                              const unsigned* counts = nullptr /* [nq] or nullptr: only the first counts[q] slots of a query's row
-                                                                  hold keys (the candidate lists of a sketch search) */);
+                              const unsigned* counts = nullptr /* [nq][parts] or nullptr (query-major lists): only the first
+                                                                  counts[q][part] slots of every list hold keys of this search
+                                                                  (the candidate sub-lists of a sketch search) */);
 // one-pass large-k check: sets *flag = 1 when some workgroup's list (list_len keys, full) ends ABOVE the query's k-th merged
 // key `kth` -- that list may have dropped a row of the true top-k (capi.hip, vqa_index_search)
 int vqa_launch_verify_wide(const vqa_key* partial, int32_t parts, int32_t list_len, int32_t nq, const vqa_key* kth, int* flag,
@@ -149,5 +156,7 @@ int vqa_launch_tile_scales(const void* tiled, int32_t src_dtype, int64_t tile0, 
 int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float* qlo, const float* qnorm, int32_t d, float* qconst,
                              unsigned* cand_cnt, int* overflow, hipStream_t stream);
 int vqa_launch_rescore(const unsigned long long* regions, const unsigned* counts, int cap, int nregions, const long long* stage_pos,
-                       int nq, int k, const void* x, const void* q, int32_t dtype /* VQA_F16 | VQA_F32: both tiled */, int32_t d_pad,
-                       vqa_key* cand_keys, unsigned* cand_cnt, int capq, int* overflow, hipStream_t stream);
+                       int nq, int k, const void* x, const void* x_rowmajor /* or nullptr: the tiled rows x are read */, const void* q,
+                       int32_t dtype, int32_t d_pad, vqa_key* cand_keys, unsigned* cand_cnt, int capq, int* overflow, hipStream_t stream);
+// rows [first, first + count) of a tiled shard -> its row-major copy (rows of row_bytes = padded row length in bytes)
+int vqa_launch_rows_to_rowmajor(const void* tiled, int64_t first, int64_t count, int32_t row_bytes, void* out, hipStream_t stream);

@@ -15,6 +15,7 @@ import torch
 
 from . import _native as N
 
+RESCORE_COPY_MAX_BYTES = 32 << 30  # rows of up to 32 GiB get the row-major re-scoring copy by default (DeviceIndex)
 _SRC_DTYPE = {torch.float32: N.VQA_F32, torch.float16: N.VQA_F16}
 _STORE_NP = {N.VQA_F32: np.float32, N.VQA_F16: np.float16, N.VQA_FP8_E4M3: np.uint8}
 FP8_SCALE = 16.0  # an fp8 index stores e4m3(16 * x) (and scores 16 * q the same way); scores come back divided by 256
@@ -58,7 +59,8 @@ class DeviceIndex:
     """
 
     def __init__(self, vectors=None, ids=None, *, id_base: int = 0, dtype="fp16", device: int = 0, normalize: bool = False,
-                 n: Optional[int] = None, d: Optional[int] = None, with_ids: Optional[bool] = None, sketch: Optional[bool] = None):
+                 n: Optional[int] = None, d: Optional[int] = None, with_ids: Optional[bool] = None, sketch: Optional[bool] = None,
+                 rescore_copy: Optional[bool] = None):
         self._handle = ctypes.c_void_p()
         self.device = int(device)
         _require_gpu(self.device)
@@ -77,6 +79,14 @@ class DeviceIndex:
         if sketch is None:
             sketch = os.environ.get("VQA_SKETCH", "1") != "0"
         flags = (N.VQA_INDEX_HAS_IDS if has_ids else 0) | (N.VQA_INDEX_SKETCH if sketch and self.dtype in (N.VQA_F16, N.VQA_F32) else 0)
+        # row-major copy of the rows for the sketch search's exact re-scoring (VQA_INDEX_RESCORE_ROWS: +100 % of the rows' memory,
+        # re-scoring 3x faster, bit-equal results; kept only where the library keeps a sketch).  Default: shards whose rows take
+        # up to RESCORE_COPY_MAX_BYTES (an 80M x 768 fp16 shard on one device does without); VQA_RESCORE_COPY=0 / 1 overrides.
+        if rescore_copy is None:
+            env = os.environ.get("VQA_RESCORE_COPY", "")
+            rescore_copy = env == "1" if env in ("0", "1") else int(n) * int(d) * N.DTYPE_BYTES[self.dtype] <= RESCORE_COPY_MAX_BYTES
+        if rescore_copy and (flags & N.VQA_INDEX_SKETCH):
+            flags |= N.VQA_INDEX_RESCORE_ROWS
         with torch.cuda.device(self.device):
             N.check(self._lib.vqa_index_create(ctypes.byref(self._handle), self.device, int(n), int(d), self.dtype, None,
                                                N.VQA_F16, None, int(id_base), flags),
@@ -87,9 +97,10 @@ class DeviceIndex:
 
     @classmethod
     def empty(cls, n: int, d: int, *, id_base: int = 0, dtype="fp16", device: int = 0, with_ids: bool = False,
-              sketch: Optional[bool] = None) -> "DeviceIndex":
+              sketch: Optional[bool] = None, rescore_copy: Optional[bool] = None) -> "DeviceIndex":
         """A shard of ``n`` zero rows to be filled with :meth:`set_rows`."""
-        return cls(None, None, id_base=id_base, dtype=dtype, device=device, n=n, d=d, with_ids=with_ids, sketch=sketch)
+        return cls(None, None, id_base=id_base, dtype=dtype, device=device, n=n, d=d, with_ids=with_ids, sketch=sketch,
+                   rescore_copy=rescore_copy)
 
     # -- filling -------------------------------------------------------------------------------------------------
     def set_rows(self, first: int, vectors, ids=None, *, normalize: bool = False, chunk_rows: int = 1 << 20) -> None:
@@ -210,6 +221,10 @@ class DeviceIndex:
         ms, n = ctypes.c_double(), ctypes.c_int64()
         N.check(self._lib.vqa_index_get_timing(self._handle, ctypes.byref(ms), ctypes.byref(n)), "vqa_index_get_timing")
         return ms.value, n.value
+
+    def device_bytes(self) -> int:
+        """Device memory the shard holds: rows + id vector + int8 sketch + re-scoring copy."""
+        return int(self._lib.vqa_index_device_bytes(self._handle))
 
     def launch_info(self, b: int, k: int) -> N.LaunchInfo:
         info = N.LaunchInfo()
