@@ -497,10 +497,10 @@ static LaunchPlan plan_launch(const vqa_index* ix, int k = 0) {
         // bound than the seeds' for the main launch over the remaining tiles, and the first stage only needs seeds from
         // half as many tiles.  Both launches flush into one array of 2 x grid lists per query for the final merge.
         if (ix->stage_min_tiles > 0 && p.grid1 == ix->max_grid && p.tiles >= (long long)ix->stage_min_tiles * p.grid1) {
-            // (the wide sketch form: theta sits at rank k > 12 of the first stage's rows, a larger sample pays -- 10M rows, k = 30:
-            // 3.00 / 2.92 / 2.97 ms at 10 / 14 / 20 %)
+            // (the wide sketch form scans every row with the sketch anyway, so its first stage is pure extra work that only buys
+            // a tighter theta: 10M rows, k = 30: 2.59 / 2.60 / 2.66 / 2.76 ms at 6 / 8 / 10 / 14 % since re-scoring a pair got cheap)
             const bool wide_sketch = ix->sketch && k > vqa_score_topk_max_k(ix->dtype) && k <= kSketchWideMaxK;
-            const int pct = wide_sketch ? ix->stage_pct * 7 / 5 : ix->stage_pct;
+            const int pct = wide_sketch ? ix->stage_pct * 7 / 10 : ix->stage_pct;
             const int per_wg = (int)((long long)p.tiles * pct / 100 / p.grid1);
             p.stage_tiles = (per_wg > 0 ? per_wg : 1) * p.grid1;
             const int half = p.seed_tiles / 2 > 0 ? p.seed_tiles / 2 : 1;

@@ -65,10 +65,13 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
     if (counts) {
         // a sketch search's candidate list: `parts` sub-lists of list_len slots, the first counts[q][part] of each are this search's
         // (the slots behind hold keys of earlier searches)
-        for (int p = 0; p < parts; ++p) {
+        // (kMergeThreads / parts threads per sub-list, all sub-lists at once: one dependent count load per thread instead of
+        // `parts` in a row)
+        const int tpp = parts <= kMergeThreads ? kMergeThreads / parts : 1;
+        for (int p = threadIdx.x / tpp; p < parts; p += kMergeThreads / tpp) {
             const int c = (int)counts[q * parts + p] < list_len ? (int)counts[q * parts + p] : list_len;
             const vqa_key* src = partial + ((size_t)q * row_lists + p) * list_len;
-            for (int j = threadIdx.x; j < c; j += kMergeThreads) {
+            for (int j = threadIdx.x % tpp; j < c; j += tpp) {
                 const vqa_key v = src[j];
                 if (v != 0ull) keys[atomicAdd(fill, 1)] = v;
             }
