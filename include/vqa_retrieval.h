@@ -51,7 +51,7 @@ extern "C" {
                              * of the rows' memory).  The sketch search scores its surviving (query, row) pairs exactly from the
                              * stored rows; in the scan's tiled layout a row is 2 d / 64 pieces of 64 bytes, 16 KiB apart (random
                              * half cache lines), in the copy one contiguous run -- the same values added in the same order, so
-                             * the results are bit-equal with and without it.  Ignored where no sketch is kept. */
+                             * the results are bit-equal with and without it.  Ignored where no sketch is kept, and when the device has no room for it. */
 
 /* limits of the fused scoring + top-k kernel */
 #define VQA_MAX_K 12       /* top-k per query found by ONE exact pass over the index (LDS candidate lists; BASELINE k = 10) */

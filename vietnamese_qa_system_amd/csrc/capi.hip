@@ -374,12 +374,11 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
                 break;
             }
             if (flags & VQA_INDEX_RESCORE_ROWS) {  // the sketch search's re-scoring then reads whole rows instead of 64-byte pieces
+                // the copy only speeds the re-scoring up: a device too full for it goes without (vqa_index_device_bytes tells)
                 if (hipMalloc(&ix->rows_rm, ix->rows_bytes) != hipSuccess) {
-                    vqa_set_error("vqa_index_create: hipMalloc of %zu bytes for the row-major re-scoring copy failed", ix->rows_bytes);
-                    rc = VQA_ENOMEM;
-                    break;
-                }
-                if (hipMemset(ix->rows_rm, 0, ix->rows_bytes) != hipSuccess) {
+                    (void)hipGetLastError();
+                    ix->rows_rm = nullptr;
+                } else if (hipMemset(ix->rows_rm, 0, ix->rows_bytes) != hipSuccess) {
                     vqa_set_error("vqa_index_create: clearing the row-major copy failed");
                     rc = VQA_EHIP;
                     break;
