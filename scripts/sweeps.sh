@@ -7,7 +7,7 @@ kb() { python scripts/kbench.py "$@" 2>&1 | grep step | sed 's/.*step/step/' | c
 echo "== search step, fp16, B=256, k=10, d=768, rows:" >> $O
 for n in 1000 5000 20000 65536 300000 1000000 3000000 10000000; do echo -n "rows=$n: " >> $O; kb --n $n --steps 30 >> $O; done
 echo "== k (10M rows):" >> $O
-for k in 1 3 10 12 13 20 30 32 33 100; do echo -n "k=$k: " >> $O; kb --k $k --steps 15 >> $O; done
+for k in 1 3 10 12 13 20 30 32 48 64 65 100; do echo -n "k=$k: " >> $O; kb --k $k --steps 15 >> $O; done
 echo "== k (20000 rows):" >> $O
 for k in 1 12 13 30 100 300; do echo -n "k=$k: " >> $O; kb --n 20000 --k $k --steps 30 >> $O; done
 echo "== batch (10M rows):" >> $O

@@ -60,11 +60,12 @@ def test_sketch_search_equals_the_exact_scan(native_lib, monkeypatch, n, d, b, k
     assert p1[0, :nd].tolist() == dup[:nd] and len(set(s1[0, :nd].tolist())) == 1  # bit-equal scores, position order
 
 
-@pytest.mark.parametrize("n,d,b,k", [(300_001, 64, 41, 30), (200_000, 128, 256, 13), (180_000, 768, 32, 32)])
+@pytest.mark.parametrize("n,d,b,k", [(300_001, 64, 41, 30), (200_000, 128, 256, 13), (180_000, 768, 32, 32), (250_000, 96, 17, 64)])
 def test_wide_sketch_search_equals_the_exact_scan(native_lib, monkeypatch, n, d, b, k):
-    """12 < k <= 32 (the dense leg of a hybrid search asks for 10 x limit rows): theta = the k-th largest key of the first
-    stage's 12-deep workgroup lists, the sketch scan covers EVERY row, survivors are scored exactly.  Same rows as the exact
-    large-k path, duplicates (inside the first stage, astride its end, in the last tile) bit-equal in position order."""
+    """12 < k <= 64 (the dense leg of a hybrid search asks for 10 x limit rows) take the same cascade as k <= 12: exact seeds ->
+    sketch scan of the first stage against their threshold -> exact k-th best of its survivors -> sketch scan of the rest.  Same
+    rows as the exact large-k path, duplicates (inside the first stage, astride its end, in the last tile) bit-equal in
+    position order."""
     rng = np.random.default_rng(n + d + k)
     x, q = _unit(rng, n, d), _unit(rng, b, d)
     dup = [3, 40_000, 65_535, 65_536, n - 1]
@@ -75,8 +76,8 @@ def test_wide_sketch_search_equals_the_exact_scan(native_lib, monkeypatch, n, d,
     ref = _index(x, monkeypatch, sketch=False, ids=ids)
     ske = _index(x, monkeypatch, sketch=True, ids=ids)
     li = ske.launch_info(b, k)
-    assert ref.launch_info(b, k).sketch_scan == 0 and li.sketch_scan == 1 and ske.launch_info(b, 33).sketch_scan == 0
-    assert li.rows_per_launch == n and li.bytes_per_launch == n * d and li.first_stage_rows == 256 * 256
+    assert ref.launch_info(b, k).sketch_scan == 0 and li.sketch_scan == 1 and ske.launch_info(b, 65).sketch_scan == 0
+    assert li.first_stage_rows == 256 * 256 and li.rows_per_launch == n - 65536 and li.bytes_per_launch == (n - 65536) * d
     s0, i0, p0 = _search(ref, q, k)
     s1, i1, p1 = _search(ske, q, k)
     s2, _, p2 = _search(ske, q, k)
@@ -233,7 +234,7 @@ def test_random_geometries_against_the_exact_scan(native_lib, monkeypatch):
     for case in range(16):
         n = int(rng.integers(140_000, 330_000))
         d = int(rng.choice([32, 40, 96, 200, 384, 520, 768, 1000]))
-        k = int(rng.choice([1, 5, 10, 12, 13, 24, 32]))
+        k = int(rng.choice([1, 5, 10, 12, 13, 24, 32, 64]))
         b = int(rng.choice([1, 3, 64, 255, 256, 257, 300]))
         dtype = "fp32" if case % 4 == 3 else "fp16"
         if dtype == "fp32":
@@ -289,3 +290,22 @@ def test_row_major_rescoring_copy_changes_no_bit(native_lib, monkeypatch, dtype,
     copy.close()
     assert np.array_equal(p0, p1) and np.array_equal(s0, s1)
     assert p1[0, :3].tolist() == [5, 70_000, n - 1] and len(set(s1[0, :3].tolist())) == 1
+
+
+def test_first_form_with_an_exact_first_stage_still_agrees(native_lib, monkeypatch):
+    """VQA_SKETCH_CASCADE=0 keeps the round's first form of the search (exact fp16 first stage -> theta -> one sketch scan) as an
+    A / B switch: same rows and bit-equal scores as the cascade (every returned score comes from the same re-scoring kernel)."""
+    n, d, b, k = 210_000, 128, 50, 10
+    rng = np.random.default_rng(4)
+    x, q = _unit(rng, n, d), _unit(rng, b, d)
+    x[[7, 65_536, n - 2]] = x[7]
+    q[0] = x[7]
+    cascade = _index(x, monkeypatch, sketch=True)
+    monkeypatch.setenv("VQA_SKETCH_CASCADE", "0")
+    first = _index(x, monkeypatch, sketch=True)
+    s0, _, p0 = _search(cascade, q, k)
+    s1, _, p1 = _search(first, q, k)
+    cascade.close()
+    first.close()
+    assert np.array_equal(p0, p1) and np.array_equal(s0, s1)
+    assert p0[0, :3].tolist() == [7, 65_536, n - 2]

@@ -78,6 +78,7 @@ struct vqa_index {
     unsigned* cand_cnt = nullptr;           // [256][kSketchSubLists]: keys in every sub-list of a query's list
     int* sketch_flag = nullptr;             // 1 = a candidate buffer filled up: the exact fallback scan runs
     long long* stage_pos = nullptr;         // [256][max_k] row positions of the first stage's top-k
+    bool cascade = true;                    // VQA_SKETCH_CASCADE=0: the exact first stage of the narrow sketch form (dev / A-B switch)
     int* sketch_flag_host = nullptr;        // pinned mirror of sketch_flag, copied behind every sketch search (read by the NEXT call)
     int sketch_cooldown = 0;                // searches left that skip the sketch: data the bound cannot prune would pay the sketch scan
                                             // AND the exact fallback every time (VQA_SKETCH_COOLDOWN searches, default 64, then it tries again)
@@ -366,6 +367,7 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
                 break;
             }
             *ix->sketch_flag_host = 0;
+            if (const char* cs = getenv("VQA_SKETCH_CASCADE")) ix->cascade = cs[0] != '0';
             if (const char* cd = getenv("VQA_SKETCH_COOLDOWN")) ix->sketch_cooldown_len = atoi(cd) > 0 ? atoi(cd) : 0;
             if (hipMemset(ix->rows8, 0, ix->rows8_bytes) != hipSuccess || hipMemset(ix->tile_info, 0, (size_t)tiles * 16) != hipSuccess ||
                 hipMemset(ix->q8_stage, 0, (size_t)VQA_QUERY_TILE * ix->d_pad8) != hipSuccess) {
@@ -459,11 +461,11 @@ struct LaunchPlan {
                              // thresholds at -inf and every list flooding: 0.43 ms per search instead of 0.08)
 };
 
-// The sketch path serves the searches the two-stage plan serves (one exact pass, k <= 12, a large shard) and, in its wide form,
-// k up to kSketchWideMaxK on the same shards (txtai's hybrid search asks the dense index for 10 x limit rows: 30 at its default
-// limit): there the candidates of a query number ~2300 at k = 30 against ~860 at k = 10 and the exact re-scoring (random 64-byte
-// pieces of the tiled index) grows with them -- past 32 the one-pass exact scan is as fast.
-constexpr int kSketchWideMaxK = 32;
+// The sketch search (capi: vqa_index_search) serves large shards -- those the two-stage plan serves -- for k up to kSketchMaxK:
+// txtai's hybrid search asks the dense index for 10 x limit rows (30 at its default limit).  The candidates of a query grow with k
+// (theta sits at rank k: ~860 rows at k = 10, ~2300 at k = 30 of a 10M-row shard) and the exact re-scoring with them; at k = 64
+// the search still takes 3.2 ms against 4.3 ms for the exact one-pass form, at 100 the candidate buffers fill up.
+constexpr int kSketchMaxK = 64;
 
 static LaunchPlan plan_launch(const vqa_index* ix, int k = 0) {
     LaunchPlan p;
@@ -496,10 +498,7 @@ static LaunchPlan plan_launch(const vqa_index* ix, int k = 0) {
         // bound than the seeds' for the main launch over the remaining tiles, and the first stage only needs seeds from
         // half as many tiles.  Both launches flush into one array of 2 x grid lists per query for the final merge.
         if (ix->stage_min_tiles > 0 && p.grid1 == ix->max_grid && p.tiles >= (long long)ix->stage_min_tiles * p.grid1) {
-            // (the wide sketch form scans every row with the sketch anyway, so its first stage is pure extra work that only buys
-            // a tighter theta: 10M rows, k = 30: 2.59 / 2.60 / 2.66 / 2.76 ms at 6 / 8 / 10 / 14 % since re-scoring a pair got cheap)
-            const bool wide_sketch = ix->sketch && k > vqa_score_topk_max_k(ix->dtype) && k <= kSketchWideMaxK;
-            const int pct = wide_sketch ? ix->stage_pct * 7 / 10 : ix->stage_pct;
+            const int pct = ix->stage_pct;
             const int per_wg = (int)((long long)p.tiles * pct / 100 / p.grid1);
             p.stage_tiles = (per_wg > 0 ? per_wg : 1) * p.grid1;
             const int half = p.seed_tiles / 2 > 0 ? p.seed_tiles / 2 : 1;
@@ -511,7 +510,7 @@ static LaunchPlan plan_launch(const vqa_index* ix, int k = 0) {
 }
 
 static bool sketch_active(const vqa_index* ix, const LaunchPlan& p, int k) {
-    return ix->sketch && p.stage_tiles > 0 && p.grid0 > 0 && k <= kSketchWideMaxK;
+    return ix->sketch && p.stage_tiles > 0 && p.grid0 > 0 && k <= kSketchMaxK;
 }
 
 extern "C" int vqa_index_launch_info(const vqa_index* ix, int32_t B, int32_t k, vqa_launch_info* out) {
@@ -523,9 +522,8 @@ extern "C" int vqa_index_launch_info(const vqa_index* ix, int32_t B, int32_t k, 
     out->lds_bytes = vqa_score_topk_lds_bytes(ix->dtype, k);
     out->rows_per_tile = 256;
     out->sketch_scan = sketch_active(ix, p, k) ? 1 : 0;
-    const bool wide_sketch = out->sketch_scan && k > vqa_score_topk_max_k(ix->dtype);  // its sketch scan covers every row
-    out->first_stage_rows = (k <= vqa_score_topk_max_k(ix->dtype) || wide_sketch) ? (int64_t)p.stage_tiles * 256 : 0;
-    out->rows_per_launch = wide_sketch ? ix->n : ix->n - out->first_stage_rows;
+    out->first_stage_rows = (k <= vqa_score_topk_max_k(ix->dtype) || out->sketch_scan) ? (int64_t)p.stage_tiles * 256 : 0;
+    out->rows_per_launch = ix->n - out->first_stage_rows;
     out->pad_ = 0;
     out->bytes_per_launch = out->rows_per_launch * (int64_t)ix->d * (out->sketch_scan ? 1 : elem_bytes(ix->dtype));
     out->flops_per_launch = 2 * (int64_t)VQA_QUERY_TILE * out->rows_per_launch * (int64_t)ix->d;
@@ -596,13 +594,13 @@ static int seed_pass(vqa_index* ix, const LaunchPlan& p, ScoreTopkArgs a, int ra
                                      1.0f, rank, 0, nullptr, true, gate, stream);
 }
 
-// The tail both sketch forms share: theta (ix->thr0) -> per-query constants -> the int8 scan of tiles [tile_begin, tiles) ->
-// exact scores of its candidate pairs (and of `stage_k` first-stage rows per query, ix->stage_pos) -> the k best of every query's
-// list -> the overflow flag to its pinned mirror.  The caller enqueues its exact fallback behind, gated on ix->sketch_flag.
-static int sketch_scan_and_select(vqa_index* ix, const LaunchPlan& p, int tile_begin, int nq, int k, int stage_k, float* os, int64_t* oi,
-                                  int64_t* op, hipStream_t stream) {
+// One sketch scan of tiles [tile_begin, tile_end) against theta = ix->thr0 and the exact scores of what it leaves: per-query
+// constants -> int8 scan -> re-scoring of its candidate pairs (and of `stage_k` first-stage rows per query, ix->stage_pos) into
+// the queries' candidate lists.  `clear`: this is the search's first scan (counters and overflow flag start at zero).
+static int sketch_scan_rescore(vqa_index* ix, const LaunchPlan& p, int tile_begin, int tile_end, int nq, int stage_k, bool clear, bool timed,
+                               hipStream_t stream) {
     int rc = vqa_launch_sketch_qconst(ix->thr0, ix->qrow, ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, ix->d_pad, ix->qconst,
-                                      ix->cand_cnt, ix->sketch_flag, stream);
+                                      ix->cand_cnt, ix->sketch_flag, clear, stream);
     if (rc != VQA_OK) return rc;
     SketchScanArgs sk;
     sk.tile_info = reinterpret_cast<const float4*>(ix->tile_info);
@@ -618,23 +616,26 @@ static int sketch_scan_and_select(vqa_index* ix, const LaunchPlan& p, int tile_b
     b.d_pad = ix->d_pad8;
     b.nq = nq;
     b.k = vqa_score_topk_max_k(ix->dtype);
-    b.thr_init = nullptr;
-    b.partial = nullptr;
     b.tile_begin = tile_begin;
-    b.tile_end = p.tiles;
+    b.tile_end = tile_end;
     b.grid = p.grid1;
     b.sketch = &sk;
-    if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
+    timed = timed && ix->timing;
+    if (timed && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
     rc = vqa_launch_score_topk(VQA_I8_SKETCH, b, stream);
     if (rc != VQA_OK) return rc;
-    if (ix->timing && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
-    rc = vqa_launch_rescore(ix->regions, ix->region_cnt, kSketchCap, p.grid1, stage_k > 0 ? ix->stage_pos : nullptr, nq, stage_k, ix->rows,
-                            ix->rows_rm, ix->q_stage, ix->dtype, ix->d_pad, ix->cand_keys, ix->cand_cnt, kSketchCap, ix->sketch_flag, stream);
+    if (timed && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
+    return vqa_launch_rescore(ix->regions, ix->region_cnt, kSketchCap, p.grid1, stage_k > 0 ? ix->stage_pos : nullptr, nq, stage_k, ix->rows,
+                              ix->rows_rm, ix->q_stage, ix->dtype, ix->d_pad, ix->cand_keys, ix->cand_cnt, kSketchCap, ix->sketch_flag, stream);
+}
+
+// the k best of every query's candidate list -> the caller's outputs (os == nullptr: only their k-th score -> ix->thr0); with
+// outputs, the overflow flag also goes to its pinned mirror.  The caller enqueues its exact fallback behind, gated on ix->sketch_flag.
+static int sketch_select(vqa_index* ix, int nq, int k, float* os, int64_t* oi, int64_t* op, hipStream_t stream) {
+    int rc = vqa_launch_merge_partials(ix->cand_keys, kSketchSubLists, kSketchCap / kSketchSubLists, nq, k, os ? ix->ids : nullptr, ix->id_base, os,
+                                       oi, op, os ? nullptr : ix->thr0, 1.0f, k, 0, nullptr, true, nullptr, stream, kSketchSubLists, ix->cand_cnt);
     if (rc != VQA_OK) return rc;
-    rc = vqa_launch_merge_partials(ix->cand_keys, kSketchSubLists, kSketchCap / kSketchSubLists, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr,
-                                   1.0f, k, 0, nullptr, true, nullptr, stream, kSketchSubLists, ix->cand_cnt);
-    if (rc != VQA_OK) return rc;
-    VQA_HIP_CHECK(hipMemcpyAsync(ix->sketch_flag_host, ix->sketch_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (os) VQA_HIP_CHECK(hipMemcpyAsync(ix->sketch_flag_host, ix->sketch_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
     return VQA_OK;
 }
 
@@ -682,7 +683,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             }
         }
         const bool any_sketch = sketch_active(ix, p, k) && ix->sketch_cooldown == 0;
-        const bool use_sketch = any_sketch && k <= max_k, use_sketch_wide = any_sketch && k > max_k;
+        const bool use_sketch = any_sketch && k <= max_k && !ix->cascade;  // the round's first form (VQA_SKETCH_CASCADE=0: A/B switch)
         if (any_sketch) {  // the query tile's int8 sketch (every query its own scale) + ||q_lo||, ||q||
             rc = vqa_launch_sketch_rows(ix->q_stage, ix->dtype, 0, VQA_QUERY_TILE, ix->d_pad, ix->d_pad8, nullptr, ix->q8_stage, ix->qrow,
                                         ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, stream);
@@ -695,30 +696,44 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
         // the device and raises wide_flag.  The exact continuation passes below are then launched GATED on the flag: they
         // return at once when the one-pass result stands (no host round trip), and overwrite it when it does not.
         const int* gate = nullptr;
-        if (use_sketch_wide) {
-            // 12 < k <= 32 on a sketch shard.  theta = the k-th largest of ANY k distinct exact scores is a valid lower bound of
-            // the k-th best: seeds -> a first-stage launch over stage_tiles tiles in which every workgroup keeps its best 12 above
-            // the seeds' threshold -> the k-th largest key of the union of those lists (-inf when they hold fewer than k: the
-            // sketch scan then overflows into the fallback).  The sketch scan covers EVERY tile (the first stage's too: nothing
-            // needs to be known about which of its rows the 12-deep lists dropped), its candidates are scored exactly and the k
-            // best of each query's list are the result.  An overflow raises sketch_flag: the exact passes below run gated on it.
-            ScoreTopkArgs a = exact_launch_args(ix, nq, max_k);
-            rc = seed_pass(ix, p, a, k, nullptr, stream);
+        if (any_sketch && ix->cascade) {
+            // A sketch shard, k <= 64, as a cascade of bounds -- no exact scan of a first stage at all:
+            //   exact seeds (2 grid tiles: sub-maxima of real rows)  ->  theta0, a valid lower bound of the k-th best score;
+            //   sketch scan of the first stage's tiles against theta0, its candidates scored exactly -> theta1 = the exact k-th best
+            //   score of those rows (every row of theirs that reaches theta0 is a candidate; the seeds' k rows are among them);
+            //   sketch scan of the other tiles against theta1, candidates scored exactly into the same lists; the k best of a list
+            //   are the result.  An overflow anywhere raises sketch_flag, and the exact search runs gated on it: for k <= 12 ONE pass
+            //   over all tiles seeded with theta1 (whatever survived of the lists gives a valid bound), for larger k the gated
+            //   exact passes below.
+            LaunchPlan pc = p;
+            pc.seed_tiles = std::min(2 * p.grid1, p.stage_tiles);  // (1-4 tiles per workgroup x 6-14 % first stage: 2.00-2.03 ms at 10M rows)
+            pc.grid0 = std::min(pc.seed_tiles, ix->max_grid);
+            pc.seeds_per_tile = 2;
+            ScoreTopkArgs a = exact_launch_args(ix, nq, k <= max_k ? k : max_k);
+            rc = seed_pass(ix, pc, a, k, nullptr, stream);
             if (rc != VQA_OK) return rc;
-            a.thr_init = ix->thr0;
-            a.tile_begin = 0;
-            a.tile_end = p.stage_tiles;
-            a.grid = p.grid1;
-            a.seed_only = false;
-            a.first_stage = true;
-            rc = vqa_launch_score_topk(ix->dtype, a, stream);
+            rc = sketch_scan_rescore(ix, p, 0, p.stage_tiles, nq, 0, true, false, stream);
             if (rc != VQA_OK) return rc;
-            rc = vqa_launch_merge_partials(ix->partial, p.grid1, max_k, nq, k, nullptr, 0, nullptr, nullptr, nullptr, ix->thr0, 1.0f, k, 0,
-                                           nullptr, true, nullptr, stream);
+            rc = sketch_select(ix, nq, k, nullptr, nullptr, nullptr, stream);  // theta1 -> thr0
             if (rc != VQA_OK) return rc;
-            rc = sketch_scan_and_select(ix, p, 0, nq, k, 0, os, oi, op, stream);
+            rc = sketch_scan_rescore(ix, p, p.stage_tiles, p.tiles, nq, 0, false, true, stream);
             if (rc != VQA_OK) return rc;
-            gate = ix->sketch_flag;
+            rc = sketch_select(ix, nq, k, os, oi, op, stream);
+            if (rc != VQA_OK) return rc;
+            if (k <= max_k) {
+                a.thr_init = ix->thr0;
+                a.tile_begin = 0;
+                a.tile_end = p.tiles;
+                a.grid = p.grid1;
+                a.gate = ix->sketch_flag;
+                rc = vqa_launch_score_topk(ix->dtype, a, stream);
+                if (rc != VQA_OK) return rc;
+                rc = vqa_launch_merge_partials(ix->partial, p.grid1, k, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr,
+                                               1.0f / (ix->scale * ix->scale), k, 0, nullptr, true, ix->sketch_flag, stream);
+                if (rc != VQA_OK) return rc;
+                continue;
+            }
+            gate = ix->sketch_flag;  // larger k: the gated exact passes below
         } else if (k > max_k && ix->wide && k <= 3 * p.grid1 && p.seed_tiles > 0) {
             ScoreTopkArgs a = exact_launch_args(ix, nq, max_k);
             VQA_HIP_CHECK(hipMemsetAsync(ix->wide_flag, 0, sizeof(int), stream));
@@ -779,12 +794,14 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
                     // first stage's k rows are scored exactly and the k best of each query's list are the result.  Should a
                     // candidate buffer fill up (adversarial data: the bound prunes nothing), sketch_flag sends the search through
                     // the exact main launch below, gated on the flag.
-                    rc = sketch_scan_and_select(ix, p, p.stage_tiles, nq, kk, kk, os, oi, op, stream);
+                    rc = sketch_scan_rescore(ix, p, p.stage_tiles, p.tiles, nq, kk, true, true, stream);
+                    if (rc != VQA_OK) return rc;
+                    rc = sketch_select(ix, nq, kk, os, oi, op, stream);
                     if (rc != VQA_OK) return rc;
                     a.gate = ix->sketch_flag;  // the exact main launch + merge below: only when the flag is up
                 }
             }
-            const bool time_it = ix->timing && !(staged && use_sketch) && !use_sketch_wide;  // a sketch search times its sketch scan instead
+            const bool time_it = ix->timing && !(staged && use_sketch) && !(gate && gate == ix->sketch_flag);  // a sketch search times its sketch scan instead
             if (time_it && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
             rc = vqa_launch_score_topk(ix->dtype, a, stream);
             if (rc != VQA_OK) return rc;

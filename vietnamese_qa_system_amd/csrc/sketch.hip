@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void rows_to_rowmajor_kernel(const uint4* __re
 // candidate counters and the overflow flag of this search
 __global__ void sketch_qconst_kernel(const float* __restrict__ thr, const float* __restrict__ qscale, const float* __restrict__ qlo,
                                      const float* __restrict__ qnorm, float fp_margin, float* __restrict__ qconst,
-                                     unsigned* __restrict__ cand_cnt, int* __restrict__ overflow) {
+                                     unsigned* __restrict__ cand_cnt, int* __restrict__ overflow, int clear) {
     const int q = threadIdx.x;
     qconst[q] = thr[q];
     // The scores a search returns -- and theta -- are fp32 sums, the bound speaks of the real-number dot product: both differ
@@ -135,17 +135,19 @@ __global__ void sketch_qconst_kernel(const float* __restrict__ thr, const float*
     qconst[256 + q] = qlo[q] + fp_margin * qnorm[q];
     qconst[512 + q] = qnorm[q] * (1.0f + fp_margin);
     qconst[768 + q] = 1.0f / qscale[q];
+    if (clear) {  // (the second scan of a cascade keeps what the first one found)
 #pragma unroll
-    for (int j = 0; j < kSketchSubLists; ++j) cand_cnt[q * kSketchSubLists + j] = 0u;
-    if (q == 0) *overflow = 0;
+        for (int j = 0; j < kSketchSubLists; ++j) cand_cnt[q * kSketchSubLists + j] = 0u;
+        if (q == 0) *overflow = 0;
+    }
 }
 
 }  // namespace
 
 int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float* qlo, const float* qnorm, int32_t d, float* qconst,
-                             unsigned* cand_cnt, int* overflow, hipStream_t stream) {
+                             unsigned* cand_cnt, int* overflow, bool clear, hipStream_t stream) {
     const float fp_margin = 2.0f * (float)d * 1.2e-7f;  // 2 gamma_d with gamma_d <= d 2^-24 / (1 - d 2^-24) < 1.2e-7 d / 2 ... kept at twice that
-    hipLaunchKernelGGL(sketch_qconst_kernel, dim3(1), dim3(256), 0, stream, thr, qscale, qlo, qnorm, fp_margin, qconst, cand_cnt, overflow);
+    hipLaunchKernelGGL(sketch_qconst_kernel, dim3(1), dim3(256), 0, stream, thr, qscale, qlo, qnorm, fp_margin, qconst, cand_cnt, overflow, clear ? 1 : 0);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

@@ -154,7 +154,8 @@ int vqa_launch_tile_scales(const void* tiled, int32_t src_dtype, int64_t tile0, 
                            hipStream_t stream);
 // sketch search: per-query constants of the scan + reset of the candidate counters; exact scores of the candidate pairs
 int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float* qlo, const float* qnorm, int32_t d, float* qconst,
-                             unsigned* cand_cnt, int* overflow, hipStream_t stream);
+                             unsigned* cand_cnt, int* overflow, bool clear /* reset the candidate counters and the overflow flag */,
+                             hipStream_t stream);
 int vqa_launch_rescore(const unsigned long long* regions, const unsigned* counts, int cap, int nregions, const long long* stage_pos,
                        int nq, int k, const void* x, const void* x_rowmajor /* or nullptr: the tiled rows x are read */, const void* q,
                        int32_t dtype, int32_t d_pad, vqa_key* cand_keys, unsigned* cand_cnt, int capq, int* overflow, hipStream_t stream);
