@@ -620,6 +620,7 @@ static int sketch_scan_rescore(vqa_index* ix, const LaunchPlan& p, int tile_begi
     b.tile_end = tile_end;
     b.grid = p.grid1;
     b.sketch = &sk;
+    b.first_stage = tile_end < p.tiles;  // (its own kernel symbol in a trace)
     timed = timed && ix->timing;
     if (timed && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
     rc = vqa_launch_score_topk(VQA_I8_SKETCH, b, stream);

@@ -1228,17 +1228,21 @@ static int launch_dt(const ScoreTopkArgs& a, int KT, int lds, hipStream_t stream
     return VQA_OK;
 }
 
-// MODE 2: the int8 sketch scan of a large fp16 shard
+// MODE 2: the int8 sketch scan of a large fp16 / fp32 shard (STAGE 1: the same code under a second symbol for the first-stage scan of
+// the cascade, so that a kernel trace keeps the two launches of a search apart)
 static int launch_sketch(const ScoreTopkArgs& a, int KT, int lds, hipStream_t stream) {
     static VqaPerDeviceOnce once;
     int rc = once.run([&](int) -> int {
         VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<2, VQA_I8_SKETCH, 0, 0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<2, VQA_I8_SKETCH, 1, 0>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         return VQA_OK;
     });
     if (rc != VQA_OK) return rc;
-    hipLaunchKernelGGL((score_topk_kernel<2, VQA_I8_SKETCH, 0, 0>), dim3(a.grid), dim3(kThreads), lds, stream, a.x, a.q, nullptr, nullptr,
-                       nullptr, (long long)a.n, KT, a.nq, a.k, a.tile_begin, a.tile_end, a.gate, a.grid, 0, 2, *a.sketch);
+    auto kern = a.first_stage ? score_topk_kernel<2, VQA_I8_SKETCH, 1, 0> : score_topk_kernel<2, VQA_I8_SKETCH, 0, 0>;
+    hipLaunchKernelGGL(kern, dim3(a.grid), dim3(kThreads), lds, stream, a.x, a.q, nullptr, nullptr, nullptr, (long long)a.n, KT, a.nq, a.k,
+                       a.tile_begin, a.tile_end, a.gate, a.grid, 0, 2, *a.sketch);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }
