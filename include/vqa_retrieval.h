@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VQA_VERSION 104 /* 0.1.4: VQA_INDEX_RESCORE_ROWS, vqa_index_device_bytes (0.1.3: VQA_INDEX_SKETCH, vqa_launch_info.sketch_scan) */
+#define VQA_VERSION 105 /* 0.1.5: vqa_index_sketch_state; 0.1.4: VQA_INDEX_RESCORE_ROWS, vqa_index_device_bytes; 0.1.3: VQA_INDEX_SKETCH */
 
 /* error codes */
 #define VQA_OK 0
@@ -92,6 +92,9 @@ int32_t vqa_index_dim(const vqa_index* index);
 int32_t vqa_index_dtype(const vqa_index* index);
 /* device memory the shard holds: rows + id vector + sketch + re-scoring copy (workspaces of a few MB not counted); -1: null */
 int64_t vqa_index_device_bytes(const vqa_index* index);
+/* -1: the shard keeps no sketch; 0: its searches take the sketch search; n > 0: a sketch search overflowed into its exact fallback
+ * (data the bound cannot prune) and the next n searches of this handle run the exact scan (call it after the searches completed) */
+int32_t vqa_index_sketch_state(const vqa_index* index);
 
 /* ---- search: replaces the scoring + top-k inside Embeddings.search / batchsearch (heavy_ranker.py:98,100) ---
  * q: [B, d] DEVICE pointer, element type q_dtype (VQA_F32 or VQA_F16; converted to the index storage type with

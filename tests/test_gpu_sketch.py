@@ -309,3 +309,29 @@ def test_first_form_with_an_exact_first_stage_still_agrees(native_lib, monkeypat
     first.close()
     assert np.array_equal(p0, p1) and np.array_equal(s0, s1)
     assert p0[0, :3].tolist() == [7, 65_536, n - 2]
+
+
+@pytest.mark.parametrize("b", [1, 3])
+def test_one_query_with_thousands_of_candidates_stays_on_the_sketch(native_lib, monkeypatch, b):
+    """A single query whose neighbourhood holds 5000 near-duplicates scattered over the shard: every one of them is a candidate.
+    The candidate list of a query is 16 sub-lists of 1024; they must fill evenly whatever the batch size (a first form picked
+    the sub-list by the pair's position in its scan region alone: with one query every region's first pairs landed in the same
+    three sub-lists and a 10M-row shard fell back to the exact scan for B = 1 and for the last query tile of B = 257)."""
+    n, d, k = 300_000, 64, 10
+    rng = np.random.default_rng(12)
+    x = _unit(rng, n, d)
+    q = _unit(rng, b, d)
+    near = rng.choice(n, 5000, replace=False)
+    x[near] = R.l2_normalize(q[0].astype(np.float32)[None, :] + 0.01 * rng.standard_normal((5000, d)).astype(np.float32)).astype(np.float16)
+    ref = _index(x, monkeypatch, sketch=False)
+    ske = _index(x, monkeypatch, sketch=True)
+    assert ske.sketch_state() == 0 and ref.sketch_state() == -1
+    s0, _, p0 = _search(ref, q, k)
+    s1, _, p1 = _search(ske, q, k)
+    state = ske.sketch_state()
+    ref.close()
+    ske.close()
+    assert state == 0, "the sketch search overflowed into its exact fallback"
+    assert np.abs(s1 - s0).max() <= 3e-7
+    diff = p1 != p0
+    assert np.all(np.abs(s1[diff] - s0[diff]) <= TIE_TOL)

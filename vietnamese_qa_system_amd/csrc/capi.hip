@@ -446,6 +446,13 @@ extern "C" int vqa_index_get_rows(vqa_index* ix, int64_t first, int64_t count, v
 extern "C" int64_t vqa_index_size(const vqa_index* ix) { return ix ? ix->n : -1; }
 extern "C" int32_t vqa_index_dim(const vqa_index* ix) { return ix ? ix->d : -1; }
 extern "C" int32_t vqa_index_dtype(const vqa_index* ix) { return ix ? ix->dtype : -1; }
+extern "C" int32_t vqa_index_sketch_state(const vqa_index* ix) {
+    if (!ix || !ix->sketch) return -1;
+    // (the flag of the last sketch search arrives in the pinned mirror when that search has completed)
+    if (__atomic_load_n(ix->sketch_flag_host, __ATOMIC_RELAXED) != 0) return ix->sketch_cooldown_len > 0 ? ix->sketch_cooldown_len : 1;
+    return ix->sketch_cooldown;
+}
+
 extern "C" int64_t vqa_index_device_bytes(const vqa_index* ix) {
     if (!ix) return -1;
     int64_t b = (int64_t)ix->rows_bytes + (ix->ids ? ix->n * 8 : 0);

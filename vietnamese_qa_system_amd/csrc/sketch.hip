@@ -62,7 +62,9 @@ __global__ __launch_bounds__(256) void rescore_kernel(const unsigned long long* 
         }
     };
     for (int i0 = wave * 4; i0 < total; i0 += nwaves * 4) {
-        const unsigned sub = (unsigned)(i0 >> 2) % kSketchSubLists;  // the four pairs of this iteration share a sub-list index
+        // the four pairs of this iteration share a sub-list index: region + position inside it, so that both a query with a few
+        // candidates per region (B = 1: every region's first pairs) and one with thousands in ONE region use all the sub-lists
+        const unsigned sub = (unsigned)(y + (i0 >> 2)) % kSketchSubLists;
         int q[2];
         long long pos[2];
         pair_of(i0 + half, q[0], pos[0]);

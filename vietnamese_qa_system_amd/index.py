@@ -226,6 +226,10 @@ class DeviceIndex:
         """Device memory the shard holds: rows + id vector + int8 sketch + re-scoring copy."""
         return int(self._lib.vqa_index_device_bytes(self._handle))
 
+    def sketch_state(self) -> int:
+        """-1: no sketch; 0: searches take the sketch search; n > 0: an overflow sent the next n searches to the exact scan."""
+        return int(self._lib.vqa_index_sketch_state(self._handle))
+
     def launch_info(self, b: int, k: int) -> N.LaunchInfo:
         info = N.LaunchInfo()
         N.check(self._lib.vqa_index_launch_info(self._handle, int(b), int(k), ctypes.byref(info)), "vqa_index_launch_info")
