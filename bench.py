@@ -274,6 +274,7 @@ def main():
         elapsed = float(t.item())
     info = index.launch_info(b, k)
     device_bytes = index.device_bytes()
+    sketch_state = index.sketch_state()
     # multi-batch steady state through search_pipelined (the all-gather of batch i hidden under the scan of batch i + 1;
     # at N = 1 the same four scans back to back): S = 4 resident query batches per call, outside the headline's timed region
     S = 4
@@ -348,6 +349,8 @@ def main():
                          # what the shard holds on the device: the rows as stored + the int8 sketch (+50 %) + the row-major copy the
                          # sketch search re-scores its survivors from (+100 %; VQA_RESCORE_COPY=0 does without: re-scoring 3x slower)
                          "device_bytes": device_bytes,
+                         # 0: every timed search took the sketch search (no overflow into its exact fallback); -1: no sketch kept
+                         "sketch_state": sketch_state,
                          "whole_step_frac": round(n * d * esize / (float(np.median(step_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          # the ceiling this box's HBM really gives a plain stream: a 1 GiB device-to-device copy (torch's copy
                          # kernel), bytes read + written over its event time, in this process

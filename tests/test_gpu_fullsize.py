@@ -101,6 +101,16 @@ def test_full_size_properties(native_lib, shard):
         s2, i2, _ = full.search(q, K)
         assert torch.equal(s2, s) and torch.equal(i2, i)
 
+    # ---- the shard is searched through its int8 sketch, and neither the full batch nor a single query, a ragged last query tile
+    # or a wide k overflowed into the exact fallback (which would silently switch the sketch off for the next searches)
+    assert full.launch_info(q.shape[0], K).sketch_scan == 1
+    ragged = torch.cat([q, q[:1]])  # one query in the last tile
+    for qs, kk, rows in ((q[:1], K, [0]), (ragged, K, list(range(q.shape[0])) + [0]), (q[:64], 30, list(range(64)))):
+        sq, iq, _ = full.search(qs, kk)
+        torch.cuda.synchronize()
+        assert torch.equal(sq[:, :K], s[rows]) and torch.equal(iq[:, :K], i[rows])
+    assert full.sketch_state() == 0
+
     # ---- planted needles: self-score = sum of squares of the stored fp16 values; the copy further down ties with it
     qq = q[:32].float().cpu().numpy()
     self_score = (qq.astype(np.float64) ** 2).sum(1)
