@@ -161,7 +161,9 @@ class Embeddings:
                 raise ValueError("a row producer needs total= (rows of the whole corpus)")
             n = int(total)
             lo, hi = shard_bounds(n, self.world, self.rank)
-            first = producer(lo, min(hi, lo + 1)) if hi > lo else producer(0, 1)
+            # the shard's first chunk tells the dimension and is stored as it is (no one-row probe: a producer may be stateful --
+            # a tokenizer feeding from a stream -- and an encoder call for one row would be paid twice); an empty shard asks row 0
+            first = producer(lo, min(hi, lo + chunk_rows)) if hi > lo else producer(0, min(1, n))
             first = torch.from_numpy(np.ascontiguousarray(first)) if isinstance(first, np.ndarray) else first
             d, v = int(first.shape[1]), None
             vdtype = first.dtype
@@ -233,7 +235,7 @@ class Embeddings:
                                             with_ids=dev_ids is not None)
             for c0 in range(lo, hi, chunk_rows):
                 c1 = min(hi, c0 + chunk_rows)
-                rows = first if (c0 == lo and c1 == lo + 1) else producer(c0, c1)
+                rows = first if c0 == lo else producer(c0, c1)
                 self._index.set_rows(c0 - lo, rows, dev_ids[c0 - lo:c1 - lo] if dev_ids is not None else None, normalize=normalize)
         self._searcher = ShardedSearcher(self._local_search, None, self.group)
         self.n, self.d, self._lo = n, d, lo
