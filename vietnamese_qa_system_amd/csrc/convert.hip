@@ -159,7 +159,91 @@ __device__ __forceinline__ void load_sketch_unit(const SRC* __restrict__ tiled, 
     }
 }
 
-template <typename SRC>
+// ---- rotation of a row before it is sketched (ROT).  One scale per tile means the largest component sets the quantisation step of
+// all the others: a few outlier dimensions (what RoBERTa-family encoders emit) widen the bound's slack six-fold.  The sketch is
+// therefore cut from T x instead of x, T = H D: random signs D (a fixed hash of the element index) and a normalised Walsh-Hadamard
+// transform H of every power-of-two block of the padded row (768 = 512 + 256; blocks of >= 128 elements), applied in fp32 to
+// rows at build time and to the query tile per search.  T is orthogonal, (T q) . (T x) = q . x, so the bound holds unchanged on
+// the rotated quantities (the norms below are those of T x); its coordinates are near-Gaussian whatever the input's.  Rounding:
+// log2(B) <= 13 butterfly stages of one fp32 add each, |T^ x - T x| <= 13 2^-24 ||x|| -- vqa_launch_sketch_qconst adds it to the margin.
+// Row layout in a wave (sketch_rows_kernel): element j = 16 (lane + 64 i) + e sits in x[i][e] of `lane`.
+constexpr int kSketchMaxPer = 8;  // rows of up to 8 * 64 * 16 = 8192 elements
+
+__device__ __forceinline__ int sketch_block_of(int j, int d8) {  // size of the power-of-two block of the padded row that holds element j
+    int off = 0, rem = d8;
+    for (;;) {
+        const int b = 1 << (31 - __builtin_clz(rem));
+        if (j < off + b || rem == b) return b;
+        off += b;
+        rem -= b;
+    }
+}
+
+__device__ __forceinline__ void sketch_rotate(float (&x)[kSketchMaxPer][16], int lane, int d8) {
+    float bs[kSketchMaxPer];  // block size of this lane's elements of register group i (0: past the row)
+#pragma unroll
+    for (int i = 0; i < kSketchMaxPer; ++i) {
+        const int j0 = 16 * (lane + 64 * i);
+        bs[i] = j0 < d8 ? (float)sketch_block_of(j0, d8) : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {  // D: sign of element j from a fixed, well-mixed hash (a bit of a plain multiplicative hash
+            // of consecutive j is close to a Walsh function: H D would map a constant row onto a few huge coordinates)
+            unsigned h = (unsigned)(j0 + e) + 0x9E3779B9u;
+            h ^= h >> 16;
+            h *= 0x85EBCA6Bu;
+            h ^= h >> 13;
+            h *= 0xC2B2AE35u;
+            h ^= h >> 16;
+            x[i][e] = (h & 1u) ? -x[i][e] : x[i][e];
+        }
+    }
+    // bits 0-3 of j: inside the 16 registers of a group (every block has at least 128 elements)
+#pragma unroll
+    for (int b = 1; b < 16; b <<= 1)
+#pragma unroll
+        for (int i = 0; i < kSketchMaxPer; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (!(e & b)) {
+                    const float u = x[i][e], v = x[i][e | b];
+                    x[i][e] = u + v;
+                    x[i][e | b] = u - v;
+                }
+    // bits 4-9: across lanes (partner lane ^ m; both inside the same block when 16 * 2 m <= block size)
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1)
+#pragma unroll
+        for (int i = 0; i < kSketchMaxPer; ++i) {
+            const bool on = bs[i] >= (float)(32 * m);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float v = x[i][e], p = __shfl_xor(v, m, 64);
+                x[i][e] = !on ? v : (lane & m) ? p - v : v + p;
+            }
+        }
+    // bits 10-12: across the register groups (blocks of 2048 elements and more)
+#pragma unroll
+    for (int m = 1; m < kSketchMaxPer; m <<= 1)
+#pragma unroll
+        for (int i = 0; i < kSketchMaxPer; ++i)
+            if (!(i & m)) {
+                const bool on = bs[i] >= (float)(2048 * m);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float u = x[i][e], v = x[i | m][e];
+                    x[i][e] = on ? u + v : u;
+                    x[i | m][e] = on ? u - v : v;
+                }
+            }
+#pragma unroll
+    for (int i = 0; i < kSketchMaxPer; ++i) {
+        const float nrm = bs[i] > 0.f ? rsqrtf(bs[i]) : 0.f;  // H / sqrt(B): orthonormal (B a power of two: exact for even log2, one rounding else)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x[i][e] *= nrm;
+    }
+}
+
+template <typename SRC, bool ROT>
 __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict__ tiled, long long first, long long count,
                                                           int KTS, int KT8, const float* tile_info, int8_t* __restrict__ out8,
                                                           float* __restrict__ row_scale, float* __restrict__ row_lo,
@@ -170,7 +254,7 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
     const long long row = first + ri;
     const int units8 = KT8 * 4;
     // this lane's int8 units u = lane, lane + 64, ...
-    constexpr int kMaxPer = 8;  // rows of up to 8 * 64 * 16 = 8192 elements
+    constexpr int kMaxPer = kSketchMaxPer;
     float x[kMaxPer][16];
     float amax = 0.f;
 #pragma unroll
@@ -180,9 +264,12 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
         else
 #pragma unroll
             for (int e = 0; e < 16; ++e) x[i][e] = 0.f;
+    }
+    if constexpr (ROT) sketch_rotate(x, lane, units8 * 16);
+#pragma unroll
+    for (int i = 0; i < kMaxPer; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) amax = fmaxf(amax, fabsf(x[i][e]));
-    }
     float s = tile_info ? tile_info[4 * (row >> 8) + 3] : 0.f;  // index rows: the scale of the row's tile
     if (!(s > 0.f)) {
 #pragma unroll
@@ -235,18 +322,38 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
 
 // one workgroup per tile of a TILED fp16 / fp32 array: scale = max |x| over the tile's 256 rows / 127 (a tile of zeros: 1), written
 // with its reciprocal to tile_info[tile] = (0, 0, 1 / scale, scale) -- the two maxima are cleared for sketch_rows_kernel to fill
-template <typename SRC>
-__global__ __launch_bounds__(256) void tile_scale_kernel(const SRC* __restrict__ tiled, long long tile0, int KTS,
+template <typename SRC, bool ROT>
+__global__ __launch_bounds__(256) void tile_scale_kernel(const SRC* __restrict__ tiled, long long tile0, int KTS, int KT8,
                                                          float* __restrict__ tile_info) {
     constexpr int EPU = 16 / (int)sizeof(SRC);
     __shared__ float red[4];
     const long long tile = tile0 + blockIdx.x;
-    const SRC* base = tiled + (size_t)tile * KTS * 1024 * EPU;  // the tile's KTS blocks of 16 KiB are contiguous
     float m = 0.f;
+    if constexpr (ROT) {  // the maximum is that of the ROTATED rows: every wave rotates 64 of the tile's rows
+        const int lane = threadIdx.x & 63, units8 = KT8 * 4;
+        for (int r = threadIdx.x >> 6; r < 256; r += 4) {
+            float x[kSketchMaxPer][16];
+#pragma unroll
+            for (int i = 0; i < kSketchMaxPer; ++i) {
+                const int u = lane + 64 * i;
+                if (u < units8) load_sketch_unit<SRC>(tiled, tile * 256 + r, u, KTS, x[i]);
+                else
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) x[i][e] = 0.f;
+            }
+            sketch_rotate(x, lane, units8 * 16);
+#pragma unroll
+            for (int i = 0; i < kSketchMaxPer; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) m = fmaxf(m, fabsf(x[i][e]));
+        }
+    } else {
+    const SRC* base = tiled + (size_t)tile * KTS * 1024 * EPU;  // the tile's KTS blocks of 16 KiB are contiguous
     for (int u = threadIdx.x; u < KTS * 1024; u += 256) {
         const SRC* p = base + (size_t)u * EPU;
 #pragma unroll
         for (int e = 0; e < EPU; ++e) m = fmaxf(m, fabsf((float)p[e]));
+    }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
@@ -336,33 +443,42 @@ extern "C" int vqa_normalize_convert(const float* rows, int64_t n, int32_t d, in
 }
 
 int vqa_launch_sketch_rows(const void* tiled, int32_t src_dtype, int64_t first, int64_t count, int32_t d_pad_src, int32_t d_pad8,
-                           const float* tile_info, void* out8, float* row_scale, float* row_lo, float* row_norm, hipStream_t stream) {
+                           const float* tile_info, void* out8, float* row_scale, float* row_lo, float* row_norm, bool rotate,
+                           hipStream_t stream) {
     if (count == 0) return VQA_OK;
     VQA_REQUIRE(src_dtype == VQA_F16 || src_dtype == VQA_F32, "sketch_rows: source type %d", src_dtype);
     VQA_REQUIRE(d_pad8 / 16 <= 8 * 64, "sketch_rows: rows of %d elements are too long for the int8 sketch", d_pad8);
     const dim3 grid((unsigned)((count + 3) / 4));
     unsigned* tmax = reinterpret_cast<unsigned*>(const_cast<float*>(tile_info));
-    if (src_dtype == VQA_F16)
-        hipLaunchKernelGGL(sketch_rows_kernel<_Float16>, grid, dim3(256), 0, stream, reinterpret_cast<const _Float16*>(tiled),
-                           (long long)first, (long long)count, d_pad_src / 32, d_pad8 / 64, tile_info, reinterpret_cast<int8_t*>(out8),
-                           row_scale, row_lo, row_norm, tmax);
-    else
-        hipLaunchKernelGGL(sketch_rows_kernel<float>, grid, dim3(256), 0, stream, reinterpret_cast<const float*>(tiled),
-                           (long long)first, (long long)count, d_pad_src / 16, d_pad8 / 64, tile_info, reinterpret_cast<int8_t*>(out8),
-                           row_scale, row_lo, row_norm, tmax);
+#define VQA_SKROWS(T, ROT, KTSV)                                                                                                  \
+    hipLaunchKernelGGL((sketch_rows_kernel<T, ROT>), grid, dim3(256), 0, stream, reinterpret_cast<const T*>(tiled), (long long)first, \
+                       (long long)count, KTSV, d_pad8 / 64, tile_info, reinterpret_cast<int8_t*>(out8), row_scale, row_lo, row_norm, tmax)
+    if (src_dtype == VQA_F16) {
+        if (rotate) VQA_SKROWS(_Float16, true, d_pad_src / 32);
+        else VQA_SKROWS(_Float16, false, d_pad_src / 32);
+    } else {
+        if (rotate) VQA_SKROWS(float, true, d_pad_src / 16);
+        else VQA_SKROWS(float, false, d_pad_src / 16);
+    }
+#undef VQA_SKROWS
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }
 
-int vqa_launch_tile_scales(const void* tiled, int32_t src_dtype, int64_t tile0, int64_t ntiles, int32_t d_pad_src, float* tile_info,
-                           hipStream_t stream) {
+int vqa_launch_tile_scales(const void* tiled, int32_t src_dtype, int64_t tile0, int64_t ntiles, int32_t d_pad_src, int32_t d_pad8,
+                           float* tile_info, bool rotate, hipStream_t stream) {
     if (ntiles == 0) return VQA_OK;
-    if (src_dtype == VQA_F16)
-        hipLaunchKernelGGL(tile_scale_kernel<_Float16>, dim3((unsigned)ntiles), dim3(256), 0, stream,
-                           reinterpret_cast<const _Float16*>(tiled), (long long)tile0, d_pad_src / 32, tile_info);
-    else
-        hipLaunchKernelGGL(tile_scale_kernel<float>, dim3((unsigned)ntiles), dim3(256), 0, stream, reinterpret_cast<const float*>(tiled),
-                           (long long)tile0, d_pad_src / 16, tile_info);
+#define VQA_TSCALE(T, ROT, KTSV)                                                                                               \
+    hipLaunchKernelGGL((tile_scale_kernel<T, ROT>), dim3((unsigned)ntiles), dim3(256), 0, stream, reinterpret_cast<const T*>(tiled), \
+                       (long long)tile0, KTSV, d_pad8 / 64, tile_info)
+    if (src_dtype == VQA_F16) {
+        if (rotate) VQA_TSCALE(_Float16, true, d_pad_src / 32);
+        else VQA_TSCALE(_Float16, false, d_pad_src / 32);
+    } else {
+        if (rotate) VQA_TSCALE(float, true, d_pad_src / 16);
+        else VQA_TSCALE(float, false, d_pad_src / 16);
+    }
+#undef VQA_TSCALE
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

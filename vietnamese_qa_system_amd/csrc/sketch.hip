@@ -147,8 +147,10 @@ __global__ void sketch_qconst_kernel(const float* __restrict__ thr, const float*
 }  // namespace
 
 int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float* qlo, const float* qnorm, int32_t d, float* qconst,
-                             unsigned* cand_cnt, int* overflow, bool clear, hipStream_t stream) {
-    const float fp_margin = 2.0f * (float)d * 1.2e-7f;  // 2 gamma_d with gamma_d <= d 2^-24 / (1 - d 2^-24) < 1.2e-7 d / 2 ... kept at twice that
+                             unsigned* cand_cnt, int* overflow, bool clear, bool rotated, hipStream_t stream) {
+    // 2 gamma_d with gamma_d <= d 2^-24 / (1 - d 2^-24) < 1.2e-7 d / 2 ... kept at twice that; a rotated sketch adds the rounding of
+    // the two rotations (13 butterfly stages + the normalisation: 14 2^-24 per side, kept at twice that too)
+    const float fp_margin = 2.0f * (float)d * 1.2e-7f + (rotated ? 4.0f * 14.0f * 6e-8f : 0.f);
     hipLaunchKernelGGL(sketch_qconst_kernel, dim3(1), dim3(256), 0, stream, thr, qscale, qlo, qnorm, fp_margin, qconst, cand_cnt, overflow, clear ? 1 : 0);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
