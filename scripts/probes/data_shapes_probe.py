@@ -25,6 +25,9 @@ def make(kind, m):
         pass
     elif kind == "two outlier dimensions (20x)":
         x[:, 77] *= 20; x[:, 588] *= 20
+    elif kind == "two constant outlier dimensions (mean cosine 0.5)":
+        x = unit(x)
+        x[:, 77] += 0.7; x[:, 588] += 0.7
     elif kind == "common component (mean cosine 0.5)":
         x = unit(x) + torch.ones(d, device=dev) / d ** 0.5
     elif kind == "1000 clusters, within-cluster sigma 0.3":
@@ -49,7 +52,7 @@ def timed(ix, q):
     return (time.perf_counter() - t0) / 10 * 1e3
 
 
-for kind in ("isotropic", "two outlier dimensions (20x)", "common component (mean cosine 0.5)", "1000 clusters, within-cluster sigma 0.3",
+for kind in ("isotropic", "two outlier dimensions (20x)", "two constant outlier dimensions (mean cosine 0.5)", "common component (mean cosine 0.5)", "1000 clusters, within-cluster sigma 0.3",
              "50 tight clusters, sigma 0.05", "low rank 32 + 10 % noise"):
     x = torch.cat([make(kind, 1 << 19) for _ in range(0, n, 1 << 19)])[:n]
     q = make(kind, b)

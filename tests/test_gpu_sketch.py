@@ -335,3 +335,43 @@ def test_one_query_with_thousands_of_candidates_stays_on_the_sketch(native_lib, 
     assert np.abs(s1 - s0).max() <= 3e-7
     diff = p1 != p0
     assert np.all(np.abs(s1[diff] - s0[diff]) <= TIE_TOL)
+
+
+@pytest.mark.parametrize("shape", ["common component", "constant outlier dimensions", "wide outlier dimensions"])
+def test_anisotropic_rows_stay_on_the_sketch_and_agree(native_lib, monkeypatch, shape):
+    """Embeddings of one encoder are not isotropic: a large common component (mean cosine 0.5), a few dimensions with huge constant
+    values, or with huge variance.  The sketch is cut from the centred, rotated rows (convert.hip: sketch_rotate; the centre is
+    the mean of the shard's first fill), which keeps the quantiser's range on what distinguishes rows: such shards stay on the
+    sketch search -- and return the exact scan's rows, whatever the chunking of the fill."""
+    from vietnamese_qa_system_amd.index import DeviceIndex
+    n, d, b, k = 260_000, 256, 64, 10
+    rng = np.random.default_rng(41)
+    def make(m):
+        x = R.l2_normalize(rng.standard_normal((m, d)).astype(np.float32))
+        if shape == "common component":
+            x = x + np.ones(d, np.float32) / np.sqrt(d)
+        elif shape == "constant outlier dimensions":
+            x[:, 7] += 0.7
+            x[:, 200] -= 0.7
+        else:
+            x[:, 7] *= 20
+            x[:, 200] *= 20
+        return R.l2_normalize(x).astype(np.float16)
+    x, q = make(n), make(b)
+    x[[11, 70_000, n - 3]] = x[11]
+    q[0] = x[11]
+    ref = _index(x, monkeypatch, sketch=False)
+    monkeypatch.setenv("VQA_STAGE_MIN", "2")
+    ske = DeviceIndex.empty(n, d, dtype="fp16", device=0, sketch=True)
+    for lo, hi in ((0, 100_001), (100_001, n)):  # the centre comes from the first fill; the second chunk is cut against it too
+        ske.set_rows(lo, x[lo:hi])
+    s0, _, p0 = _search(ref, q, k)
+    s1, _, p1 = _search(ske, q, k)
+    state = ske.sketch_state()
+    ref.close()
+    ske.close()
+    assert state == 0, "the sketch search overflowed into its exact fallback"
+    assert np.abs(s1 - s0).max() <= 6e-7
+    diff = p1 != p0
+    assert np.all(np.abs(s1[diff] - s0[diff]) <= TIE_TOL) and diff.mean() < 0.01
+    assert p1[0, :3].tolist() == [11, 70_000, n - 3] and len(set(s1[0, :3].tolist())) == 1

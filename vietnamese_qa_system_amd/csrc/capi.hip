@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <atomic>
 #include <thread>
 #include <vector>
@@ -78,6 +79,11 @@ struct vqa_index {
     unsigned* cand_cnt = nullptr;           // [256][kSketchSubLists]: keys in every sub-list of a query's list
     int* sketch_flag = nullptr;             // 1 = a candidate buffer filled up: the exact fallback scan runs
     long long* stage_pos = nullptr;         // [256][max_k] row positions of the first stage's top-k
+    float* mu = nullptr;                    // [d_pad8] centre of the shard (mean of the rows of its first fill), subtracted before the sketch
+    float* qoff = nullptr;                  // [256] q . mu of the query tile
+    float mu_norm = 0.f;
+    bool mu_set = false;
+    bool center = true;                     // VQA_SKETCH_CENTER=0: no centring (needs the rotated form)
     bool rotate = true;                     // the sketch is cut from rotated rows (convert.hip: sketch_rotate); VQA_SKETCH_ROTATE=0: from the rows as they are
     bool cascade = true;                    // VQA_SKETCH_CASCADE=0: the exact first stage of the narrow sketch form (dev / A-B switch)
     int* sketch_flag_host = nullptr;        // pinned mirror of sketch_flag, copied behind every sketch search (read by the NEXT call)
@@ -132,6 +138,8 @@ extern "C" void vqa_index_destroy(vqa_index* ix) {
                     (void*)ix->stage_pos})
         if (p) (void)hipFree(p);
     if (ix->rows_rm) (void)hipFree(ix->rows_rm);
+    if (ix->mu) (void)hipFree(ix->mu);
+    if (ix->qoff) (void)hipFree(ix->qoff);
     if (ix->sketch_flag_host) (void)hipHostFree(ix->sketch_flag_host);
     if (ix->partial) (void)hipFree(ix->partial);
     if (ix->thr0) (void)hipFree(ix->thr0);
@@ -237,11 +245,23 @@ extern "C" int vqa_index_set_rows(vqa_index* ix, int64_t first, int64_t count, c
         // several calls always ends up consistent
         VQA_HIP_CHECK(hipStreamSynchronize(nullptr));
         const int64_t t0 = first >> 8, t1 = (first + count - 1) >> 8;
-        int rc = vqa_launch_tile_scales(ix->rows, ix->dtype, t0, t1 - t0 + 1, ix->d_pad, ix->d_pad8, ix->tile_info, ix->rotate, nullptr);
+        if (ix->center && !ix->mu_set) {
+            // the shard's centre: the mean of (up to 65 536 of) the rows of its FIRST fill, fixed from then on -- every tile's sketch
+            // must be cut against the same centre; any centre is valid (q . x = q . mu + q . (x - mu)), a good one shortens the rows
+            int rcm = vqa_launch_row_mean(ix->rows, ix->dtype, first, std::min<int64_t>(count, 65536), ix->d_pad, ix->d_pad8, ix->mu, nullptr);
+            if (rcm != VQA_OK) return rcm;
+            std::vector<float> h((size_t)ix->d_pad8);
+            VQA_HIP_CHECK(hipMemcpy(h.data(), ix->mu, h.size() * 4, hipMemcpyDeviceToHost));
+            double n2 = 0.0;
+            for (float v : h) n2 += (double)v * v;
+            ix->mu_norm = (float)(std::sqrt(n2) * (1.0 + 1e-6));
+            ix->mu_set = true;
+        }
+        int rc = vqa_launch_tile_scales(ix->rows, ix->dtype, t0, t1 - t0 + 1, ix->d_pad, ix->d_pad8, ix->tile_info, ix->rotate, ix->center ? ix->mu : nullptr, nullptr);
         if (rc != VQA_OK) return rc;
         const int64_t r0 = t0 * 256, r1 = std::min<int64_t>(ix->n, (t1 + 1) * 256);
         rc = vqa_launch_sketch_rows(ix->rows, ix->dtype, r0, r1 - r0, ix->d_pad, ix->d_pad8, ix->tile_info, ix->rows8, nullptr, nullptr,
-                                    nullptr, ix->rotate, nullptr);
+                                    nullptr, ix->rotate, ix->center ? ix->mu : nullptr, true, nullptr, nullptr);
         if (rc != VQA_OK) return rc;
         if (ix->rows_rm) {  // the same stored values, row-major
             rc = vqa_launch_rows_to_rowmajor(ix->rows, first, count, ix->d_pad * elem_bytes(ix->dtype), ix->rows_rm, nullptr);
@@ -373,6 +393,15 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
             *ix->sketch_flag_host = 0;
             if (const char* cs = getenv("VQA_SKETCH_CASCADE")) ix->cascade = cs[0] != '0';
             if (const char* ro = getenv("VQA_SKETCH_ROTATE")) ix->rotate = ro[0] != '0';
+            if (const char* ce = getenv("VQA_SKETCH_CENTER")) ix->center = ce[0] != '0';
+            ix->center = ix->center && ix->rotate;
+            if (ix->center && (hipMalloc((void**)&ix->mu, (size_t)ix->d_pad8 * 4) != hipSuccess ||
+                               hipMalloc((void**)&ix->qoff, VQA_QUERY_TILE * 4) != hipSuccess ||
+                               hipMemset(ix->mu, 0, (size_t)ix->d_pad8 * 4) != hipSuccess)) {
+                vqa_set_error("vqa_index_create: allocating the sketch's centre failed");
+                rc = VQA_ENOMEM;
+                break;
+            }
             if (const char* cd = getenv("VQA_SKETCH_COOLDOWN")) ix->sketch_cooldown_len = atoi(cd) > 0 ? atoi(cd) : 0;
             if (hipMemset(ix->rows8, 0, ix->rows8_bytes) != hipSuccess || hipMemset(ix->tile_info, 0, (size_t)tiles * 16) != hipSuccess ||
                 hipMemset(ix->q8_stage, 0, (size_t)VQA_QUERY_TILE * ix->d_pad8) != hipSuccess) {
@@ -612,7 +641,7 @@ static int seed_pass(vqa_index* ix, const LaunchPlan& p, ScoreTopkArgs a, int ra
 static int sketch_scan_rescore(vqa_index* ix, const LaunchPlan& p, int tile_begin, int tile_end, int nq, int stage_k, bool clear, bool timed,
                                hipStream_t stream) {
     int rc = vqa_launch_sketch_qconst(ix->thr0, ix->qrow, ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, ix->d_pad, ix->qconst,
-                                      ix->cand_cnt, ix->sketch_flag, clear, ix->rotate, stream);
+                                      ix->cand_cnt, ix->sketch_flag, clear, ix->rotate, ix->center ? ix->qoff : nullptr, ix->mu_norm, stream);
     if (rc != VQA_OK) return rc;
     SketchScanArgs sk;
     sk.tile_info = reinterpret_cast<const float4*>(ix->tile_info);
@@ -699,7 +728,8 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
         const bool use_sketch = any_sketch && k <= max_k && !ix->cascade;  // the round's first form (VQA_SKETCH_CASCADE=0: A/B switch)
         if (any_sketch) {  // the query tile's int8 sketch (every query its own scale) + ||q_lo||, ||q||
             rc = vqa_launch_sketch_rows(ix->q_stage, ix->dtype, 0, VQA_QUERY_TILE, ix->d_pad, ix->d_pad8, nullptr, ix->q8_stage, ix->qrow,
-                                        ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, ix->rotate, stream);
+                                        ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, ix->rotate, ix->center ? ix->mu : nullptr,
+                                        false, ix->qoff, stream);
             if (rc != VQA_OK) return rc;
         }
         // k <= 12: one pass.  Larger k, first attempt: ONE pass in which every workgroup keeps its local top 12 above the

@@ -243,11 +243,15 @@ __device__ __forceinline__ void sketch_rotate(float (&x)[kSketchMaxPer][16], int
     }
 }
 
+// mu (or null): the shard's centre, d8 floats.  Index rows (center = 1) are sketched as T (x - mu): embeddings of one encoder share a
+// large common component (mean cosine 0.5 and more), which would otherwise eat the quantiser's range; q . x = q . mu + q . (x - mu), so
+// the query side (center = 0) only reports q . mu (row_off) and the scan's threshold moves by it (sketch_qconst_kernel).
 template <typename SRC, bool ROT>
 __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict__ tiled, long long first, long long count,
                                                           int KTS, int KT8, const float* tile_info, int8_t* __restrict__ out8,
                                                           float* __restrict__ row_scale, float* __restrict__ row_lo,
-                                                          float* __restrict__ row_norm, unsigned* tile_max /* = tile_info */) {
+                                                          float* __restrict__ row_norm, unsigned* tile_max /* = tile_info */,
+                                                          const float* __restrict__ mu, int center, float* __restrict__ row_off) {
     const int lane = threadIdx.x & 63;
     const long long ri = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ri >= count) return;
@@ -264,6 +268,27 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
         else
 #pragma unroll
             for (int e = 0; e < 16; ++e) x[i][e] = 0.f;
+    }
+    if (mu) {
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < kMaxPer; ++i) {
+            const int u = lane + 64 * i;
+            if (u >= units8) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float m = mu[16 * u + e];
+                if (center) x[i][e] -= m;
+                else dot = __builtin_fmaf(x[i][e], m, dot);
+            }
+        }
+        if (!center) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) dot += __shfl_xor(dot, off, 64);
+            if (lane == 0 && row_off) row_off[ri] = dot;
+        }
+    } else if (lane == 0 && row_off) {
+        row_off[ri] = 0.f;
     }
     if constexpr (ROT) sketch_rotate(x, lane, units8 * 16);
 #pragma unroll
@@ -324,7 +349,7 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
 // with its reciprocal to tile_info[tile] = (0, 0, 1 / scale, scale) -- the two maxima are cleared for sketch_rows_kernel to fill
 template <typename SRC, bool ROT>
 __global__ __launch_bounds__(256) void tile_scale_kernel(const SRC* __restrict__ tiled, long long tile0, int KTS, int KT8,
-                                                         float* __restrict__ tile_info) {
+                                                         float* __restrict__ tile_info, const float* __restrict__ mu) {
     constexpr int EPU = 16 / (int)sizeof(SRC);
     __shared__ float red[4];
     const long long tile = tile0 + blockIdx.x;
@@ -340,6 +365,15 @@ __global__ __launch_bounds__(256) void tile_scale_kernel(const SRC* __restrict__
                 else
 #pragma unroll
                     for (int e = 0; e < 16; ++e) x[i][e] = 0.f;
+            }
+            if (mu) {
+#pragma unroll
+                for (int i = 0; i < kSketchMaxPer; ++i) {
+                    const int u = lane + 64 * i;
+                    if (u >= units8) continue;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) x[i][e] -= mu[16 * u + e];
+                }
             }
             sketch_rotate(x, lane, units8 * 16);
 #pragma unroll
@@ -370,7 +404,47 @@ __global__ __launch_bounds__(256) void tile_scale_kernel(const SRC* __restrict__
     }
 }
 
+// centre of a shard: mean of rows [first, first + count) of a TILED array, element by element -> mu [d8] (zero past the row's padding);
+// one workgroup per 16-element unit, 256 threads over the rows
+template <typename SRC>
+__global__ __launch_bounds__(256) void row_mean_kernel(const SRC* __restrict__ tiled, long long first, long long count, int KTS,
+                                                       float* __restrict__ mu) {
+    __shared__ float red[256][17];
+    const int u = blockIdx.x;
+    float acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (long long r = threadIdx.x; r < count; r += 256) {
+        float x[16];
+        load_sketch_unit<SRC>(tiled, first + r, u, KTS, x);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] += x[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) red[threadIdx.x][e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        float sum = 0.f;
+        for (int t = 0; t < 256; ++t) sum += red[t][threadIdx.x];
+        const float m = sum / (float)count;
+        mu[16 * u + threadIdx.x] = m == m && fabsf(m) < INFINITY ? m : 0.f;  // NaN / Inf rows: no centre in that dimension
+    }
+}
+
 }  // namespace
+
+int vqa_launch_row_mean(const void* tiled, int32_t src_dtype, int64_t first, int64_t count, int32_t d_pad_src, int32_t d_pad8, float* mu,
+                        hipStream_t stream) {
+    VQA_REQUIRE(count > 0 && (src_dtype == VQA_F16 || src_dtype == VQA_F32), "row_mean: bad arguments");
+    if (src_dtype == VQA_F16)
+        hipLaunchKernelGGL(row_mean_kernel<_Float16>, dim3(d_pad8 / 16), dim3(256), 0, stream, reinterpret_cast<const _Float16*>(tiled),
+                           (long long)first, (long long)count, d_pad_src / 32, mu);
+    else
+        hipLaunchKernelGGL(row_mean_kernel<float>, dim3(d_pad8 / 16), dim3(256), 0, stream, reinterpret_cast<const float*>(tiled),
+                           (long long)first, (long long)count, d_pad_src / 16, mu);
+    VQA_HIP_CHECK(hipGetLastError());
+    return VQA_OK;
+}
 
 template <typename SRC>
 static int launch_tile_rows_src(const SRC* rows, int64_t first, int64_t count, int64_t valid, int32_t d, int32_t d_pad,
@@ -444,7 +518,7 @@ extern "C" int vqa_normalize_convert(const float* rows, int64_t n, int32_t d, in
 
 int vqa_launch_sketch_rows(const void* tiled, int32_t src_dtype, int64_t first, int64_t count, int32_t d_pad_src, int32_t d_pad8,
                            const float* tile_info, void* out8, float* row_scale, float* row_lo, float* row_norm, bool rotate,
-                           hipStream_t stream) {
+                           const float* mu, bool center, float* row_off, hipStream_t stream) {
     if (count == 0) return VQA_OK;
     VQA_REQUIRE(src_dtype == VQA_F16 || src_dtype == VQA_F32, "sketch_rows: source type %d", src_dtype);
     VQA_REQUIRE(d_pad8 / 16 <= 8 * 64, "sketch_rows: rows of %d elements are too long for the int8 sketch", d_pad8);
@@ -452,7 +526,8 @@ int vqa_launch_sketch_rows(const void* tiled, int32_t src_dtype, int64_t first, 
     unsigned* tmax = reinterpret_cast<unsigned*>(const_cast<float*>(tile_info));
 #define VQA_SKROWS(T, ROT, KTSV)                                                                                                  \
     hipLaunchKernelGGL((sketch_rows_kernel<T, ROT>), grid, dim3(256), 0, stream, reinterpret_cast<const T*>(tiled), (long long)first, \
-                       (long long)count, KTSV, d_pad8 / 64, tile_info, reinterpret_cast<int8_t*>(out8), row_scale, row_lo, row_norm, tmax)
+                       (long long)count, KTSV, d_pad8 / 64, tile_info, reinterpret_cast<int8_t*>(out8), row_scale, row_lo, row_norm, tmax, mu,  \
+                       center ? 1 : 0, row_off)
     if (src_dtype == VQA_F16) {
         if (rotate) VQA_SKROWS(_Float16, true, d_pad_src / 32);
         else VQA_SKROWS(_Float16, false, d_pad_src / 32);
@@ -466,11 +541,12 @@ int vqa_launch_sketch_rows(const void* tiled, int32_t src_dtype, int64_t first, 
 }
 
 int vqa_launch_tile_scales(const void* tiled, int32_t src_dtype, int64_t tile0, int64_t ntiles, int32_t d_pad_src, int32_t d_pad8,
-                           float* tile_info, bool rotate, hipStream_t stream) {
+                           float* tile_info, bool rotate, const float* mu, hipStream_t stream) {
     if (ntiles == 0) return VQA_OK;
+    VQA_REQUIRE(rotate || !mu, "tile_scales: a centre needs the rotated form");
 #define VQA_TSCALE(T, ROT, KTSV)                                                                                               \
     hipLaunchKernelGGL((tile_scale_kernel<T, ROT>), dim3((unsigned)ntiles), dim3(256), 0, stream, reinterpret_cast<const T*>(tiled), \
-                       (long long)tile0, KTSV, d_pad8 / 64, tile_info)
+                       (long long)tile0, KTSV, d_pad8 / 64, tile_info, mu)
     if (src_dtype == VQA_F16) {
         if (rotate) VQA_TSCALE(_Float16, true, d_pad_src / 32);
         else VQA_TSCALE(_Float16, false, d_pad_src / 32);

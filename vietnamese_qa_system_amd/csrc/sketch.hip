@@ -127,9 +127,12 @@ __global__ __launch_bounds__(256) void rows_to_rowmajor_kernel(const uint4* __re
 // candidate counters and the overflow flag of this search
 __global__ void sketch_qconst_kernel(const float* __restrict__ thr, const float* __restrict__ qscale, const float* __restrict__ qlo,
                                      const float* __restrict__ qnorm, float fp_margin, float* __restrict__ qconst,
-                                     unsigned* __restrict__ cand_cnt, int* __restrict__ overflow, int clear) {
+                                     unsigned* __restrict__ cand_cnt, int* __restrict__ overflow, int clear,
+                                     const float* __restrict__ qoff, float mu_norm) {
     const int q = threadIdx.x;
-    qconst[q] = thr[q];
+    // a centred sketch bounds q . (x - mu): the threshold moves by q . mu (fp32 dot: its rounding and that of x - mu, <= 2 gamma_d
+    // ||q|| ||mu||, err towards more candidates)
+    qconst[q] = qoff ? thr[q] - qoff[q] - 2.0f * fp_margin * qnorm[q] * mu_norm : thr[q];
     // The scores a search returns -- and theta -- are fp32 sums, the bound speaks of the real-number dot product: both differ
     // from it by at most gamma_d ||q|| ||x|| (d terms, unit roundoff 2^-24 per fma; for the MFMA's internal order as well),
     // ||x|| <= ||x_hi|| + ||x_lo||.  fp_margin = 2 gamma_d rides on BOTH slack terms: ||q_lo|| A + ||q|| B + fp_margin ||q|| (A + B)
@@ -147,11 +150,13 @@ __global__ void sketch_qconst_kernel(const float* __restrict__ thr, const float*
 }  // namespace
 
 int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float* qlo, const float* qnorm, int32_t d, float* qconst,
-                             unsigned* cand_cnt, int* overflow, bool clear, bool rotated, hipStream_t stream) {
+                             unsigned* cand_cnt, int* overflow, bool clear, bool rotated, const float* qoff, float mu_norm,
+                             hipStream_t stream) {
     // 2 gamma_d with gamma_d <= d 2^-24 / (1 - d 2^-24) < 1.2e-7 d / 2 ... kept at twice that; a rotated sketch adds the rounding of
     // the two rotations (13 butterfly stages + the normalisation: 14 2^-24 per side, kept at twice that too)
     const float fp_margin = 2.0f * (float)d * 1.2e-7f + (rotated ? 4.0f * 14.0f * 6e-8f : 0.f);
-    hipLaunchKernelGGL(sketch_qconst_kernel, dim3(1), dim3(256), 0, stream, thr, qscale, qlo, qnorm, fp_margin, qconst, cand_cnt, overflow, clear ? 1 : 0);
+    hipLaunchKernelGGL(sketch_qconst_kernel, dim3(1), dim3(256), 0, stream, thr, qscale, qlo, qnorm, fp_margin, qconst, cand_cnt, overflow, clear ? 1 : 0, qoff,
+                       mu_norm);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

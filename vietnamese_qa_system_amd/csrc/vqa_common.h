@@ -149,14 +149,20 @@ int vqa_launch_untile_rows(const void* tiled, int64_t first, int64_t count, int3
 // maxima; null (the query tile) -> every row its own max|x| / 127, with per-row scale / ||x_lo|| / ||x|| outputs
 int vqa_launch_sketch_rows(const void* tiled, int32_t src_dtype, int64_t first, int64_t count, int32_t d_pad_src, int32_t d_pad8,
                            const float* tile_info, void* out8, float* row_scale, float* row_lo, float* row_norm,
-                           bool rotate /* sketch T x instead of x (convert.hip: sketch_rotate); rows and queries alike */, hipStream_t stream);
+                           bool rotate /* sketch T x instead of x (convert.hip: sketch_rotate); rows and queries alike */,
+                           const float* mu /* the shard's centre [d_pad8] or nullptr */, bool center /* index rows: sketch x - mu */,
+                           float* row_off /* query rows: q . mu per row, or nullptr */, hipStream_t stream);
+// mean of rows [first, first + count) of a TILED array -> mu [d_pad8]
+int vqa_launch_row_mean(const void* tiled, int32_t src_dtype, int64_t first, int64_t count, int32_t d_pad_src, int32_t d_pad8, float* mu,
+                        hipStream_t stream);
 // scale (= max |x| / 127) of tiles [tile0, tile0 + ntiles) of a TILED fp16 / fp32 array into tile_info; clears their two maxima
 int vqa_launch_tile_scales(const void* tiled, int32_t src_dtype, int64_t tile0, int64_t ntiles, int32_t d_pad_src, int32_t d_pad8,
-                           float* tile_info, bool rotate, hipStream_t stream);
+                           float* tile_info, bool rotate, const float* mu, hipStream_t stream);
 // sketch search: per-query constants of the scan + reset of the candidate counters; exact scores of the candidate pairs
 int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float* qlo, const float* qnorm, int32_t d, float* qconst,
                              unsigned* cand_cnt, int* overflow, bool clear /* reset the candidate counters and the overflow flag */,
-                             bool rotated /* the sketch is of rotated rows: the rotation's rounding joins the margin */, hipStream_t stream);
+                             bool rotated /* the sketch is of rotated rows: the rotation's rounding joins the margin */,
+                             const float* qoff /* q . mu per query or nullptr */, float mu_norm, hipStream_t stream);
 int vqa_launch_rescore(const unsigned long long* regions, const unsigned* counts, int cap, int nregions, const long long* stage_pos,
                        int nq, int k, const void* x, const void* x_rowmajor /* or nullptr: the tiled rows x are read */, const void* q,
                        int32_t dtype, int32_t d_pad, vqa_key* cand_keys, unsigned* cand_cnt, int capq, int* overflow, hipStream_t stream);
