@@ -167,7 +167,7 @@ __device__ __forceinline__ void load_sketch_unit(const SRC* __restrict__ tiled, 
 // the rotated quantities (the norms below are those of T x); its coordinates are near-Gaussian whatever the input's.  Rounding:
 // log2(B) <= 13 butterfly stages of one fp32 add each, |T^ x - T x| <= 13 2^-24 ||x|| -- vqa_launch_sketch_qconst adds it to the margin.
 // Row layout in a wave (sketch_rows_kernel): element j = 16 (lane + 64 i) + e sits in x[i][e] of `lane`.
-constexpr int kSketchMaxPer = 8;  // rows of up to 8 * 64 * 16 = 8192 elements
+constexpr int kSketchMaxPer = 8;  // rows of up to 8 * 64 * 16 = 8192 elements (NG = register groups of 1024 elements a kernel is built for: 1, 2, 4, 8)
 
 __device__ __forceinline__ int sketch_block_of(int j, int d8) {  // size of the power-of-two block of the padded row that holds element j
     int off = 0, rem = d8;
@@ -179,10 +179,11 @@ __device__ __forceinline__ int sketch_block_of(int j, int d8) {  // size of the 
     }
 }
 
-__device__ __forceinline__ void sketch_rotate(float (&x)[kSketchMaxPer][16], int lane, int d8) {
-    float bs[kSketchMaxPer];  // block size of this lane's elements of register group i (0: past the row)
+template <int NG>
+__device__ __forceinline__ void sketch_rotate(float (&x)[NG][16], int lane, int d8) {
+    float bs[NG];  // block size of this lane's elements of register group i (0: past the row)
 #pragma unroll
-    for (int i = 0; i < kSketchMaxPer; ++i) {
+    for (int i = 0; i < NG; ++i) {
         const int j0 = 16 * (lane + 64 * i);
         bs[i] = j0 < d8 ? (float)sketch_block_of(j0, d8) : 0.f;
 #pragma unroll
@@ -201,7 +202,7 @@ __device__ __forceinline__ void sketch_rotate(float (&x)[kSketchMaxPer][16], int
 #pragma unroll
     for (int b = 1; b < 16; b <<= 1)
 #pragma unroll
-        for (int i = 0; i < kSketchMaxPer; ++i)
+        for (int i = 0; i < NG; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 if (!(e & b)) {
@@ -213,7 +214,7 @@ __device__ __forceinline__ void sketch_rotate(float (&x)[kSketchMaxPer][16], int
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1)
 #pragma unroll
-        for (int i = 0; i < kSketchMaxPer; ++i) {
+        for (int i = 0; i < NG; ++i) {
             const bool on = bs[i] >= (float)(32 * m);
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -223,9 +224,9 @@ __device__ __forceinline__ void sketch_rotate(float (&x)[kSketchMaxPer][16], int
         }
     // bits 10-12: across the register groups (blocks of 2048 elements and more)
 #pragma unroll
-    for (int m = 1; m < kSketchMaxPer; m <<= 1)
+    for (int m = 1; m < NG; m <<= 1)
 #pragma unroll
-        for (int i = 0; i < kSketchMaxPer; ++i)
+        for (int i = 0; i < NG; ++i)
             if (!(i & m)) {
                 const bool on = bs[i] >= (float)(2048 * m);
 #pragma unroll
@@ -236,7 +237,7 @@ __device__ __forceinline__ void sketch_rotate(float (&x)[kSketchMaxPer][16], int
                 }
             }
 #pragma unroll
-    for (int i = 0; i < kSketchMaxPer; ++i) {
+    for (int i = 0; i < NG; ++i) {
         const float nrm = bs[i] > 0.f ? rsqrtf(bs[i]) : 0.f;  // H / sqrt(B): orthonormal (B a power of two: exact for even log2, one rounding else)
 #pragma unroll
         for (int e = 0; e < 16; ++e) x[i][e] *= nrm;
@@ -246,7 +247,7 @@ __device__ __forceinline__ void sketch_rotate(float (&x)[kSketchMaxPer][16], int
 // mu (or null): the shard's centre, d8 floats.  Index rows (center = 1) are sketched as T (x - mu): embeddings of one encoder share a
 // large common component (mean cosine 0.5 and more), which would otherwise eat the quantiser's range; q . x = q . mu + q . (x - mu), so
 // the query side (center = 0) only reports q . mu (row_off) and the scan's threshold moves by it (sketch_qconst_kernel).
-template <typename SRC, bool ROT>
+template <typename SRC, bool ROT, int NG>
 __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict__ tiled, long long first, long long count,
                                                           int KTS, int KT8, const float* tile_info, int8_t* __restrict__ out8,
                                                           float* __restrict__ row_scale, float* __restrict__ row_lo,
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
     const long long row = first + ri;
     const int units8 = KT8 * 4;
     // this lane's int8 units u = lane, lane + 64, ...
-    constexpr int kMaxPer = kSketchMaxPer;
+    constexpr int kMaxPer = NG;
     float x[kMaxPer][16];
     float amax = 0.f;
 #pragma unroll
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
     } else if (lane == 0 && row_off) {
         row_off[ri] = 0.f;
     }
-    if constexpr (ROT) sketch_rotate(x, lane, units8 * 16);
+    if constexpr (ROT) sketch_rotate<NG>(x, lane, units8 * 16);
 #pragma unroll
     for (int i = 0; i < kMaxPer; ++i)
 #pragma unroll
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
 
 // one workgroup per tile of a TILED fp16 / fp32 array: scale = max |x| over the tile's 256 rows / 127 (a tile of zeros: 1), written
 // with its reciprocal to tile_info[tile] = (0, 0, 1 / scale, scale) -- the two maxima are cleared for sketch_rows_kernel to fill
-template <typename SRC, bool ROT>
+template <typename SRC, bool ROT, int NG>
 __global__ __launch_bounds__(256) void tile_scale_kernel(const SRC* __restrict__ tiled, long long tile0, int KTS, int KT8,
                                                          float* __restrict__ tile_info, const float* __restrict__ mu) {
     constexpr int EPU = 16 / (int)sizeof(SRC);
@@ -357,9 +358,9 @@ __global__ __launch_bounds__(256) void tile_scale_kernel(const SRC* __restrict__
     if constexpr (ROT) {  // the maximum is that of the ROTATED rows: every wave rotates 64 of the tile's rows
         const int lane = threadIdx.x & 63, units8 = KT8 * 4;
         for (int r = threadIdx.x >> 6; r < 256; r += 4) {
-            float x[kSketchMaxPer][16];
+            float x[NG][16];
 #pragma unroll
-            for (int i = 0; i < kSketchMaxPer; ++i) {
+            for (int i = 0; i < NG; ++i) {
                 const int u = lane + 64 * i;
                 if (u < units8) load_sketch_unit<SRC>(tiled, tile * 256 + r, u, KTS, x[i]);
                 else
@@ -368,16 +369,16 @@ __global__ __launch_bounds__(256) void tile_scale_kernel(const SRC* __restrict__
             }
             if (mu) {
 #pragma unroll
-                for (int i = 0; i < kSketchMaxPer; ++i) {
+                for (int i = 0; i < NG; ++i) {
                     const int u = lane + 64 * i;
                     if (u >= units8) continue;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) x[i][e] -= mu[16 * u + e];
                 }
             }
-            sketch_rotate(x, lane, units8 * 16);
+            sketch_rotate<NG>(x, lane, units8 * 16);
 #pragma unroll
-            for (int i = 0; i < kSketchMaxPer; ++i)
+            for (int i = 0; i < NG; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) m = fmaxf(m, fabsf(x[i][e]));
         }
@@ -524,10 +525,17 @@ int vqa_launch_sketch_rows(const void* tiled, int32_t src_dtype, int64_t first, 
     VQA_REQUIRE(d_pad8 / 16 <= 8 * 64, "sketch_rows: rows of %d elements are too long for the int8 sketch", d_pad8);
     const dim3 grid((unsigned)((count + 3) / 4));
     unsigned* tmax = reinterpret_cast<unsigned*>(const_cast<float*>(tile_info));
-#define VQA_SKROWS(T, ROT, KTSV)                                                                                                  \
-    hipLaunchKernelGGL((sketch_rows_kernel<T, ROT>), grid, dim3(256), 0, stream, reinterpret_cast<const T*>(tiled), (long long)first, \
+#define VQA_SKROWS_NG(T, ROT, NGV, KTSV)                                                                                          \
+    hipLaunchKernelGGL((sketch_rows_kernel<T, ROT, NGV>), grid, dim3(256), 0, stream, reinterpret_cast<const T*>(tiled), (long long)first, \
                        (long long)count, KTSV, d_pad8 / 64, tile_info, reinterpret_cast<int8_t*>(out8), row_scale, row_lo, row_norm, tmax, mu,  \
                        center ? 1 : 0, row_off)
+#define VQA_SKROWS(T, ROT, KTSV)                                                                                                  \
+    do {                                                                                                                          \
+        if (d_pad8 <= 1024) VQA_SKROWS_NG(T, ROT, 1, KTSV);                                                                       \
+        else if (d_pad8 <= 2048) VQA_SKROWS_NG(T, ROT, 2, KTSV);                                                                  \
+        else if (d_pad8 <= 4096) VQA_SKROWS_NG(T, ROT, 4, KTSV);                                                                  \
+        else VQA_SKROWS_NG(T, ROT, 8, KTSV);                                                                                      \
+    } while (0)
     if (src_dtype == VQA_F16) {
         if (rotate) VQA_SKROWS(_Float16, true, d_pad_src / 32);
         else VQA_SKROWS(_Float16, false, d_pad_src / 32);
@@ -536,6 +544,7 @@ int vqa_launch_sketch_rows(const void* tiled, int32_t src_dtype, int64_t first, 
         else VQA_SKROWS(float, false, d_pad_src / 16);
     }
 #undef VQA_SKROWS
+#undef VQA_SKROWS_NG
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }
@@ -544,9 +553,16 @@ int vqa_launch_tile_scales(const void* tiled, int32_t src_dtype, int64_t tile0, 
                            float* tile_info, bool rotate, const float* mu, hipStream_t stream) {
     if (ntiles == 0) return VQA_OK;
     VQA_REQUIRE(rotate || !mu, "tile_scales: a centre needs the rotated form");
-#define VQA_TSCALE(T, ROT, KTSV)                                                                                               \
-    hipLaunchKernelGGL((tile_scale_kernel<T, ROT>), dim3((unsigned)ntiles), dim3(256), 0, stream, reinterpret_cast<const T*>(tiled), \
+#define VQA_TSCALE_NG(T, ROT, NGV, KTSV)                                                                                       \
+    hipLaunchKernelGGL((tile_scale_kernel<T, ROT, NGV>), dim3((unsigned)ntiles), dim3(256), 0, stream, reinterpret_cast<const T*>(tiled), \
                        (long long)tile0, KTSV, d_pad8 / 64, tile_info, mu)
+#define VQA_TSCALE(T, ROT, KTSV)                                                                                               \
+    do {                                                                                                                       \
+        if (d_pad8 <= 1024) VQA_TSCALE_NG(T, ROT, 1, KTSV);                                                                    \
+        else if (d_pad8 <= 2048) VQA_TSCALE_NG(T, ROT, 2, KTSV);                                                               \
+        else if (d_pad8 <= 4096) VQA_TSCALE_NG(T, ROT, 4, KTSV);                                                               \
+        else VQA_TSCALE_NG(T, ROT, 8, KTSV);                                                                                   \
+    } while (0)
     if (src_dtype == VQA_F16) {
         if (rotate) VQA_TSCALE(_Float16, true, d_pad_src / 32);
         else VQA_TSCALE(_Float16, false, d_pad_src / 32);
@@ -555,6 +571,7 @@ int vqa_launch_tile_scales(const void* tiled, int32_t src_dtype, int64_t tile0, 
         else VQA_TSCALE(float, false, d_pad_src / 16);
     }
 #undef VQA_TSCALE
+#undef VQA_TSCALE_NG
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }
