@@ -167,7 +167,7 @@ __device__ __forceinline__ void load_sketch_unit(const SRC* __restrict__ tiled, 
 // the rotated quantities (the norms below are those of T x); its coordinates are near-Gaussian whatever the input's.  Rounding:
 // log2(B) <= 13 butterfly stages of one fp32 add each, |T^ x - T x| <= 13 2^-24 ||x|| -- vqa_launch_sketch_qconst adds it to the margin.
 // Row layout in a wave (sketch_rows_kernel): element j = 16 (lane + 64 i) + e sits in x[i][e] of `lane`.
-constexpr int kSketchMaxPer = 8;  // rows of up to 8 * 64 * 16 = 8192 elements (NG = register groups of 1024 elements a kernel is built for: 1, 2, 4, 8)
+// (NG = register groups of 1024 elements a kernel is built for: 1, 2, 4 or 8 -- rows of up to 8 * 64 * 16 = 8192 elements)
 
 __device__ __forceinline__ int sketch_block_of(int j, int d8) {  // size of the power-of-two block of the padded row that holds element j
     int off = 0, rem = d8;
