@@ -351,8 +351,62 @@ def sketch_queries(q: np.ndarray):
     return qi.astype(np.int8), s, np.sqrt((lo ** 2).sum(axis=1, dtype=np.float32)) * up, np.sqrt((q ** 2).sum(axis=1, dtype=np.float32)) * up
 
 
-def sketch_upper_bounds(q: np.ndarray, x: np.ndarray, tile: int = 256) -> np.ndarray:
-    """[b, n] rigorous upper bounds of q . x (the stored values, real-number dot product) from the int8 sketches."""
+def _sketch_signs(d8: int) -> np.ndarray:
+    """The random signs D of the sketch's rotation (csrc/convert.hip: sketch_rotate): +-1 from a mixed hash of the element index."""
+    h = (np.arange(d8, dtype=np.uint64) + np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    h = (h * np.uint64(0x85EBCA6B)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(13)
+    h = (h * np.uint64(0xC2B2AE35)) & np.uint64(0xFFFFFFFF)
+    h ^= h >> np.uint64(16)
+    return np.where((h & np.uint64(1)) == 1, -1.0, 1.0)
+
+
+def sketch_transform(v: np.ndarray, mu=None) -> np.ndarray:
+    """T (v - mu) of csrc/convert.hip (sketch_rotate): rows padded to a multiple of 128 elements, random signs, then the normalised
+    Walsh-Hadamard transform of every power-of-two block of the padded row (768 = 512 + 256).  T is orthogonal:
+    sketch_transform(q) . sketch_transform(x, mu) + q . mu = q . x.  float64 here (the kernel works in fp32)."""
+    v = np.asarray(v, dtype=np.float64)
+    n, d = v.shape
+    d8 = (d + 127) // 128 * 128
+    y = np.zeros((n, d8))
+    y[:, :d] = v - (0.0 if mu is None else np.asarray(mu, dtype=np.float64)[None, :d])
+    y *= _sketch_signs(d8)[None, :]
+    off, rem = 0, d8
+    while rem > 0:
+        b = 1 << (rem.bit_length() - 1)
+        blk = y[:, off:off + b]
+        h = 1
+        while h < b:  # in-place butterflies on bit h of the element index
+            w = blk.reshape(n, b // (2 * h), 2, h)
+            lo, hi = w[:, :, 0, :] + w[:, :, 1, :], w[:, :, 0, :] - w[:, :, 1, :]
+            w[:, :, 0, :], w[:, :, 1, :] = lo, hi
+            h *= 2
+        blk /= np.sqrt(b)
+        off += b
+        rem -= b
+    return y
+
+
+def sketch_upper_bounds(q: np.ndarray, x: np.ndarray, tile: int = 256, transform: bool = False, mu=None) -> np.ndarray:
+    """[b, n] rigorous upper bounds of q . x (the stored values, real-number dot product) from the int8 sketches.
+    ``transform``: the sketches are cut from the centred, rotated vectors (what the library does by default): rows T (x - mu),
+    queries T q, and q . mu joins the bound."""
+    off = 0.0
+    if transform:
+        mu = x[: min(len(x), 65536)].astype(np.float64).mean(axis=0) if mu is None else mu
+        off = (np.asarray(q, dtype=np.float64) @ np.asarray(mu, dtype=np.float64))[:, None]
+        q, x = sketch_transform(q).astype(np.float32), sketch_transform(x, mu).astype(np.float32)
+        # (the float32 rounding of the transformed vectors is what the kernel quantises; its distance to the exact transform is
+        # part of the margin the kernel adds: 1e-6 relative here)
+        off = off + 4e-6 * np.linalg.norm(q, axis=1)[:, None] * (np.linalg.norm(x, axis=1)[None, :] + np.linalg.norm(mu))
+        xi, sx, hi_max, lo_max = sketch_rows(x, tile)
+        qi, sq, qlo, qn = sketch_queries(q)
+        d_int = qi.astype(np.int64) @ xi.astype(np.int64).T
+        t_of = np.arange(x.shape[0]) // tile
+        main = sq[:, None].astype(np.float64) * sx[t_of][None, :].astype(np.float64) * d_int
+        slack = qlo[:, None].astype(np.float64) * hi_max[t_of][None, :] + qn[:, None].astype(np.float64) * lo_max[t_of][None, :]
+        return main + slack + off
     xi, sx, hi_max, lo_max = sketch_rows(x, tile)
     qi, sq, qlo, qn = sketch_queries(q)
     d_int = qi.astype(np.int64) @ xi.astype(np.int64).T  # exact, as the int32 MFMA accumulators are

@@ -66,3 +66,54 @@ def test_sketch_rows_layout_and_scales():
     xi, s, hi, lo = R.sketch_rows(x)
     assert s.shape == (2,) and np.isclose(s[0], 0.01) and np.isclose(s[1], 0.02)
     assert xi[0, 0] == 127 and xi[299, 3] == -127 and hi[0] >= 1.27 and lo.max() < 1e-6
+
+
+def test_the_sketch_rotation_is_orthogonal_and_flattens_outliers():
+    """T = H D of csrc/convert.hip as restated in oracle/retrieval.py: (T q) . (T (x - mu)) + q . mu = q . x for any centre mu,
+    norms are kept, and a row dominated by two outlier dimensions comes out with near-Gaussian coordinates (max / rms about 3-4
+    instead of 19) -- which is what keeps the quantiser's step small."""
+    rng = np.random.default_rng(3)
+    for d in (64, 100, 768, 1000):
+        x = rng.standard_normal((40, d))
+        x[:, 3] *= 20
+        x[:, d // 2] += 15
+        q = rng.standard_normal((7, d))
+        mu = x.mean(axis=0)
+        tx, tq = R.sketch_transform(x, mu), R.sketch_transform(q)
+        assert np.allclose(tq @ tx.T + (q @ mu)[:, None], q @ x.T, rtol=0, atol=1e-9 * np.abs(q @ x.T).max())
+        assert np.allclose(np.linalg.norm(tx, axis=1), np.linalg.norm(x - mu, axis=1))
+        ratio = lambda v: np.abs(v).max(axis=1) / np.sqrt((v ** 2).mean(axis=1))
+        if d >= 768:
+            assert ratio(x - mu).mean() > 10 and ratio(tx).mean() < 4.5
+    const = np.ones((1, 768))
+    assert (np.abs(R.sketch_transform(const)).max() / np.sqrt((R.sketch_transform(const) ** 2).mean())) < 4.5  # no spike from a constant row
+
+
+@pytest.mark.parametrize("name,x", _cases(), ids=[c[0] for c in _cases()])
+def test_transformed_sketch_bound_never_falls_below_the_true_score(name, x):
+    rng = np.random.default_rng(1)
+    q = R.l2_normalize(rng.standard_normal((33, x.shape[1])).astype(np.float32)).astype(np.float16).astype(np.float32)
+    q[0] = x[300] / max(np.linalg.norm(x[300]), 1e-9)
+    q[1] = 0
+    q[2] = x[5]
+    ub = R.sketch_upper_bounds(q, x, transform=True)
+    true = q.astype(np.float64) @ x.astype(np.float64).T
+    assert np.all(ub >= true), (name, float((true - ub).max()))
+    assert np.all(np.isfinite(ub))
+
+
+def test_transformed_sketch_prunes_anisotropic_rows():
+    """Rows with a common component and two outlier dimensions: the plain sketch's bound leaves most rows above a top-10 threshold,
+    the centred, rotated one a few."""
+    rng = np.random.default_rng(8)
+    n, d = 4096, 256
+    def make(m):
+        v = R.l2_normalize(rng.standard_normal((m, d)).astype(np.float32)) + np.ones(d, np.float32) / np.sqrt(d)
+        v[:, 9] += 0.9
+        return R.l2_normalize(v).astype(np.float16).astype(np.float32)
+    x, q = make(n), make(16)
+    true = q.astype(np.float64) @ x.astype(np.float64).T
+    thr = np.sort(true, axis=1)[:, -10][:, None]
+    plain = (R.sketch_upper_bounds(q, x) >= thr).mean()
+    rotated = (R.sketch_upper_bounds(q, x, transform=True) >= thr).mean()
+    assert rotated < 0.25 * plain and rotated < 0.2, (plain, rotated)
