@@ -19,6 +19,15 @@ def unit(x):
     return x / x.norm(dim=1, keepdim=True)
 
 
+_shared = {}
+
+
+def shared(name, fn):  # structure the rows and the queries of a shape share (cluster centres, the low-rank basis)
+    if name not in _shared:
+        _shared[name] = fn()
+    return _shared[name]
+
+
 def make(kind, m):
     x = torch.randn((m, d), generator=g, device=dev)
     if kind == "isotropic":
@@ -31,13 +40,13 @@ def make(kind, m):
     elif kind == "common component (mean cosine 0.5)":
         x = unit(x) + torch.ones(d, device=dev) / d ** 0.5
     elif kind == "1000 clusters, within-cluster sigma 0.3":
-        c = unit(torch.randn((1000, d), generator=g, device=dev))
+        c = shared(kind, lambda: unit(torch.randn((1000, d), generator=g, device=dev)))
         x = c[torch.randint(0, 1000, (m,), generator=g, device=dev)] + 0.3 * x / d ** 0.5
     elif kind == "50 tight clusters, sigma 0.05":
-        c = unit(torch.randn((50, d), generator=g, device=dev))
+        c = shared(kind, lambda: unit(torch.randn((50, d), generator=g, device=dev)))
         x = c[torch.randint(0, 50, (m,), generator=g, device=dev)] + 0.05 * x / d ** 0.5
     elif kind == "low rank 32 + 10 % noise":
-        p = torch.randn((32, d), generator=g, device=dev)
+        p = shared(kind, lambda: torch.randn((32, d), generator=g, device=dev))
         x = torch.randn((m, 32), generator=g, device=dev) @ p + 0.1 * x
     return unit(x).half()
 
