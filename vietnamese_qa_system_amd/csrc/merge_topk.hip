@@ -116,6 +116,9 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
     }
     __syncthreads();
     const int m = *fill;
+    // The winners are collected in LDS and written out after the last round: __syncthreads waits for every outstanding memory
+    // operation of the wave, so a global store per round made each round pay a store round trip (~2 us against ~0.6 us of work).
+    vqa_key* win = reinterpret_cast<vqa_key*>(fill + 2);  // [k]
     vqa_key prev = ~0ull;
     for (int r = 0; r < k; ++r) {
         vqa_key best = 0ull;
@@ -124,18 +127,20 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
             best = (v < prev && v > best) ? v : best;
         }
         best = block_max_key(best, red);
-        if (threadIdx.x == 0) {
-            const bool empty = best == 0ull;
-            const long long pos = empty ? -1 : (long long)vqa_key_pos(best);
-            const size_t o = (size_t)q * out_stride + out_offset + r;
-            if (out_scores) out_scores[o] = empty ? -INFINITY : vqa_key_score(best) * score_scale;
-            if (out_ids) out_ids[o] = empty ? -1 : (ids ? ids[pos] : id_base + pos);
-            if (out_pos) out_pos[o] = pos;
-            if (out_thr && r == k - 1) out_thr[q] = empty ? -INFINITY : vqa_key_score(best);
-            if (out_last_key && r == k - 1) out_last_key[q] = best;
-        }
+        if (threadIdx.x == 0) win[r] = best;
         prev = best;  // 0 once the candidates are exhausted: later rounds stay empty
-        if (best == 0ull) prev = 0ull;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < k; r += kMergeThreads) {
+        const vqa_key best = win[r];
+        const bool empty = best == 0ull;
+        const long long pos = empty ? -1 : (long long)vqa_key_pos(best);
+        const size_t o = (size_t)q * out_stride + out_offset + r;
+        if (out_scores) out_scores[o] = empty ? -INFINITY : vqa_key_score(best) * score_scale;
+        if (out_ids) out_ids[o] = empty ? -1 : (ids ? ids[pos] : id_base + pos);
+        if (out_pos) out_pos[o] = pos;
+        if (out_thr && r == k - 1) out_thr[q] = empty ? -INFINITY : vqa_key_score(best);
+        if (out_last_key && r == k - 1) out_last_key[q] = best;
     }
 }
 
@@ -206,6 +211,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_shards_kernel(const float
     extern __shared__ __attribute__((aligned(16))) char smem[];
     vqa_key* keys = reinterpret_cast<vqa_key*>(smem);  // [R * k]
     vqa_key* red = keys + (size_t)R * k;
+    vqa_key* win = red + 4;  // [k_out] winners
     const int q = blockIdx.x;
     const int m = R * k;
     for (int i = threadIdx.x; i < m; i += kMergeThreads) {
@@ -224,18 +230,21 @@ __global__ __launch_bounds__(kMergeThreads) void merge_shards_kernel(const float
             best = (v < prev && v > best) ? v : best;
         }
         best = block_max_key(best, red);
-        if (threadIdx.x == 0) {
-            const bool empty = best == 0ull;
-            size_t src = 0, rr = 0;
-            if (!empty) {
-                const int i = (int)vqa_key_pos(best);
-                rr = (size_t)(i / k);
-                src = (size_t)q * k + (size_t)(i - (int)rr * k);
-            }
-            out_scores[(size_t)q * k_out + r] = empty ? -INFINITY : scores[rr * score_rank_stride + src];
-            out_ids[(size_t)q * k_out + r] = empty ? -1 : ids[rr * id_rank_stride + src];
-        }
+        if (threadIdx.x == 0) win[r] = best;  // written out after the last round (no global round trip inside a round: see merge_partials)
         prev = best;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < k_out; r += kMergeThreads) {
+        const vqa_key best = win[r];
+        const bool empty = best == 0ull;
+        size_t src = 0, rr = 0;
+        if (!empty) {
+            const int i = (int)vqa_key_pos(best);
+            rr = (size_t)(i / k);
+            src = (size_t)q * k + (size_t)(i - (int)rr * k);
+        }
+        out_scores[(size_t)q * k_out + r] = empty ? -INFINITY : scores[rr * score_rank_stride + src];
+        out_ids[(size_t)q * k_out + r] = empty ? -1 : ids[rr * id_rank_stride + src];
     }
 }
 
@@ -269,7 +278,7 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
     VQA_REQUIRE(row_lists >= parts, "merge_partials: %d lists per row but %d to merge", row_lists, parts);
     VQA_REQUIRE(parts >= 1 && list_len >= 1 && nq >= 1 && nq <= VQA_QUERY_TILE && k >= 1,
                 "merge_partials: bad shape parts=%d list_len=%d nq=%d k=%d", parts, list_len, nq, k);
-    const size_t lds = ((size_t)parts * list_len + 5) * sizeof(vqa_key);  // keys, 4 reduction slots, the fill counter
+    const size_t lds = ((size_t)parts * list_len + 6 + (size_t)k) * sizeof(vqa_key);  // keys, 4 reduction slots, the fill counter, k winners
     VQA_REQUIRE(lds <= 160 * 1024, "merge_partials: %d lists x %d keys do not fit in LDS", parts, list_len);
     if (lds > 64 * 1024) {
         static VqaPerDeviceOnce once;
@@ -315,12 +324,12 @@ extern "C" int vqa_merge_topk(const float* scores, const int64_t* ids, int64_t s
     VQA_REQUIRE(score_rank_stride >= (int64_t)B * k && id_rank_stride >= (int64_t)B * k,
                 "vqa_merge_topk: rank strides %lld / %lld are smaller than one [B, k] block", (long long)score_rank_stride,
                 (long long)id_rank_stride);
-    const size_t lds = ((size_t)R * k + 4) * sizeof(vqa_key);  // 65 568 B at the R * k = 8192 limit: above the 64 KiB default
+    const size_t lds = ((size_t)R * k + 4 + (size_t)k_out) * sizeof(vqa_key);  // keys, 4 reduction slots, k_out winners: above the 64 KiB default near the R * k = 8192 limit
     if (lds > 64 * 1024) {
         static VqaPerDeviceOnce once;
         int rc = once.run([&](int) -> int {
             VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(merge_shards_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024));
             return VQA_OK;
         });
         if (rc != VQA_OK) return rc;
