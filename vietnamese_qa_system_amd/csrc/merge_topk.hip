@@ -49,16 +49,18 @@ __device__ __forceinline__ vqa_key wave_max_key(vqa_key v) {
     return v;
 }
 
-// block-wide max of per-thread values; every thread gets the result.  red: LDS [4].
-__device__ __forceinline__ vqa_key block_max_key(vqa_key v, vqa_key* red) {
+// block-wide max of per-thread values; every thread gets the result.  red: LDS [2][4], `round` picks the half -- ONE barrier per
+// call: the half written in round r is next written in round r + 2, behind the barrier of round r + 1 that every reader of round r
+// has passed.
+__device__ __forceinline__ vqa_key block_max_key(vqa_key v, vqa_key* red, int round) {
     v = wave_max_key(v);
     const int wave = threadIdx.x >> 6;
-    __syncthreads();  // previous round's readers are done with red[]
-    if ((threadIdx.x & 63) == 0) red[wave] = v;
+    vqa_key* slot = red + 4 * (round & 1);
+    if ((threadIdx.x & 63) == 0) slot[wave] = v;
     __syncthreads();
-    vqa_key m = red[0];
+    vqa_key m = slot[0];
 #pragma unroll
-    for (int w = 1; w < kMergeThreads / 64; ++w) m = red[w] > m ? red[w] : m;
+    for (int w = 1; w < kMergeThreads / 64; ++w) m = slot[w] > m ? slot[w] : m;
     return m;
 }
 
@@ -76,8 +78,8 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
     if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     vqa_key* keys = reinterpret_cast<vqa_key*>(smem);    // [parts * list_len]
-    vqa_key* red = keys + (size_t)parts * list_len;      // [4]
-    int* fill = reinterpret_cast<int*>(red + 4);         // keys kept
+    vqa_key* red = keys + (size_t)parts * list_len;      // [2][4]
+    int* fill = reinterpret_cast<int*>(red + 8);         // keys kept
     const int q = blockIdx.x;
     const int m_all = parts * list_len;
     // Only the non-empty slots are kept: a workgroup's list of a query holds ~1-3 keys after a scan seeded with good
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
             const vqa_key v = keys[i];
             best = (v < prev && v > best) ? v : best;
         }
-        best = block_max_key(best, red);
+        best = block_max_key(best, red, r);
         if (threadIdx.x == 0) win[r] = best;
         prev = best;  // 0 once the candidates are exhausted: later rounds stay empty
     }
@@ -210,8 +212,8 @@ __global__ __launch_bounds__(kMergeThreads) void merge_shards_kernel(const float
                                                                      long long* __restrict__ out_ids) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     vqa_key* keys = reinterpret_cast<vqa_key*>(smem);  // [R * k]
-    vqa_key* red = keys + (size_t)R * k;
-    vqa_key* win = red + 4;  // [k_out] winners
+    vqa_key* red = keys + (size_t)R * k;  // [2][4]
+    vqa_key* win = red + 8;  // [k_out] winners
     const int q = blockIdx.x;
     const int m = R * k;
     for (int i = threadIdx.x; i < m; i += kMergeThreads) {
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_shards_kernel(const float
             const vqa_key v = keys[i];
             best = (v < prev && v > best) ? v : best;
         }
-        best = block_max_key(best, red);
+        best = block_max_key(best, red, r);
         if (threadIdx.x == 0) win[r] = best;  // written out after the last round (no global round trip inside a round: see merge_partials)
         prev = best;
     }
@@ -278,7 +280,7 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
     VQA_REQUIRE(row_lists >= parts, "merge_partials: %d lists per row but %d to merge", row_lists, parts);
     VQA_REQUIRE(parts >= 1 && list_len >= 1 && nq >= 1 && nq <= VQA_QUERY_TILE && k >= 1,
                 "merge_partials: bad shape parts=%d list_len=%d nq=%d k=%d", parts, list_len, nq, k);
-    const size_t lds = ((size_t)parts * list_len + 6 + (size_t)k) * sizeof(vqa_key);  // keys, 4 reduction slots, the fill counter, k winners
+    const size_t lds = ((size_t)parts * list_len + 10 + (size_t)k) * sizeof(vqa_key);  // keys, 2 x 4 reduction slots, the fill counter, k winners
     VQA_REQUIRE(lds <= 160 * 1024, "merge_partials: %d lists x %d keys do not fit in LDS", parts, list_len);
     if (lds > 64 * 1024) {
         static VqaPerDeviceOnce once;
@@ -324,7 +326,7 @@ extern "C" int vqa_merge_topk(const float* scores, const int64_t* ids, int64_t s
     VQA_REQUIRE(score_rank_stride >= (int64_t)B * k && id_rank_stride >= (int64_t)B * k,
                 "vqa_merge_topk: rank strides %lld / %lld are smaller than one [B, k] block", (long long)score_rank_stride,
                 (long long)id_rank_stride);
-    const size_t lds = ((size_t)R * k + 4 + (size_t)k_out) * sizeof(vqa_key);  // keys, 4 reduction slots, k_out winners: above the 64 KiB default near the R * k = 8192 limit
+    const size_t lds = ((size_t)R * k + 8 + (size_t)k_out) * sizeof(vqa_key);  // keys, 4 reduction slots, k_out winners: above the 64 KiB default near the R * k = 8192 limit
     if (lds > 64 * 1024) {
         static VqaPerDeviceOnce once;
         int rc = once.run([&](int) -> int {
