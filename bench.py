@@ -275,6 +275,7 @@ def main():
     info = index.launch_info(b, k)
     device_bytes = index.device_bytes()
     sketch_state = index.sketch_state()
+    sketch_stats = index.sketch_stats() if info.sketch_scan else None  # pair counts of the last timed search (synchronises: after the timed region)
     # multi-batch steady state through search_pipelined (the all-gather of batch i hidden under the scan of batch i + 1;
     # at N = 1 the same four scans back to back): S = 4 resident query batches per call, outside the headline's timed region
     S = 4
@@ -318,7 +319,9 @@ def main():
             "metric": "queries_per_sec", "value": round(qps, 1), "unit": "queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dt, "data": "synthetic",
-            "config": {"workload": f"{world}x{n}x{d} {args.dtype} index row-sharded, batch={b} queries, top-{k}, fused MFMA scoring + top-k"
+            "config": {"workload": f"{world}x{n}x{d} {args.dtype} index row-sharded, batch={b} queries, top-{k}, "
+                                   + ("int8 sketch scan (v_mfma_i32_16x16x64_i8, rigorous score bound) + exact " + args.dtype
+                                      + " re-scoring of the surviving pairs + top-k" if sketch else "fused MFMA scoring + top-k")
                                    + (", RCCL all-gather + merge" if world > 1 else ""),
                        "docs_total": world * n, "docs_per_gpu": n, "dim": d, "batch": b, "k": k,
                        "parallelism": f"row-shard x{world}"},
@@ -335,23 +338,26 @@ def main():
                          "seed_pass_rows": int(info.seed_tiles) * int(info.rows_per_tile),
                          # two-stage search: the dominant launch covers rows_per_launch of the shard's rows, a first-stage
                          # launch of the same code (symbol score_topk_kernel<1, DT, 1, 0>) the first first_stage_rows; bytes,
-                         # flops, achieved and kernel_ms above are the dominant launch's alone.  whole_step_frac prices the
-                         # WHOLE step (every launch, merges, gaps) as one read of the shard: shard bytes / median step / peak
+                         # flops, achieved and kernel_ms above are the dominant launch's alone; step_frac_physical (below) prices
+                         # the WHOLE step on the bytes all its launches move
                          "rows_per_launch": int(info.rows_per_launch), "first_stage_rows": int(info.first_stage_rows),
                          # sketch_scan: large fp16 shards run the dominant launch over an int8 sketch of the rows (one byte per
                          # element: bytes_per_launch / achieved / frac price THAT launch on the bytes it has to read; the
                          # multiply-adds are int8 x int8 -> int32, mfma_tflops counts them) and score exactly only the pairs
-                         # its rigorous bound cannot exclude.  whole_step_frac prices the WHOLE step as one read of the
-                         # shard AS STORED (index_bytes = rows x d x element size of the index type): queries/s over the
-                         # HBM-roofline queries/s of BASELINE.md -- a step that reads fewer bytes than the shard holds can
-                         # pass the rate of a plain scan
+                         # its rigorous bound cannot exclude (index_bytes = rows x d x element size of the index type as stored)
                          "sketch_scan": sketch, "index_bytes": n * d * esize,
                          # what the shard holds on the device: the rows as stored + the int8 sketch (+50 %) + the row-major copy the
                          # sketch search re-scores its survivors from (+100 %; VQA_RESCORE_COPY=0 does without: re-scoring 3x slower)
                          "device_bytes": device_bytes,
                          # 0: every timed search took the sketch search (no overflow into its exact fallback); -1: no sketch kept
                          "sketch_state": sketch_state,
-                         "whole_step_frac": round(n * d * esize / (float(np.median(step_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         # queries/s over the queries/s of BASELINE.md's HBM roofline for this index (one read of the shard AS STORED
+                         # per batch at 8 TB/s: 133 333 q/s for 10M x 768 fp16).  NOT a bandwidth fraction: a sketch search reads fewer
+                         # bytes than the shard holds (round 3 printed this as "whole_step_frac")
+                         "qps_over_hbm_roofline_qps": round(n * d * esize / (float(np.median(step_ms)) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         # what the step PHYSICALLY moves: algorithmic bytes of every launch of one search (below), and that sum over
+                         # the median step time as a fraction of 8 TB/s
+                         **step_bytes(info, sketch_stats, n, d, esize, b, float(np.median(step_ms))),
                          # the ceiling this box's HBM really gives a plain stream: a 1 GiB device-to-device copy (torch's copy
                          # kernel), bytes read + written over its event time, in this process
                          "hbm_copy_measured_gbs": copy_gbs},
@@ -412,7 +418,8 @@ def main():
         result["exact_scan"] = {"ms_per_step": round(st_ms, 4), "queries_per_s": round(b / (st_ms * 1e-3), 1), "kernel": f"score_topk_kernel<1, {mode}, 0, 0>",
                                 "kernel_ms": round(kn_ms, 4), "bytes_per_launch": int(ei.bytes_per_launch),
                                 "frac": round(ei.bytes_per_launch / (kn_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                "whole_step_frac": round(n * d * esize / (st_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                "qps_over_hbm_roofline_qps": round(n * d * esize / (st_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                **{kk: vv for kk, vv in step_bytes(ei, None, n, d, esize, b, st_ms).items() if kk != "step_bytes_by_launch"},
                                 "same_rows_as_sketch_search": bool(torch.equal(p_ex, p_sk)),
                                 "max_abs_score_diff": float((s_ex - s_sk).abs().max())}
         exact.close()
@@ -427,6 +434,32 @@ def main():
     if world > 1:
         dist.barrier()  # rank 0's recall check (CPU oracle, tens of seconds) ends before any rank tears the group down
         dist.destroy_process_group()
+
+
+def step_bytes(info, stats, n, d, esize, b, step_ms):
+    """Algorithmic HBM bytes of every launch of ONE search step (cross-checked against PMC once per round: profiles/), their sum
+    and that sum over the step time as a fraction of the 8 TB/s peak."""
+    seed = int(info.seed_tiles) * int(info.rows_per_tile) * d * esize
+    qbytes = 256 * d * (4 + esize)  # query staging (read fp32 / fp16 rows, write the tiled tile); L2-resident afterwards
+    if stats is None:  # exact search: seed rows once more + every row of the shard once (first stage + main launch)
+        parts = {"query_staging": qbytes, "exact_seed_rows": seed, "exact_scan_rows": n * d * esize}
+    else:
+        # the cascade (vqa_index_search): exact seeds over 2 tiles per workgroup, int8 scan of the first stage, exact re-scoring of its
+        # pairs, int8 scan of the rest, exact re-scoring of its pairs (one stored row of d x esize bytes per pair; the query rows come
+        # from L2), selections (the candidate keys: 8 bytes per pair, written once and read twice)
+        seed = min(2 * int(info.grid), int(info.first_stage_rows) // int(info.rows_per_tile)) * int(info.rows_per_tile) * d * esize
+        pairs = int(stats["rescored_pairs"])
+        parts = {"query_staging_and_sketch": qbytes + 256 * d, "exact_seed_rows": seed,
+                 "sketch_scan_first_stage": int(info.first_stage_rows) * d, "sketch_scan_main": int(info.rows_per_launch) * d,
+                 "rescored_rows": pairs * d * esize, "candidate_pairs_and_keys": pairs * (8 + 8 + 3 * 8)}
+    total = sum(parts.values())
+    out = {"step_bytes_moved": total, "step_bytes_by_launch": parts,
+           "step_frac_physical": round(total / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    if stats is not None:
+        out["candidate_pairs"] = {"main_scan": int(stats["last_scan_pairs"]), "rescored_total": int(stats["rescored_pairs"]),
+                                  "largest_region": int(stats["largest_region"]), "region_capacity": int(stats["region_capacity"]),
+                                  "longest_sublist": int(stats["longest_sublist"]), "sublist_capacity": int(stats["sublist_capacity"])}
+    return out
 
 
 def timed_search(torch, index, q, k, steps, warmup=5):
@@ -495,7 +528,7 @@ def other_configs(torch, np, device, dev_index, n, d, b, k):
     gbs = info.bytes_per_launch / (kern_ms * 1e-3) / 1e9
     out["fp8_e4m3"] = {"rows": n, "queries_per_s": round(b / (step_ms * 1e-3), 1), "step_ms": round(step_ms, 4),
                        "kernel_ms": round(kern_ms, 4), "main_launch_frac": round(gbs / HBM_PEAK_GBS, 4),
-                       "whole_step_frac": round(n * d / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                       **{kk: vv for kk, vv in step_bytes(info, None, n, d, 1, b, step_ms).items() if kk != "step_bytes_by_launch"},
                        "mfma_tflops": round(info.flops_per_launch / (kern_ms * 1e-3) / 1e12, 1),
                        "recall_at_10_same_codes": R.recall_at_k(p_gpu, ref_same), "recall_at_10_vs_fp32_rows": R.recall_at_k(p_gpu, ref_32),
                        "recall_check": f"{nv} queries x the first {pre_rows} rows (a prefix-only index), oracle on the same e4m3 codes / on the fp32 rows",
@@ -572,7 +605,91 @@ def other_configs(torch, np, device, dev_index, n, d, b, k):
     out["config0_api_1k"] = {"batch256_ms": round(t_batch * 1e3, 3), "single_query_ms": round(t_one * 1e3, 3),
                              "recall_at_10": R.recall_at_k(got, ref_ids)}
     emb._index.close()
+    if d == 768:
+        out["non_isotropic"] = non_isotropic_legs(torch, np, device, dev_index, b, k)
     return out
+
+
+def non_isotropic_legs(torch, np, device, dev_index, b, k):
+    """The sketch search OFF the benchmark's isotropic Gaussian corpus (its best case), driver-visible and bounded (~15 s):
+    (1) rows produced by this build's own PhoBERT-base-shaped encoder (random-init weights, mean pooling, L2 norm) from 1.57M synthetic
+    token sequences -- the one anisotropic embedding source available offline --, queries encoded the same way;
+    (2) 3M rows in 1000 clusters (within-cluster sigma 0.3 of the centre norm), queries drawn like the rows.
+    Per leg: candidate pairs, whether the search stayed on the sketch (sketch_state 0), sketch search vs exact scan of the same shard
+    (queries/s), same rows as the exact scan."""
+    from vietnamese_qa_system_amd.index import DeviceIndex
+    d = 768
+    legs = {}
+
+    def compare(x, q, extra):
+        t0 = time.perf_counter()
+        ske = DeviceIndex(x, id_base=1, dtype="fp16", device=dev_index, sketch=True)
+        build_s = time.perf_counter() - t0
+        s1, _, p1 = ske.search(q, k, return_positions=True)
+        torch.cuda.synchronize(device)
+        stats, state_first = ske.sketch_stats(), ske.sketch_state()
+        sk_ms, sk_kern = timed_search(torch, ske, q, k, 20)
+        state = ske.sketch_state()
+        li = ske.launch_info(b, k)
+        ske.close()
+        ref = DeviceIndex(x, id_base=1, dtype="fp16", device=dev_index, sketch=False)
+        s0, _, p0 = ref.search(q, k, return_positions=True)
+        ex_ms, _ = timed_search(torch, ref, q, k, 20)
+        ref.close()
+        diff = p0 != p1
+        n = int(x.shape[0])
+        xs = x[:: max(1, n // 4096)].float()
+        cen = xs.mean(0)
+        return {"rows": n, "sketch_scan": bool(li.sketch_scan), "candidate_pairs_main_scan": stats["last_scan_pairs"],
+                "rescored_pairs": stats["rescored_pairs"], "pairs_per_query": round(stats["rescored_pairs"] / b, 1),
+                "overflow_first_search": stats["overflow"], "sketch_state_after_first_search": state_first,
+                "sketch_state_after_25_searches": state,
+                "sketch_search": {"step_ms": round(sk_ms, 4), "queries_per_s": round(b / (sk_ms * 1e-3), 1), "main_launch_ms": round(sk_kern, 4)},
+                "exact_scan": {"step_ms": round(ex_ms, 4), "queries_per_s": round(b / (ex_ms * 1e-3), 1)},
+                "speedup_over_exact": round(ex_ms / sk_ms, 3),
+                "same_rows_as_exact": bool(not diff.any()), "rows_differing": int(diff.sum()),
+                "max_abs_score_diff": float((s0 - s1).abs().max()),
+                "max_score_gap_where_rows_differ": float((s0 - s1).abs()[diff].max()) if diff.any() else 0.0,
+                # how far from isotropic: mean cosine of a row to the corpus centroid direction, norm of the centroid of unit rows
+                "mean_cosine_to_centroid": round(float((xs @ (cen / cen.norm())).mean()), 4), "centroid_norm": round(float(cen.norm()), 4),
+                "index_build_s": round(build_s, 2), **extra}
+
+    # ---- (1) the build's own encoder
+    t0 = time.perf_counter()
+    S, L, n_enc = 1024, 32, 1_572_864
+    enc, _, _, _, g = make_encoder(torch, device, dev_index, S, L, max_tokens=S * L)
+    from vietnamese_qa_system_amd.encoder import PHOBERT_BASE
+    x = torch.empty((n_enc, d), dtype=torch.float16, device=device)
+    for c0 in range(0, n_enc, S):
+        ids, mask, lens = make_tokens(torch, device, g, PHOBERT_BASE, S, L)
+        x[c0:c0 + S] = enc.forward(ids, mask, pooling="mean", normalize=True, real_tokens=int(lens.sum())).to(torch.float16)
+    ids, mask, lens = make_tokens(torch, device, g, PHOBERT_BASE, b, L)
+    q = enc.forward(ids, mask, pooling="mean", normalize=True, real_tokens=int(lens.sum())).to(torch.float16)
+    torch.cuda.synchronize(device)
+    enc.close()
+    enc_s = time.perf_counter() - t0
+    legs["own_encoder_outputs"] = compare(x, q, {"source": f"{n_enc} synthetic token sequences (lengths 8-{L}) through this build's PhoBERT-base-shaped "
+                                                          "encoder (random init), mean pooling, L2 norm, fp16 rows; queries encoded alike",
+                                                "encode_s": round(enc_s, 1), "encode_docs_per_s": round(n_enc / enc_s, 1)})
+    del x
+    torch.cuda.empty_cache()
+    # ---- (2) 1000 clusters
+    t0 = time.perf_counter()
+    gen = torch.Generator(device=device)
+    gen.manual_seed(11)
+    n_cl = 3_000_000
+    centres = torch.randn((1000, d), generator=gen, device=device)
+    centres /= centres.norm(dim=1, keepdim=True)
+
+    def draw(m):
+        v = centres[torch.randint(0, 1000, (m,), generator=gen, device=device)] + 0.3 * torch.randn((m, d), generator=gen, device=device) / d ** 0.5
+        return (v / v.norm(dim=1, keepdim=True)).to(torch.float16)
+
+    x = torch.cat([draw(1 << 19) for _ in range(0, n_cl, 1 << 19)])[:n_cl]
+    q = draw(b)
+    legs["clusters_1000"] = compare(x, q, {"source": "1000 cluster centres on the unit sphere + 0.3 / sqrt(d) N(0, 1) noise per component, L2-normalised; "
+                                                     "queries drawn like the rows", "generate_s": round(time.perf_counter() - t0, 1)})
+    return legs
 
 
 def make_encoder(torch, device, dev_index, b, L, max_tokens=None):

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VQA_VERSION 105 /* 0.1.5: vqa_index_sketch_state; 0.1.4: VQA_INDEX_RESCORE_ROWS, vqa_index_device_bytes; 0.1.3: VQA_INDEX_SKETCH */
+#define VQA_VERSION 106 /* 0.1.6: vqa_index_sketch_stats, vqa_index_get_sketch_tile; 0.1.5: vqa_index_sketch_state; 0.1.4: VQA_INDEX_RESCORE_ROWS, vqa_index_device_bytes; 0.1.3: VQA_INDEX_SKETCH */
 
 /* error codes */
 #define VQA_OK 0
@@ -95,8 +95,33 @@ int32_t vqa_index_dtype(const vqa_index* index);
 /* device memory the shard holds: rows + id vector + sketch + re-scoring copy (workspaces of a few MB not counted); -1: null */
 int64_t vqa_index_device_bytes(const vqa_index* index);
 /* -1: the shard keeps no sketch; 0: its searches take the sketch search; n > 0: a sketch search overflowed into its exact fallback
- * (data the bound cannot prune) and the next n searches of this handle run the exact scan (call it after the searches completed) */
+ * (data the bound cannot prune) and about the next n searches of this handle run the exact scan (call it after the searches completed).
+ *
+ * The stateful part of a sketch shard, in full.  A sketch search whose candidate buffers fill up (any query tile of the call)
+ * still returns the exact result -- its exact fallback runs behind it on the device, gated on a flag, no host round trip -- but
+ * costs a sketch scan AND an exact scan.  The flags of a call (+ the call's number) are copied to a pinned mirror behind its
+ * last launch; a LATER vqa_index_search on the handle that finds the report of a call it has not seen yet, with a flag up, starts
+ * a pause: the next VQA_SKETCH_COOLDOWN (default 64) searches run the exact scan only, then the sketch is tried again; every
+ * further overflow doubles the pause (up to 64 x), a sketch search that stands resets it.  The host may run many searches ahead
+ * of the device: reports of calls queued before a pause began are ignored, so the reaction lags by the queue depth and never
+ * compounds.  Nothing but SPEED depends on this state: every path returns the exact top-k of the stored values.  Scores are
+ * bit-stable within one path; between the sketch path (fp32 fma chain of the re-scoring kernel) and the exact scan (MFMA
+ * accumulation) the last bits of a score may differ (<= 3e-7 on unit vectors at d = 768), and with them the order of rows
+ * whose scores tie to within that.
+ * Under hipGraph capture the host-side choice is frozen: a captured search replays the launch sequence chosen at capture
+ * time -- captured outside a pause: the sketch search with its gated fallback (an overflow inside a replay takes the fallback,
+ * correct results, and no pause ever starts because no host code runs); captured inside a pause: the exact scan. */
 int32_t vqa_index_sketch_state(const vqa_index* index);
+/* Diagnostics of the sketch search; both SYNCHRONISE the device (never call them between the searches of a timed loop).
+ * vqa_index_sketch_stats: what the last search of this handle left in its candidate buffers -- out[8] = { candidate pairs of the last
+ * sketch scan (of a cascade: its second, main scan) of the call's last query tile, the fullest workgroup region of that scan, pairs
+ * scored exactly for that query tile (all its scans), its longest candidate sub-list, overflow flag of that tile, OR of the flags of
+ * the call's earlier tiles, capacity of a region, capacity of a sub-list }.  bench.py derives a step's physical bytes from it.
+ * vqa_index_get_sketch_tile: the int8 codes of one 256-row tile as host [256, d8] row-major (d8 = d rounded up to 128), its
+ * (max ||x_hi||, max ||x_lo||, 1 / scale, scale) and, optionally, the shard's centre mu [d8] (zeros when the sketch is not centred):
+ * what the bound of the sketch search is computed from, for tests that restate it independently. */
+int vqa_index_sketch_stats(vqa_index* index, int64_t* out /* [8] */);
+int vqa_index_get_sketch_tile(vqa_index* index, int64_t tile, int8_t* out_codes, float* out_info /* [4] */, float* out_mu_or_null);
 
 /* ---- search: replaces the scoring + top-k inside Embeddings.search / batchsearch (heavy_ranker.py:98,100) ---
  * q: [B, d] DEVICE pointer, element type q_dtype (VQA_F32 or VQA_F16; converted to the index storage type with

@@ -1,18 +1,16 @@
 """Dev probe: how does the sketch search's pruning hold up on data that is not isotropic?  3M x 768 fp16 rows of several shapes,
-256 queries drawn like the rows; per shape: candidate pairs of the main scan (a -DVQA_DEV library reports them), whether the
+256 queries drawn like the rows; per shape: candidate pairs of the main scan (vqa_index_sketch_stats), whether the
 search stayed on the sketch, step time against the exact scan."""
 import ctypes, os, sys, time
 import torch
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root)
-os.environ.setdefault("VQA_LIB", os.path.join(root, "vietnamese_qa_system_amd/lib/libvqa_retrieval_dev.so"))
 from vietnamese_qa_system_amd.index import DeviceIndex
 from vietnamese_qa_system_amd import _native as N
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(11)
 n, d, b, k = 3_000_000, 768, 256, 10
 lib = N.load()
-lib.vqa_dev_sketch_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_longlong)]
 
 
 def unit(x):
@@ -67,7 +65,7 @@ for kind in ("isotropic", "two outlier dimensions (20x)", "two constant outlier 
     q = make(kind, b)
     ske = DeviceIndex(x, dtype="fp16", sketch=True)
     s1, i1, _ = ske.search(q, k); torch.cuda.synchronize()
-    out = (ctypes.c_longlong * 4)(); lib.vqa_dev_sketch_stats(ske._handle, out)
+    st = ske.sketch_stats(); out = (st['last_scan_pairs'], st['largest_region'], st['longest_sublist'], st['overflow'])
     state = ske.sketch_state()
     t_s = timed(ske, q)
     ske.close()

@@ -21,13 +21,8 @@ torch.cuda.synchronize()
 print("pos equal:", torch.equal(pa, pb), "max |ds|:", (sa - sb).abs().max().item(), "dups:", pb[0, :3].tolist())
 if not torch.equal(pa, pb):
     bad = (pa != pb).nonzero(); print(bad[:5], sa[bad[0,0]], sb[bad[0,0]])
-import ctypes
-from vietnamese_qa_system_amd import _native as N
-if hasattr(N.load(), "vqa_dev_sketch_stats"):
-    st = (ctypes.c_longlong * 4)()
-    N.load().vqa_dev_sketch_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
-    N.load().vqa_dev_sketch_stats(b._handle, st)
-    print(f"candidate pairs {st[0]} ({st[0] / 256:.0f} per query), largest region {st[1]}, longest query list {st[2]}, overflow {st[3]}")
+st = b.sketch_stats()
+print(f"candidate pairs {st['last_scan_pairs']} ({st['last_scan_pairs'] / 256:.0f} per query), largest region {st['largest_region']}, longest query sub-list {st['longest_sublist']}, overflow {st['overflow']}")
 for ix, nm in ((a, "exact"), (b, "sketch")):
     for _ in range(5): ix.search(q, 10)
     ix.set_timing(True); torch.cuda.synchronize(); t0 = time.perf_counter()

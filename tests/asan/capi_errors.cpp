@@ -57,6 +57,14 @@ int main() {
     EXPECT(vqa_index_set_rows(nullptr, 0, 1, s, VQA_F32, nullptr) == VQA_EINVAL);
     EXPECT(vqa_index_get_rows(nullptr, 0, 1, s, nullptr) == VQA_EINVAL);
     EXPECT(vqa_index_launch_info(nullptr, 1, 1, nullptr) == VQA_EINVAL);
+    {
+        int64_t st[8];
+        int8_t codes[16];
+        float info4[4];
+        EXPECT(vqa_index_sketch_stats(nullptr, st) == VQA_EINVAL);
+        EXPECT(vqa_index_get_sketch_tile(nullptr, 0, codes, info4, nullptr) == VQA_EINVAL);
+        EXPECT(vqa_index_sketch_state(nullptr) == -1 && vqa_index_device_bytes(nullptr) == -1);
+    }
     EXPECT(vqa_index_set_timing(nullptr, 1) == VQA_EINVAL);
     double ms;
     int64_t n;

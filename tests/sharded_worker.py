@@ -1,4 +1,4 @@
-"""One rank of the jobs tests/test_gpu_sharded_exec.py and tests/test_gpu_rccl_world1.py start with
+"""One rank of the jobs tests/test_gpu_sharded_exec.py starts with
 ``python -m torch.distributed.run --nproc-per-node R`` (R = 1, 2 or 8).
 
 Runs the REAL sharded path -- DeviceIndex.search (HIP) -> dist.all_gather_into_tensor -> vqa_merge_topk (HIP) -- and

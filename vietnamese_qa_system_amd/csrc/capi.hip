@@ -60,6 +60,7 @@ struct vqa_index {
     size_t up_bytes = 0;
     vqa_key* partial = nullptr;  // [max_grid, 256, max(max_k, seeds per query)]: seed pass output, then main pass lists
     float* thr0 = nullptr;       // [256]
+    float* thr_seed = nullptr;   // [256] the cascade's theta0 (k-th largest exact seed, MFMA arithmetic): kept for its exact fallback
     vqa_key* upper = nullptr;    // [256] last key returned per query (continuation passes of a search with k > 12)
     int* wide_flag = nullptr;    // 1 = the one-pass large-k result could not be verified: the gated continuation passes run
     bool wide = true;            // VQA_WIDE_K=0 disables the one-pass large-k attempt
@@ -77,7 +78,8 @@ struct vqa_index {
     unsigned* region_cnt = nullptr;         // [max_grid]
     vqa_key* cand_keys = nullptr;           // [256][kSketchCap] exact (score, position) keys per query
     unsigned* cand_cnt = nullptr;           // [256][kSketchSubLists]: keys in every sub-list of a query's list
-    int* sketch_flag = nullptr;             // 1 = a candidate buffer filled up: the exact fallback scan runs
+    int* sketch_flag = nullptr;             // [3]: [0] 1 = a candidate buffer filled up in this query tile: its exact fallback scan runs;
+                                            // [1] = OR of [0] over the EARLIER query tiles of the call, [2] = the call's number (sketch_qconst_kernel)
     long long* stage_pos = nullptr;         // [256][max_k] row positions of the first stage's top-k
     float* mu = nullptr;                    // [d_pad8] centre of the shard (mean of the rows of its first fill), subtracted before the sketch
     float* qoff = nullptr;                  // [256] q . mu of the query tile
@@ -86,10 +88,16 @@ struct vqa_index {
     bool center = true;                     // VQA_SKETCH_CENTER=0: no centring (needs the rotated form)
     bool rotate = true;                     // the sketch is cut from rotated rows (convert.hip: sketch_rotate); VQA_SKETCH_ROTATE=0: from the rows as they are
     bool cascade = true;                    // VQA_SKETCH_CASCADE=0: the exact first stage of the narrow sketch form (dev / A-B switch)
-    int* sketch_flag_host = nullptr;        // pinned mirror of sketch_flag, copied behind every sketch search (read by the NEXT call)
+    int* sketch_flag_host = nullptr;        // pinned mirror of sketch_flag [3], copied once behind the last query tile of a call (read by LATER calls)
     int sketch_cooldown = 0;                // searches left that skip the sketch: data the bound cannot prune would pay the sketch scan
-                                            // AND the exact fallback every time (VQA_SKETCH_COOLDOWN searches, default 64, then it tries again)
-    int sketch_cooldown_len = 64;
+                                            // AND the exact fallback every time (VQA_SKETCH_COOLDOWN searches, default 64, then it tries again;
+                                            // every overflow in a row doubles the pause, up to 64 x the base: data the bound never prunes
+                                            // ends up paying one wasted sketch scan per 4096 searches)
+    int sketch_cooldown_len = 64;           // base length
+    int sketch_cooldown_cur = 64;           // length of the next pause
+    int sketch_seq = 0;                     // calls of this handle that ran the sketch search; the device writes the call's number beside its
+    int sketch_seq_seen = 0;                // flags (sketch_flag[2]), so the host reacts ONCE to every completed call, however far it runs ahead
+    int sketch_seq_ignore = 0;              // calls up to this number were queued before the current pause began
     // opt-in kernel timing (bench.py): event pairs around the main scoring kernel
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -143,6 +151,7 @@ extern "C" void vqa_index_destroy(vqa_index* ix) {
     if (ix->sketch_flag_host) (void)hipHostFree(ix->sketch_flag_host);
     if (ix->partial) (void)hipFree(ix->partial);
     if (ix->thr0) (void)hipFree(ix->thr0);
+    if (ix->thr_seed) (void)hipFree(ix->thr_seed);
     if (ix->upper) (void)hipFree(ix->upper);
     if (ix->wide_flag) (void)hipFree(ix->wide_flag);
     for (hipEvent_t e : ix->ev) (void)hipEventDestroy(e);
@@ -228,6 +237,10 @@ extern "C" int vqa_index_set_rows(vqa_index* ix, int64_t first, int64_t count, c
                 "vqa_index_set_rows: the index was created %s an id vector", ix->ids ? "with" : "without");
     if (count == 0) return VQA_OK;
     VQA_REQUIRE(rows, "vqa_index_set_rows: rows is null");
+    // the rows, the sketch's codes and tile_info are what a search of this handle reads: one call at a time per handle (a search
+    // still in flight on a stream is the caller's to order: this call runs on the null stream and synchronises)
+    HandleBusy busy(ix->busy);
+    VQA_REQUIRE(busy.ok, "vqa_index_set_rows: this index handle is in use by another host thread (one call at a time per handle)");
     DeviceGuard guard(ix->device);
     hipPointerAttribute_t attr;
     bool on_device = hipPointerGetAttributes(&attr, rows) == hipSuccess && attr.type == hipMemoryTypeDevice;
@@ -246,9 +259,11 @@ extern "C" int vqa_index_set_rows(vqa_index* ix, int64_t first, int64_t count, c
         VQA_HIP_CHECK(hipStreamSynchronize(nullptr));
         const int64_t t0 = first >> 8, t1 = (first + count - 1) >> 8;
         if (ix->center && !ix->mu_set) {
-            // the shard's centre: the mean of (up to 65 536 of) the rows of its FIRST fill, fixed from then on -- every tile's sketch
-            // must be cut against the same centre; any centre is valid (q . x = q . mu + q . (x - mu)), a good one shortens the rows
-            int rcm = vqa_launch_row_mean(ix->rows, ix->dtype, first, std::min<int64_t>(count, 65536), ix->d_pad, ix->d_pad8, ix->mu, nullptr);
+            // the shard's centre: the mean of (up to 65 536 of) the rows of its FIRST fill -- a strided sample over the whole fill, so
+            // that a corpus stored sorted by topic still gets its overall mean --, fixed from then on: every tile's sketch must be
+            // cut against the same centre; any centre is valid (q . x = q . mu + q . (x - mu)), a good one shortens the rows
+            const int64_t samples = std::min<int64_t>(count, 65536);
+            int rcm = vqa_launch_row_mean(ix->rows, ix->dtype, first, samples, count / samples, ix->d_pad, ix->d_pad8, ix->mu, nullptr);
             if (rcm != VQA_OK) return rcm;
             std::vector<float> h((size_t)ix->d_pad8);
             VQA_HIP_CHECK(hipMemcpy(h.data(), ix->mu, h.size() * 4, hipMemcpyDeviceToHost));
@@ -356,6 +371,7 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
         if (hipMalloc(&ix->q_stage, (size_t)VQA_QUERY_TILE * ix->d_pad * eb) != hipSuccess ||
             hipMalloc((void**)&ix->partial, (size_t)4 * ix->max_grid * VQA_QUERY_TILE * list_len * sizeof(vqa_key)) != hipSuccess ||
             hipMalloc((void**)&ix->thr0, VQA_QUERY_TILE * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&ix->thr_seed, VQA_QUERY_TILE * sizeof(float)) != hipSuccess ||
             hipMalloc((void**)&ix->upper, VQA_QUERY_TILE * sizeof(vqa_key)) != hipSuccess ||
             hipMalloc((void**)&ix->wide_flag, sizeof(int)) != hipSuccess) {
             vqa_set_error("vqa_index_create: workspace allocation failed");
@@ -383,14 +399,14 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
                 hipMalloc((void**)&ix->regions, (size_t)ix->max_grid * kSketchCap * 8) != hipSuccess ||
                 hipMalloc((void**)&ix->region_cnt, (size_t)ix->max_grid * 4) != hipSuccess ||
                 hipMalloc((void**)&ix->cand_keys, (size_t)VQA_QUERY_TILE * kSketchCap * sizeof(vqa_key)) != hipSuccess ||
-                hipMalloc((void**)&ix->cand_cnt, VQA_QUERY_TILE * kSketchSubLists * 4) != hipSuccess || hipMalloc((void**)&ix->sketch_flag, 4) != hipSuccess ||
+                hipMalloc((void**)&ix->cand_cnt, VQA_QUERY_TILE * kSketchSubLists * 4) != hipSuccess || hipMalloc((void**)&ix->sketch_flag, 3 * sizeof(int)) != hipSuccess ||
                 hipMalloc((void**)&ix->stage_pos, (size_t)VQA_QUERY_TILE * max_k * 8) != hipSuccess ||
-                hipHostMalloc((void**)&ix->sketch_flag_host, sizeof(int), hipHostMallocDefault) != hipSuccess) {
+                hipHostMalloc((void**)&ix->sketch_flag_host, 3 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
                 vqa_set_error("vqa_index_create: allocating the int8 sketch (%zu bytes) failed", ix->rows8_bytes);
                 rc = VQA_ENOMEM;
                 break;
             }
-            *ix->sketch_flag_host = 0;
+            ix->sketch_flag_host[0] = ix->sketch_flag_host[1] = ix->sketch_flag_host[2] = 0;
             if (const char* cs = getenv("VQA_SKETCH_CASCADE")) ix->cascade = cs[0] != '0';
             if (const char* ro = getenv("VQA_SKETCH_ROTATE")) ix->rotate = ro[0] != '0';
             if (const char* ce = getenv("VQA_SKETCH_CENTER")) ix->center = ce[0] != '0';
@@ -403,15 +419,26 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
                 break;
             }
             if (const char* cd = getenv("VQA_SKETCH_COOLDOWN")) ix->sketch_cooldown_len = atoi(cd) > 0 ? atoi(cd) : 0;
+            ix->sketch_cooldown_cur = ix->sketch_cooldown_len;
             if (hipMemset(ix->rows8, 0, ix->rows8_bytes) != hipSuccess || hipMemset(ix->tile_info, 0, (size_t)tiles * 16) != hipSuccess ||
+                hipMemset(ix->sketch_flag, 0, 3 * sizeof(int)) != hipSuccess ||
                 hipMemset(ix->q8_stage, 0, (size_t)VQA_QUERY_TILE * ix->d_pad8) != hipSuccess) {
                 vqa_set_error("vqa_index_create: clearing the int8 sketch failed");
                 rc = VQA_EHIP;
                 break;
             }
             if (flags & VQA_INDEX_RESCORE_ROWS) {  // the sketch search's re-scoring then reads whole rows instead of 64-byte pieces
-                // the copy only speeds the re-scoring up: a device too full for it goes without (vqa_index_device_bytes tells)
-                if (hipMalloc(&ix->rows_rm, ix->rows_bytes) != hipSuccess) {
+                // the copy only speeds the re-scoring up: a device too full for it goes without (vqa_index_device_bytes tells) -- and
+                // "too full" leaves the caller room: the copy is only taken when an eighth of the device's memory stays free behind it
+                // (36 GB of 288: the encoder's workspace, torch's allocations, another shard's buffers)
+                size_t mem_free = 0, mem_total = 0;
+                if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) {
+                    (void)hipGetLastError();
+                    mem_free = mem_total = 0;
+                }
+                const char* force = getenv("VQA_RESCORE_COPY");
+                const bool room = (force && force[0] == '1') || mem_total == 0 || mem_free >= ix->rows_bytes + mem_total / 8;
+                if (!room || hipMalloc(&ix->rows_rm, ix->rows_bytes) != hipSuccess) {
                     (void)hipGetLastError();
                     ix->rows_rm = nullptr;
                 } else if (hipMemset(ix->rows_rm, 0, ix->rows_bytes) != hipSuccess) {
@@ -480,7 +507,10 @@ extern "C" int32_t vqa_index_dtype(const vqa_index* ix) { return ix ? ix->dtype 
 extern "C" int32_t vqa_index_sketch_state(const vqa_index* ix) {
     if (!ix || !ix->sketch) return -1;
     // (the flag of the last sketch search arrives in the pinned mirror when that search has completed)
-    if (__atomic_load_n(ix->sketch_flag_host, __ATOMIC_RELAXED) != 0) return ix->sketch_cooldown_len > 0 ? ix->sketch_cooldown_len : 1;
+    // a completed call's report the host has not looked at yet: what the next search will do with it
+    if (__atomic_load_n(ix->sketch_flag_host + 2, __ATOMIC_RELAXED) != ix->sketch_seq_seen &&
+        (__atomic_load_n(ix->sketch_flag_host, __ATOMIC_RELAXED) | __atomic_load_n(ix->sketch_flag_host + 1, __ATOMIC_RELAXED)) != 0)
+        return ix->sketch_cooldown_cur > 0 ? ix->sketch_cooldown_cur : 1;
     return ix->sketch_cooldown;
 }
 
@@ -621,8 +651,8 @@ static ScoreTopkArgs exact_launch_args(const vqa_index* ix, int nq, int k) {
 }
 
 // Seed pass: the plan's first seed_tiles tiles scored by the MODE 0 kernel (sub-maxima per query and tile) and the `rank`-th
-// largest of them per query -> ix->thr0, the starting threshold of the launches behind it (`a` carries upper / gate)
-static int seed_pass(vqa_index* ix, const LaunchPlan& p, ScoreTopkArgs a, int rank, const int* gate, hipStream_t stream) {
+// largest of them per query -> thr_out (ix->thr0 by default), the starting threshold of the launches behind it (`a` carries upper / gate)
+static int seed_pass(vqa_index* ix, const LaunchPlan& p, ScoreTopkArgs a, int rank, const int* gate, hipStream_t stream, float* thr_out = nullptr) {
     a.thr_init = nullptr;
     a.tile_begin = 0;
     a.tile_end = p.seed_tiles;
@@ -631,17 +661,19 @@ static int seed_pass(vqa_index* ix, const LaunchPlan& p, ScoreTopkArgs a, int ra
     a.seeds_per_tile = p.seeds_per_tile;
     int rc = vqa_launch_score_topk(ix->dtype, a, stream);
     if (rc != VQA_OK) return rc;
-    return vqa_launch_merge_partials(ix->partial, p.seed_tiles, p.seeds_per_tile, a.nq, rank, nullptr, 0, nullptr, nullptr, nullptr, ix->thr0,
-                                     1.0f, rank, 0, nullptr, true, gate, stream);
+    return vqa_launch_merge_partials(ix->partial, p.seed_tiles, p.seeds_per_tile, a.nq, rank, nullptr, 0, nullptr, nullptr, nullptr,
+                                     thr_out ? thr_out : ix->thr0, 1.0f, rank, 0, nullptr, true, gate, stream);
 }
 
-// One sketch scan of tiles [tile_begin, tile_end) against theta = ix->thr0 and the exact scores of what it leaves: per-query
+// One sketch scan of tiles [tile_begin, tile_end) against theta = thr[] and the exact scores of what it leaves: per-query
 // constants -> int8 scan -> re-scoring of its candidate pairs (and of `stage_k` first-stage rows per query, ix->stage_pos) into
-// the queries' candidate lists.  `clear`: this is the search's first scan (counters and overflow flag start at zero).
-static int sketch_scan_rescore(vqa_index* ix, const LaunchPlan& p, int tile_begin, int tile_end, int nq, int stage_k, bool clear, bool timed,
-                               hipStream_t stream) {
-    int rc = vqa_launch_sketch_qconst(ix->thr0, ix->qrow, ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, ix->d_pad, ix->qconst,
-                                      ix->cand_cnt, ix->sketch_flag, clear, ix->rotate, ix->center ? ix->qoff : nullptr, ix->mu_norm, stream);
+// the queries' candidate lists.  `clear`: 1 / 2 = this is the query tile's first scan (counters and overflow flag start at zero;
+// 2: the first tile of the call), 0 = a later one.
+static int sketch_scan_rescore(vqa_index* ix, const LaunchPlan& p, const float* thr, int tile_begin, int tile_end, int nq, int stage_k, int clear,
+                               bool timed, hipStream_t stream) {
+    const int seq = ix->sketch_seq;
+    int rc = vqa_launch_sketch_qconst(thr, ix->qrow, ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, ix->d_pad, ix->qconst,
+                                      ix->cand_cnt, ix->sketch_flag, clear, seq, ix->rotate, ix->center ? ix->qoff : nullptr, ix->mu_norm, stream);
     if (rc != VQA_OK) return rc;
     SketchScanArgs sk;
     sk.tile_info = reinterpret_cast<const float4*>(ix->tile_info);
@@ -671,14 +703,12 @@ static int sketch_scan_rescore(vqa_index* ix, const LaunchPlan& p, int tile_begi
                               ix->rows_rm, ix->q_stage, ix->dtype, ix->d_pad, ix->cand_keys, ix->cand_cnt, kSketchCap, ix->sketch_flag, stream);
 }
 
-// the k best of every query's candidate list -> the caller's outputs (os == nullptr: only their k-th score -> ix->thr0); with
-// outputs, the overflow flag also goes to its pinned mirror.  The caller enqueues its exact fallback behind, gated on ix->sketch_flag.
+// the k best of every query's candidate list -> the caller's outputs (os == nullptr: only their k-th score -> ix->thr0).  The
+// caller enqueues its exact fallback behind, gated on ix->sketch_flag.
 static int sketch_select(vqa_index* ix, int nq, int k, float* os, int64_t* oi, int64_t* op, hipStream_t stream) {
     int rc = vqa_launch_merge_partials(ix->cand_keys, kSketchSubLists, kSketchCap / kSketchSubLists, nq, k, os ? ix->ids : nullptr, ix->id_base, os,
                                        oi, op, os ? nullptr : ix->thr0, 1.0f, k, 0, nullptr, true, nullptr, stream, kSketchSubLists, ix->cand_cnt);
-    if (rc != VQA_OK) return rc;
-    if (os) VQA_HIP_CHECK(hipMemcpyAsync(ix->sketch_flag_host, ix->sketch_flag, sizeof(int), hipMemcpyDeviceToHost, stream));
-    return VQA_OK;
+    return rc;
 }
 
 extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, int32_t B, int32_t k, float* out_scores,
@@ -695,6 +725,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
     DeviceGuard guard(ix->device);
     const int qeb = q_dtype == VQA_F32 ? 4 : 2;
     const LaunchPlan p = plan_launch(ix, k);
+    bool sketch_call = false;  // some query tile of this call ran the sketch search
     for (int q0 = 0; q0 < B; q0 += VQA_QUERY_TILE) {
         const int nq = B - q0 < VQA_QUERY_TILE ? B - q0 : VQA_QUERY_TILE;
         float* os = out_scores + (size_t)q0 * k;
@@ -717,14 +748,32 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
         // An earlier sketch search of this handle that overflowed into its exact fallback (its flag arrives in the pinned mirror
         // some time after that call; a stale read only delays the reaction by a search) switches the sketch off for a while
         if (ix->sketch && q0 == 0) {
-            if (__atomic_load_n(ix->sketch_flag_host, __ATOMIC_RELAXED) != 0) {
-                __atomic_store_n(ix->sketch_flag_host, 0, __ATOMIC_RELAXED);
-                ix->sketch_cooldown = ix->sketch_cooldown_len;
+            // (the three words arrive by one 12-byte DMA; the number is read first, so a report caught half-way is at worst taken
+            // for the previous call's and looked at again next time)
+            const int seq = __atomic_load_n(ix->sketch_flag_host + 2, __ATOMIC_ACQUIRE);
+            const bool over = (__atomic_load_n(ix->sketch_flag_host, __ATOMIC_RELAXED) | __atomic_load_n(ix->sketch_flag_host + 1, __ATOMIC_RELAXED)) != 0;
+            if (seq != ix->sketch_seq_seen) {  // a sketch search completed since the last look
+                ix->sketch_seq_seen = seq;
+                // (reports of calls that were already queued when the current pause began say nothing new)
+                const bool fresh = (int)((unsigned)seq - (unsigned)ix->sketch_seq_ignore) > 0;
+                if (over && fresh) {
+                    ix->sketch_cooldown = ix->sketch_cooldown_cur;
+                    // overflow, pause, overflow again: the pause doubles (64, 128, ... 4096 searches)
+                    ix->sketch_cooldown_cur = std::min(2 * ix->sketch_cooldown_cur, 64 * ix->sketch_cooldown_len);
+                    ix->sketch_seq_ignore = ix->sketch_seq;
+                } else if (!over && fresh && ix->sketch_cooldown == 0) {
+                    ix->sketch_cooldown_cur = ix->sketch_cooldown_len;  // a sketch search stood: back to the base pause
+                }
             } else if (ix->sketch_cooldown > 0) {
                 --ix->sketch_cooldown;
             }
         }
         const bool any_sketch = sketch_active(ix, p, k) && ix->sketch_cooldown == 0;
+        if (any_sketch && q0 == 0) {
+            ++ix->sketch_seq;
+            sketch_call = true;
+        }
+        const int sk_clear = q0 == 0 ? 2 : 1;  // the call's first query tile also clears the OR over the tiles
         const bool use_sketch = any_sketch && k <= max_k && !ix->cascade;  // the round's first form (VQA_SKETCH_CASCADE=0: A/B switch)
         if (any_sketch) {  // the query tile's int8 sketch (every query its own scale) + ||q_lo||, ||q||
             rc = vqa_launch_sketch_rows(ix->q_stage, ix->dtype, 0, VQA_QUERY_TILE, ix->d_pad, ix->d_pad8, nullptr, ix->q8_stage, ix->qrow,
@@ -746,25 +795,27 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             //   score of those rows (every row of theirs that reaches theta0 is a candidate; the seeds' k rows are among them);
             //   sketch scan of the other tiles against theta1, candidates scored exactly into the same lists; the k best of a list
             //   are the result.  An overflow anywhere raises sketch_flag, and the exact search runs gated on it: for k <= 12 ONE pass
-            //   over all tiles seeded with theta1 (whatever survived of the lists gives a valid bound), for larger k the gated
-            //   exact passes below.
+            //   over all tiles seeded with theta0 -- NOT theta1: that is a sum in the re-scoring kernel's order, and the scan's
+            //   `score >= threshold` test on MFMA sums could drop the very row that defines it by an ulp; theta0 is an MFMA sum of
+            //   the same kernel family (test_small_k_fallback_keeps_the_row_that_defines_theta) --, for larger k the gated exact
+            //   passes below.
             LaunchPlan pc = p;
             pc.seed_tiles = std::min(2 * p.grid1, p.stage_tiles);  // (1-4 tiles per workgroup x 6-14 % first stage: 2.00-2.03 ms at 10M rows)
             pc.grid0 = std::min(pc.seed_tiles, ix->max_grid);
             pc.seeds_per_tile = 2;
             ScoreTopkArgs a = exact_launch_args(ix, nq, k <= max_k ? k : max_k);
-            rc = seed_pass(ix, pc, a, k, nullptr, stream);
+            rc = seed_pass(ix, pc, a, k, nullptr, stream, ix->thr_seed);  // theta0 -> thr_seed
             if (rc != VQA_OK) return rc;
-            rc = sketch_scan_rescore(ix, p, 0, p.stage_tiles, nq, 0, true, false, stream);
+            rc = sketch_scan_rescore(ix, p, ix->thr_seed, 0, p.stage_tiles, nq, 0, sk_clear, false, stream);
             if (rc != VQA_OK) return rc;
             rc = sketch_select(ix, nq, k, nullptr, nullptr, nullptr, stream);  // theta1 -> thr0
             if (rc != VQA_OK) return rc;
-            rc = sketch_scan_rescore(ix, p, p.stage_tiles, p.tiles, nq, 0, false, true, stream);
+            rc = sketch_scan_rescore(ix, p, ix->thr0, p.stage_tiles, p.tiles, nq, 0, 0, true, stream);
             if (rc != VQA_OK) return rc;
             rc = sketch_select(ix, nq, k, os, oi, op, stream);
             if (rc != VQA_OK) return rc;
             if (k <= max_k) {
-                a.thr_init = ix->thr0;
+                a.thr_init = ix->thr_seed;
                 a.tile_begin = 0;
                 a.tile_end = p.tiles;
                 a.grid = p.grid1;
@@ -837,7 +888,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
                     // first stage's k rows are scored exactly and the k best of each query's list are the result.  Should a
                     // candidate buffer fill up (adversarial data: the bound prunes nothing), sketch_flag sends the search through
                     // the exact main launch below, gated on the flag.
-                    rc = sketch_scan_rescore(ix, p, p.stage_tiles, p.tiles, nq, kk, true, true, stream);
+                    rc = sketch_scan_rescore(ix, p, ix->thr0, p.stage_tiles, p.tiles, nq, kk, sk_clear, true, stream);
                     if (rc != VQA_OK) return rc;
                     rc = sketch_select(ix, nq, kk, os, oi, op, stream);
                     if (rc != VQA_OK) return rc;
@@ -855,31 +906,66 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             if (rc != VQA_OK) return rc;
         }
     }
+    // the overflow flags of this call (its last tile's, the OR over the earlier ones, the call's number) -> the pinned mirror a later
+    // call's cool-down bookkeeping reads
+    if (sketch_call) VQA_HIP_CHECK(hipMemcpyAsync(ix->sketch_flag_host, ix->sketch_flag, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
     return VQA_OK;
 }
 
-#ifdef VQA_DEV
-// dev-only (scripts/probes/sketch_probe.py, -DVQA_DEV builds): what the last sketch search left in its candidate buffers --
-// out[0] = candidate pairs of the scan, out[1] = largest region, out[2] = longest per-query list, out[3] = overflow flag
-extern "C" int vqa_dev_sketch_stats(vqa_index* ix, long long* out) {
-    VQA_REQUIRE(ix && out && ix->sketch, "vqa_dev_sketch_stats: no sketch");
+// ---- diagnostics of the sketch search (bench.py prices a step's physical bytes from the pair counts; tests/test_gpu_sketch_bound.py
+// compares a tile's codes and maxima with a restatement of its own).  Both synchronise the device: never on a hot path.
+extern "C" int vqa_index_sketch_stats(vqa_index* ix, int64_t* out) {
+    VQA_REQUIRE(ix && out, "vqa_index_sketch_stats: null pointer");
+    VQA_REQUIRE(ix->sketch, "vqa_index_sketch_stats: the shard keeps no sketch");
     DeviceGuard guard(ix->device);
     VQA_HIP_CHECK(hipDeviceSynchronize());
-    std::vector<unsigned> rc(ix->max_grid), cc(VQA_QUERY_TILE * kSketchSubLists);  // (out[2]: the longest SUB-list)
-    int flag = 0;
+    std::vector<unsigned> rc(ix->max_grid), cc(VQA_QUERY_TILE * kSketchSubLists);
+    int flag[3] = {0, 0, 0};
     VQA_HIP_CHECK(hipMemcpy(rc.data(), ix->region_cnt, rc.size() * 4, hipMemcpyDeviceToHost));
     VQA_HIP_CHECK(hipMemcpy(cc.data(), ix->cand_cnt, cc.size() * 4, hipMemcpyDeviceToHost));
-    VQA_HIP_CHECK(hipMemcpy(&flag, ix->sketch_flag, 4, hipMemcpyDeviceToHost));
-    long long sum = 0, mx = 0, mq = 0;
+    VQA_HIP_CHECK(hipMemcpy(flag, ix->sketch_flag, sizeof(flag), hipMemcpyDeviceToHost));
+    int64_t sum = 0, mx = 0, qsum = 0, mq = 0;
     for (unsigned v : rc) {
         sum += v;
-        mx = std::max<long long>(mx, v);
+        mx = std::max<int64_t>(mx, v);
     }
-    for (unsigned v : cc) mq = std::max<long long>(mq, v);
-    out[0] = sum;
-    out[1] = mx;
-    out[2] = mq;
-    out[3] = flag;
+    for (unsigned v : cc) {
+        qsum += v;
+        mq = std::max<int64_t>(mq, v);
+    }
+    out[0] = sum;   // candidate pairs the LAST sketch scan of the last query tile left (a cascade: its second, main scan)
+    out[1] = mx;    // ... the fullest workgroup region of that scan (capacity kSketchCap)
+    out[2] = qsum;  // pairs scored exactly for that query tile: every scan of its cascade
+    out[3] = mq;    // ... the longest candidate sub-list (capacity kSketchCap / kSketchSubLists)
+    out[4] = flag[0];  // 1: that tile overflowed into its exact fallback
+    out[5] = flag[1];  // 1: an earlier query tile of the same call did
+    out[6] = kSketchCap;
+    out[7] = kSketchCap / kSketchSubLists;
     return VQA_OK;
 }
-#endif
+
+extern "C" int vqa_index_get_sketch_tile(vqa_index* ix, int64_t tile, int8_t* out_codes, float* out_info, float* out_mu_or_null) {
+    VQA_REQUIRE(ix && out_codes && out_info, "vqa_index_get_sketch_tile: null pointer");
+    VQA_REQUIRE(ix->sketch, "vqa_index_get_sketch_tile: the shard keeps no sketch");
+    const int64_t tiles = (ix->n + 255) / 256;
+    VQA_REQUIRE(tile >= 0 && tile < tiles, "vqa_index_get_sketch_tile: tile %lld outside [0, %lld)", (long long)tile, (long long)tiles);
+    DeviceGuard guard(ix->device);
+    const size_t bytes = (size_t)256 * ix->d_pad8;
+    void* dev = nullptr;
+    if (hipMalloc(&dev, bytes) != hipSuccess) {
+        vqa_set_error("vqa_index_get_sketch_tile: hipMalloc of %zu bytes failed", bytes);
+        return VQA_ENOMEM;
+    }
+    // the sketch is a TILED array of one-byte elements (K-blocks of 64): the fp8 form of the untile kernel moves bytes
+    int rc = vqa_launch_untile_rows(ix->rows8, tile * 256, 256, ix->d_pad8, ix->d_pad8, VQA_FP8_E4M3, dev, nullptr);
+    hipError_t e = rc == VQA_OK ? hipMemcpy(out_codes, dev, bytes, hipMemcpyDeviceToHost) : hipSuccess;
+    (void)hipFree(dev);
+    if (rc != VQA_OK) return rc;
+    VQA_HIP_CHECK(e);
+    VQA_HIP_CHECK(hipMemcpy(out_info, ix->tile_info + 4 * tile, 16, hipMemcpyDeviceToHost));
+    if (out_mu_or_null) {
+        if (ix->mu) VQA_HIP_CHECK(hipMemcpy(out_mu_or_null, ix->mu, (size_t)ix->d_pad8 * 4, hipMemcpyDeviceToHost));
+        else memset(out_mu_or_null, 0, (size_t)ix->d_pad8 * 4);
+    }
+    return VQA_OK;
+}

@@ -405,11 +405,11 @@ __global__ __launch_bounds__(256) void tile_scale_kernel(const SRC* __restrict__
     }
 }
 
-// centre of a shard: mean of rows [first, first + count) of a TILED array, element by element -> mu [d8] (zero past the row's padding);
+// centre of a shard: mean of the `count` rows first, first + stride, ... of a TILED array, element by element -> mu [d8] (zero past the row's padding);
 // one workgroup per 16-element unit, 256 threads over the rows
 template <typename SRC>
-__global__ __launch_bounds__(256) void row_mean_kernel(const SRC* __restrict__ tiled, long long first, long long count, int KTS,
-                                                       float* __restrict__ mu) {
+__global__ __launch_bounds__(256) void row_mean_kernel(const SRC* __restrict__ tiled, long long first, long long count, long long stride,
+                                                       int KTS, float* __restrict__ mu) {
     __shared__ float red[256][17];
     const int u = blockIdx.x;
     float acc[16];
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void row_mean_kernel(const SRC* __restrict__ t
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     for (long long r = threadIdx.x; r < count; r += 256) {
         float x[16];
-        load_sketch_unit<SRC>(tiled, first + r, u, KTS, x);
+        load_sketch_unit<SRC>(tiled, first + r * stride, u, KTS, x);
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] += x[e];
     }
@@ -434,15 +434,15 @@ __global__ __launch_bounds__(256) void row_mean_kernel(const SRC* __restrict__ t
 
 }  // namespace
 
-int vqa_launch_row_mean(const void* tiled, int32_t src_dtype, int64_t first, int64_t count, int32_t d_pad_src, int32_t d_pad8, float* mu,
-                        hipStream_t stream) {
-    VQA_REQUIRE(count > 0 && (src_dtype == VQA_F16 || src_dtype == VQA_F32), "row_mean: bad arguments");
+int vqa_launch_row_mean(const void* tiled, int32_t src_dtype, int64_t first, int64_t count, int64_t stride, int32_t d_pad_src, int32_t d_pad8,
+                        float* mu, hipStream_t stream) {
+    VQA_REQUIRE(count > 0 && stride >= 1 && (src_dtype == VQA_F16 || src_dtype == VQA_F32), "row_mean: bad arguments");
     if (src_dtype == VQA_F16)
         hipLaunchKernelGGL(row_mean_kernel<_Float16>, dim3(d_pad8 / 16), dim3(256), 0, stream, reinterpret_cast<const _Float16*>(tiled),
-                           (long long)first, (long long)count, d_pad_src / 32, mu);
+                           (long long)first, (long long)count, (long long)stride, d_pad_src / 32, mu);
     else
         hipLaunchKernelGGL(row_mean_kernel<float>, dim3(d_pad8 / 16), dim3(256), 0, stream, reinterpret_cast<const float*>(tiled),
-                           (long long)first, (long long)count, d_pad_src / 16, mu);
+                           (long long)first, (long long)count, (long long)stride, d_pad_src / 16, mu);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void rows_to_rowmajor_kernel(const uint4* __re
 // candidate counters and the overflow flag of this search
 __global__ void sketch_qconst_kernel(const float* __restrict__ thr, const float* __restrict__ qscale, const float* __restrict__ qlo,
                                      const float* __restrict__ qnorm, float fp_margin, float* __restrict__ qconst,
-                                     unsigned* __restrict__ cand_cnt, int* __restrict__ overflow, int clear,
+                                     unsigned* __restrict__ cand_cnt, int* __restrict__ overflow, int clear, int seq,
                                      const float* __restrict__ qoff, float mu_norm) {
     const int q = threadIdx.x;
     // a centred sketch bounds q . (x - mu): the threshold moves by q . mu (fp32 dot: its rounding and that of x - mu, <= 2 gamma_d
@@ -143,19 +143,25 @@ __global__ void sketch_qconst_kernel(const float* __restrict__ thr, const float*
     if (clear) {  // (the second scan of a cascade keeps what the first one found)
 #pragma unroll
         for (int j = 0; j < kSketchSubLists; ++j) cand_cnt[q * kSketchSubLists + j] = 0u;
-        if (q == 0) *overflow = 0;
+        if (q == 0) {
+            // overflow[0]: this query tile's flag (gates its exact fallback); overflow[1]: OR over the earlier tiles of the call
+            // (clear == 2: the call's first tile), so that the host's cool-down sees an overflow of ANY tile of a B > 256 call
+            overflow[1] = clear == 2 ? 0 : (overflow[1] | overflow[0]);
+            overflow[0] = 0;
+            overflow[2] = seq;  // which call of the handle these flags belong to (the host's cool-down bookkeeping, capi.hip)
+        }
     }
 }
 
 }  // namespace
 
 int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float* qlo, const float* qnorm, int32_t d, float* qconst,
-                             unsigned* cand_cnt, int* overflow, bool clear, bool rotated, const float* qoff, float mu_norm,
+                             unsigned* cand_cnt, int* overflow, int clear, int seq, bool rotated, const float* qoff, float mu_norm,
                              hipStream_t stream) {
     // 2 gamma_d with gamma_d <= d 2^-24 / (1 - d 2^-24) < 1.2e-7 d / 2 ... kept at twice that; a rotated sketch adds the rounding of
     // the two rotations (13 butterfly stages + the normalisation: 14 2^-24 per side, kept at twice that too)
     const float fp_margin = 2.0f * (float)d * 1.2e-7f + (rotated ? 4.0f * 14.0f * 6e-8f : 0.f);
-    hipLaunchKernelGGL(sketch_qconst_kernel, dim3(1), dim3(256), 0, stream, thr, qscale, qlo, qnorm, fp_margin, qconst, cand_cnt, overflow, clear ? 1 : 0, qoff,
+    hipLaunchKernelGGL(sketch_qconst_kernel, dim3(1), dim3(256), 0, stream, thr, qscale, qlo, qnorm, fp_margin, qconst, cand_cnt, overflow, clear, seq, qoff,
                        mu_norm);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;

@@ -152,15 +152,18 @@ int vqa_launch_sketch_rows(const void* tiled, int32_t src_dtype, int64_t first, 
                            bool rotate /* sketch T x instead of x (convert.hip: sketch_rotate); rows and queries alike */,
                            const float* mu /* the shard's centre [d_pad8] or nullptr */, bool center /* index rows: sketch x - mu */,
                            float* row_off /* query rows: q . mu per row, or nullptr */, hipStream_t stream);
-// mean of rows [first, first + count) of a TILED array -> mu [d_pad8]
-int vqa_launch_row_mean(const void* tiled, int32_t src_dtype, int64_t first, int64_t count, int32_t d_pad_src, int32_t d_pad8, float* mu,
-                        hipStream_t stream);
+// mean of the `count` rows first, first + stride, first + 2 stride, ... of a TILED array -> mu [d_pad8]
+int vqa_launch_row_mean(const void* tiled, int32_t src_dtype, int64_t first, int64_t count, int64_t stride, int32_t d_pad_src, int32_t d_pad8,
+                        float* mu, hipStream_t stream);
 // scale (= max |x| / 127) of tiles [tile0, tile0 + ntiles) of a TILED fp16 / fp32 array into tile_info; clears their two maxima
 int vqa_launch_tile_scales(const void* tiled, int32_t src_dtype, int64_t tile0, int64_t ntiles, int32_t d_pad_src, int32_t d_pad8,
                            float* tile_info, bool rotate, const float* mu, hipStream_t stream);
 // sketch search: per-query constants of the scan + reset of the candidate counters; exact scores of the candidate pairs
 int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float* qlo, const float* qnorm, int32_t d, float* qconst,
-                             unsigned* cand_cnt, int* overflow, bool clear /* reset the candidate counters and the overflow flag */,
+                             unsigned* cand_cnt, int* overflow /* [3]: this tile's flag, OR over the call's earlier tiles, seq */,
+                             int clear /* 0: keep; 1: reset the candidate counters and the tile's overflow flag (OR-ed into overflow[1]
+                                          first); 2: the same for the first query tile of a call (overflow[1] = 0) */,
+                             int seq /* written to overflow[2] when clearing: the call these flags belong to */,
                              bool rotated /* the sketch is of rotated rows: the rotation's rounding joins the margin */,
                              const float* qoff /* q . mu per query or nullptr */, float mu_norm, hipStream_t stream);
 int vqa_launch_rescore(const unsigned long long* regions, const unsigned* counts, int cap, int nregions, const long long* stage_pos,

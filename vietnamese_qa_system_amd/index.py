@@ -230,6 +230,25 @@ class DeviceIndex:
         """-1: no sketch; 0: searches take the sketch search; n > 0: an overflow sent the next n searches to the exact scan."""
         return int(self._lib.vqa_index_sketch_state(self._handle))
 
+    def sketch_stats(self) -> dict:
+        """Diagnostics of the last sketch search of this handle (synchronises the device; ``include/vqa_retrieval.h``)."""
+        out = (ctypes.c_int64 * 8)()
+        N.check(self._lib.vqa_index_sketch_stats(self._handle, out), "vqa_index_sketch_stats")
+        names = ("last_scan_pairs", "largest_region", "rescored_pairs", "longest_sublist", "overflow", "overflow_earlier_tiles",
+                 "region_capacity", "sublist_capacity")
+        return dict(zip(names, (int(v) for v in out)))
+
+    def sketch_tile(self, tile: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(int8 codes [256, d8], tile_info [4] = (max ||x_hi||, max ||x_lo||, 1 / scale, scale), centre mu [d8]) of one tile of
+        the sketch -- what its score bound is computed from (tests restate it independently)."""
+        d8 = (self.d + 127) // 128 * 128
+        codes = np.empty((256, d8), dtype=np.int8)
+        info = np.empty((4,), dtype=np.float32)
+        mu = np.empty((d8,), dtype=np.float32)
+        N.check(self._lib.vqa_index_get_sketch_tile(self._handle, int(tile), codes.ctypes.data, info.ctypes.data, mu.ctypes.data),
+                "vqa_index_get_sketch_tile")
+        return codes, info, mu
+
     def launch_info(self, b: int, k: int) -> N.LaunchInfo:
         info = N.LaunchInfo()
         N.check(self._lib.vqa_index_launch_info(self._handle, int(b), int(k), ctypes.byref(info)), "vqa_index_launch_info")

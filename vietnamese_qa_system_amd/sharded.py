@@ -38,7 +38,7 @@ class ShardedSearcher:
 
     ``always_gather`` (default: the environment variable ``VQA_ALWAYS_GATHER=1``) runs the all-gather and the merge even in
     a process group of ONE rank, so that a single-GPU box takes every collective call of the N > 1 path through RCCL
-    (``tests/test_gpu_rccl_world1.py``); without it a lone rank returns its shard's result directly."""
+    (``tests/test_gpu_sharded_exec.py::test_one_rank_over_rccl``); without it a lone rank returns its shard's result directly."""
 
     def __init__(self, local_search: Callable[[torch.Tensor, int, torch.Tensor, torch.Tensor], None],
                  merge: Optional[Callable[[torch.Tensor, torch.Tensor, int], Tuple[torch.Tensor, torch.Tensor]]] = None,
