@@ -607,6 +607,41 @@ def other_configs(torch, np, device, dev_index, n, d, b, k):
     emb._index.close()
     if d == 768:
         out["non_isotropic"] = non_isotropic_legs(torch, np, device, dev_index, b, k)
+    out["reference_model_shapes"] = reference_model_shapes(torch, np, device, dev_index, b)
+    return out
+
+
+def reference_model_shapes(torch, np, device, dev_index, b, L=32):
+    """Forward time of the two encoders the reference's retriever loads (heavy_ranker.py:80,83), by their published shapes, random-init
+    weights: paraphrase-multilingual-MiniLM-L12-v2 (BERT, hidden 384, 12 heads of 32, FFN 1536) and paraphrase-multilingual-mpnet-base-v2
+    (XLM-R base, vocab 250 002).  B x L = 256 x 32 ragged questions (packed), mean pooling + L2 norm; and one 128-token batch."""
+    from vietnamese_qa_system_amd.encoder import MINILM_L12, XLMR_BASE
+    out = {}
+    for name, cfg in (("minilm_l12_h384_dh32", MINILM_L12), ("xlmr_base_h768_dh64", XLMR_BASE)):
+        enc, ids, mask, lens, g = make_encoder(torch, device, dev_index, b, L, max_tokens=64 * 128, cfg=cfg)
+        h, f, layers = cfg["hidden"], cfg["ffn"], cfg["layers"]
+
+        def timed(ids, mask, lens, reps=12):
+            real = int(lens.sum())
+            for _ in range(3):
+                enc.forward(ids, mask, pooling="mean", normalize=True, real_tokens=real)
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+            for e0, e1 in ev:
+                e0.record()
+                enc.forward(ids, mask, pooling="mean", normalize=True, real_tokens=real)
+                e1.record()
+            torch.cuda.synchronize(device)
+            ms = float(np.median([e0.elapsed_time(e1) for e0, e1 in ev]))
+            lf = lens.double()
+            flops = layers * (float(lf.sum()) * 2 * (4 * h * h + 2 * h * f) + float((lf * lf).sum()) * 4 * h)
+            return {"forward_ms": round(ms, 4), "real_tokens": real, "sequences": int(ids.shape[0]), "max_len": int(ids.shape[1]),
+                    "tflops": round(flops / (ms * 1e-3) / 1e12, 1), "frac_of_f16_mfma_peak": round(flops / (ms * 1e-3) / 1e12 / F16_MFMA_PEAK_TFLOPS, 4)}
+
+        out[name] = {"questions_256x32": timed(ids, mask, lens)}
+        ids2, mask2, lens2 = make_tokens(torch, device, g, cfg, 64, 128)
+        out[name]["passages_64x128"] = timed(ids2, mask2, lens2)
+        enc.close()
+        torch.cuda.empty_cache()
     return out
 
 
@@ -692,10 +727,10 @@ def non_isotropic_legs(torch, np, device, dev_index, b, k):
     return legs
 
 
-def make_encoder(torch, device, dev_index, b, L, max_tokens=None):
-    """PhoBERT-base-shaped encoder with seeded random weights + one synthetic ragged token batch (lengths uniform 8..L)."""
+def make_encoder(torch, device, dev_index, b, L, max_tokens=None, cfg=None):
+    """PhoBERT-base-shaped encoder (or `cfg`) with seeded random weights + one synthetic ragged token batch (lengths uniform 8..L)."""
     from vietnamese_qa_system_amd.encoder import PHOBERT_BASE, QuestionEncoder
-    cfg = PHOBERT_BASE
+    cfg = cfg or PHOBERT_BASE
     g = torch.Generator(device=device)
     g.manual_seed(4321)
     h, f = cfg["hidden"], cfg["ffn"]

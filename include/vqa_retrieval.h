@@ -176,11 +176,16 @@ int vqa_index_get_timing(vqa_index* index, double* kernel_ms_sum, int64_t* launc
 
 /* ---- question encoder: replaces the transformer forward + pooling + L2-normalise inside txtai
  * (model chosen by `path=` at heavy_ranker.py:80,83; DPR form at src/test.py:84-86 `.pooler_output`).
- * RoBERTa/PhoBERT-base-shaped post-LN encoder.  All weight pointers are fp32, host or device, copied (and
+ * BERT-family post-LN encoder: RoBERTa / PhoBERT / XLM-R (paraphrase-multilingual-mpnet-base-v2, heavy_ranker.py:83: hidden 768,
+ * 12 heads of 64, vocab 250 002, 514 positions) and BERT (paraphrase-multilingual-MiniLM-L12-v2, heavy_ranker.py:80: hidden 384,
+ * 12 heads of 32, FFN 1536, absolute position ids); head sizes 64 and 32 run the matrix-core attention kernel.  All weight pointers are fp32, host or device, copied (and
  * converted to fp16) at create time. */
+#define VQA_POS_ROBERTA 0  /* position id = pad_id + number of non-pad tokens up to and including this one (RoBERTa, XLM-R, PhoBERT) */
+#define VQA_POS_ABSOLUTE 1 /* position id = index of the token in its sequence (BERT: paraphrase-multilingual-MiniLM-L12-v2, heavy_ranker.py:80) */
 typedef struct vqa_encoder_config {
     int32_t vocab_size, hidden, layers, heads, ffn, max_pos, type_vocab, pad_id;
     float ln_eps;
+    int32_t position_ids; /* VQA_POS_*; token_type ids are 0 for every token either way (row 0 of the type table) */
 } vqa_encoder_config;
 
 typedef struct vqa_encoder_layer_weights {

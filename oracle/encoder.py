@@ -49,7 +49,12 @@ def linear(x: np.ndarray, w: np.ndarray, b: np.ndarray) -> np.ndarray:
 
 
 def embed(w: dict, cfg: dict, input_ids: np.ndarray) -> np.ndarray:
-    pos = position_ids(input_ids, cfg["pad_id"])
+    # RoBERTa / XLM-R: pad-offset ids; BERT (``transformers/models/bert/modeling_bert.py`` ``BertEmbeddings``: the registered buffer
+    # ``position_ids = arange(max_pos)[:, :L]``): the token's index -- paraphrase-multilingual-MiniLM-L12-v2 (heavy_ranker.py:80)
+    if cfg.get("position_ids", "roberta") == "absolute":
+        pos = np.broadcast_to(np.arange(input_ids.shape[1]), input_ids.shape)
+    else:
+        pos = position_ids(input_ids, cfg["pad_id"])
     x = (w["embeddings.word_embeddings.weight"][input_ids] + w["embeddings.position_embeddings.weight"][pos]
          + w["embeddings.token_type_embeddings.weight"][0])
     return layer_norm(x, w["embeddings.LayerNorm.weight"], w["embeddings.LayerNorm.bias"], cfg["ln_eps"])
@@ -112,6 +117,10 @@ def encode(w: dict, cfg: dict, input_ids, attention_mask, pooling: str = "cls", 
 # generator, so only inputs/outputs need to be committed -------------------------------------------------------------
 PHOBERT_BASE = dict(vocab_size=64001, hidden=768, layers=12, heads=12, ffn=3072, max_pos=258, type_vocab=1, pad_id=1,
                     ln_eps=1e-5)
+# the models heavy_ranker.py:80,83 load, by their published configs (XLM-RoBERTa base; a BERT with 12 heads of 32)
+XLMR_BASE = dict(vocab_size=250002, hidden=768, layers=12, heads=12, ffn=3072, max_pos=514, type_vocab=1, pad_id=1, ln_eps=1e-5)
+MINILM_L12 = dict(vocab_size=250037, hidden=384, layers=12, heads=12, ffn=1536, max_pos=512, type_vocab=2, pad_id=0, ln_eps=1e-12,
+                  position_ids="absolute")
 
 
 def synthetic_weights(cfg: dict, seed: int = 0, layers=None, std: float = 0.02) -> dict:

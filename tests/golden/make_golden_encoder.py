@@ -8,6 +8,13 @@ to the GPU box; only these inputs/outputs and this script are committed).
   ``attention_mask`` / HF ``hidden_out``.  Its weights are NOT stored: they come from ``oracle.encoder.synthetic_weights``
   (numpy PCG64 recipe, seed 1234), which tests re-run.
 
+* ``enc_bert_tiny.npz`` (round 4): a tiny BERT -- what ``paraphrase-multilingual-MiniLM-L12-v2`` (``heavy_ranker.py:80``) is: absolute
+  position ids, two token types, pad id 0, LayerNorm eps 1e-12 -- with HEAD SIZE 32 (hidden 64, 2 heads; 2 layers, FFN 128, vocab
+  120, 48 positions): full state_dict, ragged inputs, HF ``BertModel`` ``last_hidden_state`` and the sentence-transformers masked
+  mean of it.
+* ``enc_minilm_layer.npz`` (round 4): ONE MiniLM-L12-shaped layer (hidden 384, 12 heads of 32, FFN 1536) of HF ``BertModel``:
+  ``hidden_in`` / ``attention_mask`` / ``hidden_out``; weights from ``oracle.encoder.synthetic_weights`` (seed 4321), not stored.
+
     python tests/golden/make_golden_encoder.py
 """
 import os
@@ -15,7 +22,7 @@ import sys
 
 import numpy as np
 import torch
-from transformers import DPRConfig, DPRQuestionEncoder, RobertaConfig, RobertaModel
+from transformers import BertConfig, BertModel, DPRConfig, DPRQuestionEncoder, RobertaConfig, RobertaModel
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
@@ -83,9 +90,57 @@ def phobert_layer():
     np.savez(os.path.join(HERE, "enc_phobert_layer.npz"), hidden_in=hidden_in, attention_mask=mask, hidden_out=out.numpy())
 
 
+def bert_tiny():
+    torch.manual_seed(1)
+    cfg = BertConfig(vocab_size=120, hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128,
+                     max_position_embeddings=48, type_vocab_size=2, pad_token_id=0, layer_norm_eps=1e-12,
+                     hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    model = BertModel(cfg, add_pooling_layer=False).eval()
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("bias"):
+                p.normal_(0, 0.05)
+            elif "LayerNorm.weight" in name:
+                p.normal_(1.0, 0.05)
+    ids = torch.tensor([[101, 5, 17, 33, 8, 99, 41, 102, 0, 0, 0, 0, 0, 0],
+                        [101, 9, 102, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0],
+                        [101, 7, 7, 7, 64, 12, 88, 3, 55, 21, 60, 119, 4, 102],
+                        [101, 45, 31, 6, 102, 0, 0, 0, 0, 0, 0, 0, 0, 0]])
+    mask = (ids != 0).long()
+    with torch.no_grad():
+        out = model(input_ids=ids, attention_mask=mask).last_hidden_state  # token_type_ids default to 0, position_ids to arange
+    m = mask[:, :, None].float()
+    mean = (out * m).sum(1) / m.sum(1).clamp(min=1e-9)  # sentence-transformers Pooling (mean of the real tokens)
+    sd = {k: v.numpy() for k, v in model.state_dict().items() if "position_ids" not in k and "token_type_ids" not in k}
+    np.savez(os.path.join(HERE, "enc_bert_tiny.npz"), input_ids=ids.numpy().astype(np.int32), attention_mask=mask.numpy().astype(np.int32),
+             last_hidden_state=out.numpy(), mean_pooled=mean.numpy(), **{"w." + k: v for k, v in sd.items()})
+
+
+def minilm_layer():
+    cfg = dict(E.MINILM_L12, layers=1, vocab_size=64, max_pos=16)  # (the embedding tables play no part in a layer's in/out)
+    w = E.synthetic_weights(cfg, seed=4321, layers=1)
+    hf_cfg = BertConfig(vocab_size=64, hidden_size=384, num_hidden_layers=1, num_attention_heads=12, intermediate_size=1536,
+                        max_position_embeddings=16, type_vocab_size=2, pad_token_id=0, layer_norm_eps=1e-12,
+                        hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    model = BertModel(hf_cfg, add_pooling_layer=False).eval()
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False)
+    assert not unexpected and all("position_ids" in m or "token_type_ids" in m for m in missing), (missing, unexpected)
+    rng = np.random.default_rng(78)
+    hidden_in = rng.standard_normal((2, 16, 384)).astype(np.float32)
+    mask = np.ones((2, 16), dtype=np.int32)
+    mask[0, 9:] = 0
+    ext = (1.0 - torch.from_numpy(mask)[:, None, None, :].float()) * torch.finfo(torch.float32).min
+    with torch.no_grad():
+        out = model.encoder.layer[0](torch.from_numpy(hidden_in), attention_mask=ext)
+        out = out[0] if isinstance(out, tuple) else out
+    np.savez(os.path.join(HERE, "enc_minilm_layer.npz"), hidden_in=hidden_in, attention_mask=mask, hidden_out=out.numpy())
+
+
 if __name__ == "__main__":
     tiny()
     phobert_layer()
+    bert_tiny()
+    minilm_layer()
     for f in sorted(os.listdir(HERE)):
         if f.startswith("enc_"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

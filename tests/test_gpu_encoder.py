@@ -274,3 +274,92 @@ def test_folded_layernorms_with_outlier_dimensions_and_wide_gammas(native_lib, m
             print(f"outlier fold test: pooling={p} packed={r}: |fold - oracle| = {err_fold:.2e}, |plain - oracle| = {err_plain:.2e}")
             assert _cos(out["1"][p, r][:nref], ref).min() > 0.999, (p, r, _cos(out["1"][p, r][:nref], ref).min())
             assert err_fold < max(2.0 * err_plain, 5e-3), (p, r, err_fold, err_plain)
+
+
+# ---- the reference's own two model shapes (heavy_ranker.py:80,83): MiniLM-L12 (a BERT: hidden 384, 12 heads of 32, FFN 1536,
+# absolute position ids, mean pooling) and XLM-R base (vocab 250 002, 514 positions, mean pooling) ------------------------------
+BERT_TINY = dict(vocab_size=120, hidden=64, layers=2, heads=2, ffn=128, max_pos=48, type_vocab=2, pad_id=0, ln_eps=1e-12,
+                 position_ids="absolute")
+
+
+def test_tiny_bert_fixture_head_size_32(native_lib, golden_dir):
+    """HF BertModel's own output (tests/golden/enc_bert_tiny.npz: head size 32, absolute positions, two token types) through the HIP
+    encoder: sentence-transformers mean pooling of the last hidden state."""
+    from vietnamese_qa_system_amd.encoder import QuestionEncoder
+    g = np.load(f"{golden_dir}/enc_bert_tiny.npz")
+    w = {k[2:]: g[k] for k in g.files if k.startswith("w.")}
+    enc = QuestionEncoder(w, BERT_TINY, max_tokens=64)
+    ids, mask = g["input_ids"], g["attention_mask"]
+    got = enc.forward(ids, mask, pooling="mean", normalize=False).cpu().numpy()
+    assert np.abs(got - g["mean_pooled"]).max() < 2e-2 and _cos(got, g["mean_pooled"]).min() > 0.9995
+    cls = enc.forward(ids, mask, pooling="cls", normalize=False).cpu().numpy()
+    assert np.abs(cls - g["last_hidden_state"][:, 0]).max() < 2e-2
+    enc.close()
+    # the RoBERTa position rule on the same weights is measurably another model
+    enc = QuestionEncoder(w, dict(BERT_TINY, position_ids="roberta"), max_tokens=64)
+    other = enc.forward(ids, mask, pooling="mean", normalize=False).cpu().numpy()
+    enc.close()
+    assert np.abs(other - g["mean_pooled"]).max() > 2e-2
+
+
+# (12, 6, 32): small call (register-staged GEMM: K = 384 is no multiple of 256), head size 32 at one query block; (2, 64, 32): 2048
+# tokens on the LDS-DMA tile kernel; (1, 3, 128): four query blocks; (2, 2, 256): eight; (2, 5, 77): ragged
+@pytest.mark.parametrize("layers,b,l,vocab", [(12, 6, 32, 250037), (2, 64, 32, 30000), (1, 3, 128, 30000), (2, 2, 256, 30000),
+                                              (2, 5, 77, 30000)])
+def test_minilm_l12_shape_vs_oracle(native_lib, layers, b, l, vocab):
+    from vietnamese_qa_system_amd.encoder import MINILM_L12, QuestionEncoder
+    assert MINILM_L12 == E.MINILM_L12
+    cfg = dict(E.MINILM_L12, layers=layers, vocab_size=vocab)
+    w = E.synthetic_weights(cfg, seed=6, layers=layers)
+    ids, mask = E.synthetic_tokens(cfg, b, l, seed=10)
+    ids[:, -1] = np.where(mask[:, -1] == 1, vocab - 1, ids[:, -1])  # the table's last row is reachable
+    enc = QuestionEncoder(w, cfg, max_tokens=b * l)
+    nref = min(b, 6)
+    for pooling in ("mean", "cls"):
+        got = enc.forward(ids, mask, pooling=pooling).cpu().numpy()
+        ref = E.encode(w, cfg, ids[:nref], mask[:nref], pooling=pooling)
+        assert _cos(got[:nref], ref).min() > 0.999, (pooling, _cos(got[:nref], ref).min())
+        assert np.abs(got[:nref] - ref).max() < 2e-2
+        assert np.abs(np.linalg.norm(got, axis=1) - 1).max() < 1e-5
+    enc.close()
+
+
+def test_minilm_packed_batch_matches_the_padded_form(native_lib):
+    """Head size 32 through the packed (ragged) path: B = 192, L = 32 -- the matrix-core attention kernel at DH = 32 takes every
+    sequence's length from the packing offsets; same vectors as the padded form and the fp64 oracle."""
+    from vietnamese_qa_system_amd.encoder import QuestionEncoder
+    cfg = dict(E.MINILM_L12, layers=3, vocab_size=20000)
+    w = E.synthetic_weights(cfg, seed=8, layers=3)
+    b, l = 192, 32
+    ids, mask = E.synthetic_tokens(cfg, b, l, seed=22)
+    enc = QuestionEncoder(w, cfg, max_tokens=b * l)
+    ids_d, mask_d = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
+    for pooling in ("mean", "cls"):
+        padded = enc.forward(ids_d, mask_d, pooling=pooling).cpu().numpy()
+        packed = enc.forward(ids, mask, pooling=pooling).cpu().numpy()
+        assert np.abs(packed - padded).max() < 5e-4
+        ref = E.encode(w, cfg, ids[:6], mask[:6], pooling=pooling)
+        assert _cos(packed[:6], ref).min() > 0.999 and np.abs(packed[:6] - ref).max() < 2e-2
+    enc.close()
+
+
+@pytest.mark.parametrize("layers,b,l", [(12, 4, 128), (2, 2, 256), (2, 48, 40)])
+def test_xlmr_base_shape_vs_oracle(native_lib, layers, b, l):
+    """paraphrase-multilingual-mpnet-base-v2 (heavy_ranker.py:83) is an XLM-RoBERTa base: the PhoBERT-base layer shape behind a
+    250 002-row vocabulary and 514 positions, mean pooling, sentences of up to 128 tokens and more."""
+    from vietnamese_qa_system_amd.encoder import XLMR_BASE, QuestionEncoder
+    assert XLMR_BASE == E.XLMR_BASE
+    cfg = dict(E.XLMR_BASE, layers=layers)
+    w = E.synthetic_weights(cfg, seed=12, layers=layers)
+    ids, mask = E.synthetic_tokens(cfg, b, l, seed=14)
+    ids[0, 1] = cfg["vocab_size"] - 1
+    enc = QuestionEncoder(w, cfg, max_tokens=max(b * l, 520))
+    nref = min(b, 4)
+    for pooling in ("mean", "cls"):
+        got = enc.forward(ids, mask, pooling=pooling).cpu().numpy()
+        ref = E.encode(w, cfg, ids[:nref], mask[:nref], pooling=pooling)
+        assert _cos(got[:nref], ref).min() > 0.999, (pooling, _cos(got[:nref], ref).min())
+        assert np.abs(got[:nref] - ref).max() < 2e-2
+    with pytest.raises(ValueError, match="position"):
+        enc.forward(np.zeros((1, 513), np.int32) + 5, np.ones((1, 513), np.int32))  # needs position 514 of a 514-row table
+    enc.close()

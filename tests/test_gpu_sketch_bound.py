@@ -260,6 +260,7 @@ def test_unfilled_tiles_and_a_partly_filled_shard(native_lib, monkeypatch):
     q = rng.standard_normal((b, d)).astype(np.float32)
     q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float16)
     monkeypatch.setenv("VQA_STAGE_MIN", "2")
+    monkeypatch.setenv("VQA_SKETCH_COOLDOWN", "0")  # no pause after the overflow: the search behind the second fill is a sketch search
     filled = 200_100
     ske = DeviceIndex.empty(n, d, dtype="fp16", device=0, sketch=True)
     ske.set_rows(0, x[:filled])
@@ -267,6 +268,7 @@ def test_unfilled_tiles_and_a_partly_filled_shard(native_lib, monkeypatch):
     x_now[filled:] = 0
     exp_s, exp_p, full = _fp64_topk(x_now, q, k)
     s1, p1 = _search(ske, q, k)
+    assert ske.sketch_stats()["overflow"] == 1
     ske.set_rows(filled, x[filled:])  # the rest arrives: now a plain sketch search
     s2, p2 = _search(ske, q, k)
     stats = ske.sketch_stats()

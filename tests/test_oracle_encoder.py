@@ -51,3 +51,31 @@ def test_synthetic_tokens_shape():
     lens = mask.sum(1)
     assert lens.min() >= 8 and lens.max() <= 32
     assert all(ids[i, lens[i] - 1] == 2 and (ids[i, lens[i]:] == 1).all() for i in range(16))
+
+
+BERT_TINY = dict(vocab_size=120, hidden=64, layers=2, heads=2, ffn=128, max_pos=48, type_vocab=2, pad_id=0, ln_eps=1e-12,
+                 position_ids="absolute")
+
+
+def test_tiny_bert_head_size_32_absolute_positions_mean_pooling(golden_dir):
+    """HF BertModel (what paraphrase-multilingual-MiniLM-L12-v2 is, heavy_ranker.py:80) at head size 32: absolute position ids, two
+    token types, pad id 0, LayerNorm eps 1e-12; sentence-transformers mean pooling."""
+    g = np.load(f"{golden_dir}/enc_bert_tiny.npz")
+    w = {k[2:]: g[k] for k in g.files if k.startswith("w.")}
+    out = E.forward(w, BERT_TINY, g["input_ids"], g["attention_mask"])
+    real = g["attention_mask"].astype(bool)
+    assert np.abs(out - g["last_hidden_state"])[real].max() < 5e-6
+    pooled = E.encode(w, BERT_TINY, g["input_ids"], g["attention_mask"], pooling="mean", l2=False)
+    assert np.abs(pooled - g["mean_pooled"]).max() < 5e-6
+    # the RoBERTa position rule on the same weights gives another answer: the mode is pinned, not incidental
+    other = E.forward(w, dict(BERT_TINY, position_ids="roberta"), g["input_ids"], g["attention_mask"])
+    assert np.abs(other - g["last_hidden_state"])[real].max() > 1e-2
+
+
+def test_minilm_shaped_layer(golden_dir):
+    p = np.load(f"{golden_dir}/enc_minilm_layer.npz")
+    cfg = dict(E.MINILM_L12, layers=1, vocab_size=64, max_pos=16)
+    w = {k: v.astype(np.float64) for k, v in E.synthetic_weights(cfg, seed=4321, layers=1).items()}
+    out = E.layer_forward(w, cfg, 0, p["hidden_in"].astype(np.float64), p["attention_mask"])
+    real = p["attention_mask"].astype(bool)
+    assert np.abs(out - p["hidden_out"])[real].max() < 5e-6

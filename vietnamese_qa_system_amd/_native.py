@@ -19,6 +19,7 @@ VQA_INDEX_SKETCH = 2
 VQA_INDEX_RESCORE_ROWS = 4
 VQA_QUERY_TILE = 256
 VQA_POOL_CLS, VQA_POOL_MEAN = 0, 1
+VQA_POS_ROBERTA, VQA_POS_ABSOLUTE = 0, 1
 
 DTYPE_NAMES = {"fp32": VQA_F32, "f32": VQA_F32, "float32": VQA_F32, "fp16": VQA_F16, "f16": VQA_F16,
                "float16": VQA_F16, "fp8": VQA_FP8_E4M3, "fp8_e4m3": VQA_FP8_E4M3, "e4m3": VQA_FP8_E4M3}
@@ -47,7 +48,7 @@ class LaunchInfo(ctypes.Structure):
 
 class EncoderConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("vocab_size", "hidden", "layers", "heads", "ffn", "max_pos", "type_vocab",
-                                              "pad_id")] + [("ln_eps", ctypes.c_float)]
+                                              "pad_id")] + [("ln_eps", ctypes.c_float), ("position_ids", ctypes.c_int32)]
 
 
 _F = ctypes.POINTER(ctypes.c_float)

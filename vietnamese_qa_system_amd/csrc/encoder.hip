@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void pack_kernel(const int* __restrict__ mask,
     }
 }
 
-__global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ ids, int T, int L, int H, int pad_id, int vocab,
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ ids, int T, int L, int H, int pad_id, int vocab, int abs_pos,
                                                        int* __restrict__ bad_ids, const int* __restrict__ cu,
                                                        const int* __restrict__ row_seq, int B, const float* __restrict__ word,
                                                        const float* __restrict__ pos,
@@ -192,12 +192,16 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ i
     const int id_raw = ids[seq * L + l];
     const int id = (unsigned)id_raw < (unsigned)vocab ? id_raw : pad_id;
     if (id != id_raw && lane == 0) __hip_atomic_store(bad_ids, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    // RoBERTa position id: pad + (number of non-pad tokens up to and including this one), pad tokens keep pad
-    int cnt = 0;
-    for (int j = lane; j <= l; j += 64) cnt += ids[seq * L + j] != pad_id;
+    // RoBERTa position id: pad + (number of non-pad tokens up to and including this one), pad tokens keep pad;
+    // BERT (VQA_POS_ABSOLUTE: the MiniLM the reference loads): the token's index in its sequence
+    int pid = l;
+    if (!abs_pos) {
+        int cnt = 0;
+        for (int j = lane; j <= l; j += 64) cnt += ids[seq * L + j] != pad_id;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-    const int pid = id != pad_id ? cnt + pad_id : pad_id;
+        for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        pid = id != pad_id ? cnt + pad_id : pad_id;
+    }
     float x[kChunks][8];
 #pragma unroll
     for (int i = 0; i < kChunks; ++i) {
@@ -1166,7 +1170,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restri
     }
 }
 
-// ---- attention on the matrix cores (head size 64, L <= 256): one workgroup per (sequence, HPW heads), one wave per head and
+// ---- attention on the matrix cores (head size DH = 64 or 32, L <= 256): one workgroup per (sequence, HPW heads), one wave per head and
 // block of 32 queries.  S^T = K . Q^T with v_mfma_f32_32x32x16_f16 (A = keys, B = queries: a lane then holds ONE query's scores
 // for 16 keys per 32-key block in registers, so the softmax is register-local plus one cross-half shuffle); the
 // normalised probabilities, converted to fp16, are used straight from the accumulator registers as the A operand of
@@ -1176,12 +1180,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restri
 // keys.  (Round 2 wrote a transposed image with 2-byte LDS stores: 82 % of the kernel's LDS cycles were bank conflicts.)
 // Image: key row of 128 B = two 64-byte halves (dimensions 0-31 | 32-63), the halves of rows with bit 1 of the key set are
 // swapped, so the four rows of a block start on banks 0 / 32 / 16 / 48: every transposed read and every store is conflict-free.
+// DH = 32 (MiniLM-L12: 12 heads of 32, the model heavy_ranker.py:80 loads): key rows of 64 B, the four rows of a block are 256
+// contiguous bytes = all 64 banks once, no swap needed; Q . K^T takes 2 instead of 4 k-steps, P . V one 32-dimension block.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
-constexpr int kAttDh = 64;
 constexpr int kAttMaxBlocks = 8;  // L <= 256
+__host__ __device__ constexpr bool att_mfma_head_size(int dh) { return dh == 64 || dh == 32; }
 
-template <int NQB, int HPW>
+template <int NQB, int HPW, int DH>
 __global__ __launch_bounds__(64 * NQB * HPW) void attention_mfma_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ mask,
                                                                          int Lmax, int H, int heads, const int* __restrict__ cu,
                                                                          _Float16* __restrict__ ctx) {
@@ -1191,29 +1197,33 @@ __global__ __launch_bounds__(64 * NQB * HPW) void attention_mfma_kernel(const _F
     const int hw = wave / NQB, qb = wave - hw * NQB;  // head inside the workgroup, query block
     const int groups = heads / HPW;
     const int seq = blockIdx.x / groups, head = (blockIdx.x - seq * groups) * HPW + hw;
-    char* vimg = smem + hw * (Lp * 128);  // this head's V image: [Lp keys][128 B]
+    static_assert(DH == 64 || DH == 32, "head sizes of the matrix-core attention");
+    constexpr int kRowB = DH * 2;      // bytes of a key row of the V image
+    constexpr int kCh = DH / 8;        // 16-byte chunks per row
+    constexpr int kVregs = DH / 16;    // 16-byte chunks of V per lane (Lp * kCh chunks over 64 NQB lanes)
+    char* vimg = smem + hw * (Lp * kRowB);  // this head's V image: [Lp keys][kRowB]
     const int li = lane & 31, h = lane >> 5;
     const size_t row_stride = (size_t)3 * H;
     // packed rows: the sequence owns rows [cu[seq], cu[seq + 1]) and every one of them is a real token
     const size_t row0 = cu ? (size_t)cu[seq] : (size_t)seq * Lmax;
     const int L = cu ? cu[seq + 1] - cu[seq] : Lmax;
-    const _Float16* base = qkv + row0 * row_stride + head * kAttDh;
-    // V -> registers now (the NQB waves of this head: 4 x 16 bytes per lane; keys beyond L are zero), -> LDS behind the softmax:
+    const _Float16* base = qkv + row0 * row_stride + head * DH;
+    // V -> registers now (the NQB waves of this head: kVregs x 16 bytes per lane; keys beyond L are zero), -> LDS behind the softmax:
     // the loads travel while Q . K^T and the softmax run
-    half8 vreg[4];
+    half8 vreg[kVregs];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < kVregs; ++t) {
         const int i = tid - hw * 64 * NQB + t * 64 * NQB;
-        const int key = i >> 3, ch = i & 7;
+        const int key = i / kCh, ch = i % kCh;
         vreg[t] = half8{0, 0, 0, 0, 0, 0, 0, 0};
         if (key < L) vreg[t] = *reinterpret_cast<const half8*>(base + (size_t)key * row_stride + 2 * H + ch * 8);
     }
     const int qrow = qb * 32 + li < L ? qb * 32 + li : L - 1;  // padded query rows recompute the last row, never stored
-    half8 qf[4];
+    half8 qf[kVregs];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const half8*>(base + (size_t)qrow * row_stride + kk * 16 + h * 8);
+    for (int kk = 0; kk < kVregs; ++kk) qf[kk] = *reinterpret_cast<const half8*>(base + (size_t)qrow * row_stride + kk * 16 + h * 8);
     f32x16 st[NQB];
-    const float scale = rsqrtf((float)kAttDh);
+    const float scale = rsqrtf((float)DH);
     float mx = -INFINITY;
 #pragma unroll
     for (int kb = 0; kb < NQB; ++kb) {
@@ -1221,7 +1231,7 @@ __global__ __launch_bounds__(64 * NQB * HPW) void attention_mfma_kernel(const _F
         const int krow = key < L ? key : L - 1;
         f32x16 acc = {};
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
+        for (int kk = 0; kk < kVregs; ++kk) {
             const half8 kf = *reinterpret_cast<const half8*>(base + (size_t)krow * row_stride + H + kk * 16 + h * 8);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], acc, 0, 0, 0);
         }
@@ -1251,19 +1261,21 @@ __global__ __launch_bounds__(64 * NQB * HPW) void attention_mfma_kernel(const _F
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < kVregs; ++t) {
         const int i = tid - hw * 64 * NQB + t * 64 * NQB;
-        const int key = i >> 3, ch = i & 7;
-        *reinterpret_cast<half8*>(vimg + key * 128 + (((ch >> 2) ^ ((key >> 1) & 1)) << 6) + ((ch & 3) << 4)) = vreg[t];
+        const int key = i / kCh, ch = i % kCh;
+        if constexpr (DH == 64) *reinterpret_cast<half8*>(vimg + key * 128 + (((ch >> 2) ^ ((key >> 1) & 1)) << 6) + ((ch & 3) << 4)) = vreg[t];
+        else *reinterpret_cast<half8*>(vimg + key * kRowB + (ch << 4)) = vreg[t];
     }
     __syncthreads();  // V images complete
     // transposed read of this lane: block row q_ = (lane & 15) >> 2 (+ the key base), columns 4 p_ .. 4 p_ + 3 of the 16-lane
     // group's 16 dimensions 16 (group & 1) ..; rows k0 + q_ with k0 a multiple of 4, so the half swap of a row is (q_ >> 1) & 1
     typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
     const int q_ = (lane & 15) >> 2, p_ = lane & 3, gi = lane >> 4;
-    const int tr_off = q_ * 128 + ((gi & 1) << 5) + (p_ << 3);  // + key base * 128 + (db ^ swap) * 64
-    const int swap = (q_ >> 1) & 1;
-    f32x16 o[2] = {};
+    const int tr_off = q_ * kRowB + ((gi & 1) << 5) + (p_ << 3);  // + key base * kRowB (+ (db ^ swap) * 64 for DH = 64)
+    const int swap = DH == 64 ? (q_ >> 1) & 1 : 0;
+    constexpr int kDb = DH / 32;  // 32-dimension blocks of the output
+    f32x16 o[kDb] = {};
 #pragma unroll
     for (int kb = 0; kb < NQB; ++kb)
 #pragma unroll
@@ -1274,10 +1286,10 @@ __global__ __launch_bounds__(64 * NQB * HPW) void attention_mfma_kernel(const _F
             // element j of lane half h is key kb*32 + 16 s2 + 8 (j >> 2) + 4 h + (j & 3): V must use the same order
             const int k0 = kb * 32 + 16 * s2 + 4 * h;
 #pragma unroll
-            for (int db = 0; db < 2; ++db) {
-                const char* at = vimg + k0 * 128 + ((db ^ swap) << 6) + tr_off;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(at));             // keys k0 .. k0 + 3
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(at + 8 * 128));   // keys k0 + 8 .. k0 + 11
+            for (int db = 0; db < kDb; ++db) {
+                const char* at = vimg + k0 * kRowB + ((db ^ swap) << 6) + tr_off;
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(at));               // keys k0 .. k0 + 3
+                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(at + 8 * kRowB));   // keys k0 + 8 .. k0 + 11
                 typedef short s16x8 __attribute__((__vector_size__(8 * sizeof(short))));
                 const s16x8 both = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
                 // O^T = V^T . P^T: the transposed V fragment is the A operand (lane = head dimension), P the B operand (lane = query,
@@ -1290,9 +1302,9 @@ __global__ __launch_bounds__(64 * NQB * HPW) void attention_mfma_kernel(const _F
     typedef _Float16 half4 __attribute__((ext_vector_type(4)));
     const int qo = qb * 32 + li;
     if (qo < L) {
-        _Float16* orow = ctx + (row0 + qo) * H + head * kAttDh + 4 * h;
+        _Float16* orow = ctx + (row0 + qo) * H + head * DH + 4 * h;
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < kDb; ++db)
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4)
                 *reinterpret_cast<half4*>(orow + db * 32 + 8 * g4) =
@@ -1782,6 +1794,8 @@ extern "C" int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encod
     VQA_REQUIRE(cfg->layers >= 1 && cfg->vocab_size >= 1 && cfg->max_pos >= 2 && cfg->type_vocab >= 1 && max_tokens >= 1,
                 "vqa_encoder_create: bad sizes");
     VQA_REQUIRE(cfg->pad_id >= 0 && cfg->pad_id < cfg->vocab_size, "vqa_encoder_create: pad_id=%d", cfg->pad_id);
+    VQA_REQUIRE(cfg->position_ids == VQA_POS_ROBERTA || cfg->position_ids == VQA_POS_ABSOLUTE, "vqa_encoder_create: position_ids=%d",
+                cfg->position_ids);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
         vqa_set_error("vqa_encoder_create: no HIP device visible");
@@ -1913,7 +1927,7 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
                           int32_t real_tokens, int32_t pooling, int32_t normalize, float* out, hipStream_t s) {
     const int H = e->cfg.hidden, F = e->cfg.ffn, heads = e->cfg.heads, dh = H / heads;
     // real_tokens > 0: the caller states how many mask entries are set (right-padded masks): only those rows are computed
-    const bool packed = real_tokens > 0 && real_tokens < B * L && dh == kAttDh && L <= 32 * kAttMaxBlocks;
+    const bool packed = real_tokens > 0 && real_tokens < B * L && att_mfma_head_size(dh) && L <= 32 * kAttMaxBlocks;
     const int T = packed ? real_tokens : B * L;  // activation rows
     const int* cu = packed ? e->cu : nullptr;
     const float eps = e->cfg.ln_eps;
@@ -1933,7 +1947,7 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
                       p_ffn % 4 == 0 && tile_stat_slots(T, 3 * H, H) > 0 && tile_stat_slots(T, F, H) > 0;
     const int st_stride = (e->max_tokens + kTokenPad - 1) / kTokenPad * kTokenPad;  // rows per statistics slot (the padded row count)
     hipLaunchKernelGGL(embed_ln_kernel, dim3(row_blocks), dim3(256), 0, s, input_ids, T, L, H, e->cfg.pad_id, e->cfg.vocab_size,
-                       e->bad_ids_dev, cu, e->row_seq, B, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x,
+                       e->cfg.position_ids == VQA_POS_ABSOLUTE ? 1 : 0, e->bad_ids_dev, cu, e->row_seq, B, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x,
                        fold ? e->st_x : (float2*)nullptr, st_stride);
     VQA_HIP_CHECK(hipGetLastError());
     // fold: x holds RAW rows; (pg, pb, p_x) = gamma / beta / slots in use of the LayerNorm that belongs on them
@@ -1951,15 +1965,21 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
                                            FoldArgs{e->st_x, p_x, st_stride, inv_h, eps, Ly.cqkv, nullptr, nullptr, nullptr}, s);
         else rc = launch_gemm<0>(e->x, Ly.wqkv, Ly.bqkv, nullptr, e->qkv, T, 3 * H, H, s);
         if (rc != VQA_OK) return rc;
-        if (dh == kAttDh && L <= 32 * kAttMaxBlocks) {
+        if (att_mfma_head_size(dh) && L <= 32 * kAttMaxBlocks) {
             const int nqb = (L + 31) / 32;
             // heads per workgroup: as many as keep the workgroup at <= 512 threads and divide the head count
             int hpw = nqb <= 2 ? 4 : nqb <= 4 ? 2 : 1;
             while (heads % hpw) hpw >>= 1;
-            const size_t lds = (size_t)hpw * nqb * 32 * 128;  // per head: [32 nqb keys][128 B]
+            const size_t lds = (size_t)hpw * nqb * 32 * 2 * dh;  // per head: [32 nqb keys][2 dh bytes]
 #define VQA_ATT(NQB, HPW)                                                                                                   \
-    hipLaunchKernelGGL((attention_mfma_kernel<NQB, HPW>), dim3(B * (heads / HPW)), dim3(64 * NQB * HPW), lds, s, e->qkv, attn_mask, \
-                       L, H, heads, cu, e->ctx)
+    do {                                                                                                                    \
+        if (dh == 64)                                                                                                       \
+            hipLaunchKernelGGL((attention_mfma_kernel<NQB, HPW, 64>), dim3(B * (heads / HPW)), dim3(64 * NQB * HPW), lds, s, e->qkv,  \
+                               attn_mask, L, H, heads, cu, e->ctx);                                                        \
+        else                                                                                                                \
+            hipLaunchKernelGGL((attention_mfma_kernel<NQB, HPW, 32>), dim3(B * (heads / HPW)), dim3(64 * NQB * HPW), lds, s, e->qkv,  \
+                               attn_mask, L, H, heads, cu, e->ctx);                                                        \
+    } while (0)
 #define VQA_ATT_H(NQB)                             \
     case NQB:                                      \
         if (hpw == 4) VQA_ATT(NQB, 4);             \
@@ -2046,8 +2066,8 @@ extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, con
     VQA_REQUIRE(B >= 1 && L >= 1, "vqa_encoder_forward: B=%d L=%d", B, L);
     VQA_REQUIRE((long long)B * L <= e->max_tokens, "vqa_encoder_forward: B*L=%lld exceeds the workspace of %d tokens",
                 (long long)B * L, e->max_tokens);
-    VQA_REQUIRE(L + e->cfg.pad_id + 1 <= e->cfg.max_pos, "vqa_encoder_forward: L=%d needs position %d, the table has %d rows", L,
-                L + e->cfg.pad_id, e->cfg.max_pos);
+    const int last_pos = e->cfg.position_ids == VQA_POS_ABSOLUTE ? L - 1 : L + e->cfg.pad_id;
+    VQA_REQUIRE(last_pos < e->cfg.max_pos, "vqa_encoder_forward: L=%d needs position %d, the table has %d rows", L, last_pos, e->cfg.max_pos);
     VQA_REQUIRE(pooling == VQA_POOL_CLS || pooling == VQA_POOL_MEAN, "vqa_encoder_forward: pooling %d", pooling);
     VQA_REQUIRE(real_tokens >= 0 && (long long)real_tokens <= (long long)B * L, "vqa_encoder_forward: real_tokens=%d outside [0, B*L=%lld]",
                 real_tokens, (long long)B * L);

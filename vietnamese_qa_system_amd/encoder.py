@@ -20,6 +20,13 @@ POOLING = {"cls": N.VQA_POOL_CLS, "mean": N.VQA_POOL_MEAN}
 
 PHOBERT_BASE = dict(vocab_size=64001, hidden=768, layers=12, heads=12, ffn=3072, max_pos=258, type_vocab=1, pad_id=1,
                     ln_eps=1e-5)
+# the two models the reference's retriever loads (inference_pipeline/db_utils/heavy_ranker.py:80,83), by their published configs:
+# paraphrase-multilingual-mpnet-base-v2 is an XLM-RoBERTa base, paraphrase-multilingual-MiniLM-L12-v2 a BERT (absolute position
+# ids, two token types) with 12 heads of 32; both are mean-pooled by sentence-transformers
+XLMR_BASE = dict(vocab_size=250002, hidden=768, layers=12, heads=12, ffn=3072, max_pos=514, type_vocab=1, pad_id=1, ln_eps=1e-5)
+MINILM_L12 = dict(vocab_size=250037, hidden=384, layers=12, heads=12, ffn=1536, max_pos=512, type_vocab=2, pad_id=0, ln_eps=1e-12,
+                  position_ids="absolute")
+POSITION_IDS = {"roberta": N.VQA_POS_ROBERTA, "absolute": N.VQA_POS_ABSOLUTE}
 
 _LAYER_FIELDS = (
     ("wq", "attention.self.query.weight"), ("bq", "attention.self.query.bias"),
@@ -40,7 +47,8 @@ class QuestionEncoder:
     """RoBERTa / PhoBERT-base-shaped encoder resident on one MI355X.
 
     ``weights``: mapping HF state-dict name -> float32 array (numpy or torch, host or device).  ``config`` keys:
-    vocab_size, hidden, layers, heads, ffn, max_pos, type_vocab, pad_id, ln_eps.  ``max_tokens`` bounds B * L of one call.
+    vocab_size, hidden, layers, heads, ffn, max_pos, type_vocab, pad_id, ln_eps and, optionally, position_ids ("roberta":
+    pad-offset ids, the default; "absolute": BERT's 0 .. L - 1).  ``max_tokens`` bounds B * L of one call.
     """
 
     def __init__(self, weights: Dict[str, object], config: dict, *, device: int = 0, max_tokens: int = 1024 * 32):
@@ -71,8 +79,11 @@ class QuestionEncoder:
 
         c = self.config
         h, f = int(c["hidden"]), int(c["ffn"])
+        pos_mode = str(c.get("position_ids", "roberta"))
+        if pos_mode not in POSITION_IDS:
+            raise ValueError(f"position_ids must be one of {sorted(POSITION_IDS)}")
         cfg = N.EncoderConfig(int(c["vocab_size"]), h, int(c["layers"]), int(c["heads"]), f, int(c["max_pos"]),
-                              int(c["type_vocab"]), int(c["pad_id"]), float(c["ln_eps"]))
+                              int(c["type_vocab"]), int(c["pad_id"]), float(c["ln_eps"]), POSITION_IDS[pos_mode])
         shapes = {"word_emb": (c["vocab_size"], h), "pos_emb": (c["max_pos"], h), "type_emb": (c["type_vocab"], h),
                   "emb_ln_g": (h,), "emb_ln_b": (h,)}
         lshapes = {"wq": (h, h), "wk": (h, h), "wv": (h, h), "wo": (h, h), "w1": (f, h), "w2": (h, f), "bq": (h,), "bk": (h,),
