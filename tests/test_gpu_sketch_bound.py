@@ -286,7 +286,10 @@ def test_overflow_in_the_first_query_tile_of_a_long_batch_is_reported(native_lib
     rng = np.random.default_rng(8)
     x = rng.standard_normal((n, d)).astype(np.float32)
     x = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float16)
-    x[1_000:150_000] = x[7]  # 149 000 duplicates: queries equal to that row cannot be pruned
+    # 100 000 duplicates of one row, all behind the first stage (the cascade's first 65 536 rows): queries equal to that row cannot
+    # be pruned; for the others the first stage's k-th best score keeps the duplicates out (duplicates INSIDE the first stage would
+    # tie with every query's seed threshold and overflow every list)
+    x[70_000:170_000] = x[7]
     q = rng.standard_normal((300, d)).astype(np.float32)
     q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float16)
     q[:256] = x[7]
