@@ -171,7 +171,9 @@ typedef struct vqa_launch_info {
     int32_t pad_;
 } vqa_launch_info;
 int vqa_index_launch_info(const vqa_index* index, int32_t B, int32_t k, vqa_launch_info* out);
-int vqa_index_set_timing(vqa_index* index, int32_t enabled);
+int vqa_index_set_timing(vqa_index* index, int32_t enabled); /* 0: off (recorded pairs are kept until get_timing), 1: on, from scratch,
+                                                               * 2: on, keeping the pairs recorded so far (an event record between two
+                                                               * launches costs the stream a few microseconds: bench.py samples) */
 int vqa_index_get_timing(vqa_index* index, double* kernel_ms_sum, int64_t* launches);
 
 /* ---- question encoder: replaces the transformer forward + pooling + L2-normalise inside txtai

@@ -66,4 +66,4 @@ for r in range(args.rounds):
 esz = {"fp16": 2, "fp8": 1, "fp32": 4}[args.dtype]
 for v, st, kn in zip(args.variants, step, kern):
     print(f"{v:40s} step median {np.median(st):.4f} min {min(st):.4f} ms | main launch median {np.median(kn):.4f} min {min(kn):.4f} ms | "
-          f"whole-step {args.n * args.d * esz / (np.median(st) * 1e-3) / 1e9 / 8000:.4f} of 8 TB/s", flush=True)
+          f"{args.b / (np.median(st) * 1e-3):.0f} q/s = {args.n * args.d * esz / (np.median(st) * 1e-3) / 1e9 / 8000:.4f} of the HBM-roofline q/s of the index as stored", flush=True)

@@ -33,5 +33,8 @@ for _ in range(args.steps):
 torch.cuda.synchronize()
 el = (time.perf_counter() - t0) / args.steps * 1e3
 ms, n = ix.get_timing()
-print(f"{os.environ.get('VQA_LIB', 'default'):60s} step {el:.3f} ms  main kernel {ms / max(n, 1):.3f} ms  "
-      f"-> {args.n * args.d * {'fp16': 2, 'fp8': 1, 'fp32': 4}[args.dtype] / (ms / max(n, 1) * 1e-3) / 1e9:.0f} GB/s, {2 * 256 * args.n * args.d / (ms / max(n, 1) * 1e-3) / 1e12:.0f} TF", flush=True)
+info = ix.launch_info(args.b, args.k)
+kms = ms / max(n, 1)
+print(f"{os.environ.get('VQA_LIB', 'default'):60s} step {el:.3f} ms  main kernel {kms:.3f} ms  "
+      f"-> {info.bytes_per_launch / (kms * 1e-3) / 1e9:.0f} GB/s of the bytes that launch reads ({'int8 sketch' if info.sketch_scan else args.dtype}), "
+      f"{info.flops_per_launch / (kms * 1e-3) / 1e12:.0f} T(FL)OP/s", flush=True)

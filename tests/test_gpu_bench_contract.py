@@ -25,11 +25,14 @@ def test_bench_prints_one_json_line_with_the_contract_keys(native_lib):
     assert r["value"] > 0 and abs(r["value"] - 256 / r["ms_per_step"] * 1e3) / r["value"] < 0.01
     rf = r["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and 0 < rf["frac"] < 1
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["launches"] == 3
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["launches"] == 1  # the dominant launch is bracketed on every 4th step
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["cpu_model"]
     assert {(p["rows"], p["batch"]) for p in cb["points"]} >= {(1000, 256), (1000, 1), (100000, 256), (100000, 1)}
     assert r["recall_at_10"] == 1.0
+    assert rf["step_bytes_moved"] >= 300000 * 768 * 2 and 0 < rf["step_frac_physical"] < 1 and "qps_over_hbm_roofline_qps" in rf
+    oc = r["other_configs"]
+    assert {"own_encoder_outputs", "clusters_1000"} <= set(oc["non_isotropic"]) and {"minilm_l12_h384_dh32", "xlmr_base_h768_dh64"} <= set(oc["reference_model_shapes"])
     sm = r["step_ms"]
     assert sm["p10"] <= sm["median"] <= sm["p90"]
     e2e = r["end_to_end"]
@@ -55,7 +58,7 @@ def test_bench_two_ranks_sharing_the_device(native_lib):
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["config"]["docs_total"] == 400000 and r["scaling"] == "weak"
     assert r["recall_at_10"] == 1.0 and "cpu_baseline" not in r  # the CPU baseline is an N = 1 leg
-    assert r["roofline"]["launches"] == 4 and r["end_to_end"]["value"] > 0
+    assert r["roofline"]["launches"] == 1 and r["end_to_end"]["value"] > 0
 
 
 def test_bench_eight_ranks_sharing_the_device(native_lib):
@@ -76,5 +79,5 @@ def test_bench_eight_ranks_sharing_the_device(native_lib):
     r = json.loads(lines[0])
     assert r["n_gpus"] == 8 and r["config"]["docs_total"] == 1600000 and r["scaling"] == "weak"
     assert r["config"]["parallelism"] == "row-shard x8" and r["recall_at_10"] == 1.0 and "cpu_baseline" not in r
-    assert r["roofline"]["launches"] == 4 and r["end_to_end"]["value"] > 0
+    assert r["roofline"]["launches"] == 1 and r["end_to_end"]["value"] > 0
     assert r["pipelined"]["value"] > 0 and r["pipelined"]["batches"] >= 2

@@ -49,6 +49,7 @@ struct vqa_index {
     int f16_loop = 0;  // fp16 K loop: 0 = anti-phase slots (two barriers per K-step), 1 = K-step pairs on the stagger loop (VQA_F16_LOOP)
     // workspace (allocated once; search never allocates)
     void* q_stage = nullptr;     // one 256-row tile in TILED layout
+    void* q_rm = nullptr;        // ... and row-major (sketch shards with the re-scoring copy: what rescore_kernel reads)
     void* q_rows = nullptr;      // device staging for get_rows' host path (lazy)
     size_t q_rows_bytes = 0;
     // host rows -> shard (set_rows with a host pointer): two pinned + two device staging buffers and a copy stream (lazy), so
@@ -77,7 +78,7 @@ struct vqa_index {
     unsigned long long* regions = nullptr;  // [max_grid][kSketchCap] candidate pairs per workgroup of the scan
     unsigned* region_cnt = nullptr;         // [max_grid]
     vqa_key* cand_keys = nullptr;           // [256][kSketchCap] exact (score, position) keys per query
-    unsigned* cand_cnt = nullptr;           // [256][kSketchSubLists]: keys in every sub-list of a query's list
+    unsigned* cand_cnt = nullptr;           // [256][kSketchSubLists] x kSketchCntStride: keys in every sub-list of a query's list (a line per counter)
     int* sketch_flag = nullptr;             // [3]: [0] 1 = a candidate buffer filled up in this query tile: its exact fallback scan runs;
                                             // [1] = OR of [0] over the EARLIER query tiles of the call, [2] = the call's number (sketch_qconst_kernel)
     long long* stage_pos = nullptr;         // [256][max_k] row positions of the first stage's top-k
@@ -87,7 +88,9 @@ struct vqa_index {
     bool mu_set = false;
     bool center = true;                     // VQA_SKETCH_CENTER=0: no centring (needs the rotated form)
     bool rotate = true;                     // the sketch is cut from rotated rows (convert.hip: sketch_rotate); VQA_SKETCH_ROTATE=0: from the rows as they are
+    bool sketch_sx5 = false;                // VQA_SKETCH_SX=5: the sketch scan on the five-stage X ring (dev / A-B switch; default six)
     bool cascade = true;                    // VQA_SKETCH_CASCADE=0: the exact first stage of the narrow sketch form (dev / A-B switch)
+    int* sketch_flag_dev_mirror = nullptr;  // device address of the pinned mirror below (mapped host memory: the cascade's last merge writes it)
     int* sketch_flag_host = nullptr;        // pinned mirror of sketch_flag [3], copied once behind the last query tile of a call (read by LATER calls)
     int sketch_cooldown = 0;                // searches left that skip the sketch: data the bound cannot prune would pay the sketch scan
                                             // AND the exact fallback every time (VQA_SKETCH_COOLDOWN searches, default 64, then it tries again;
@@ -134,6 +137,7 @@ extern "C" void vqa_index_destroy(vqa_index* ix) {
     if (ix->rows) (void)hipFree(ix->rows);
     if (ix->ids) (void)hipFree(ix->ids);
     if (ix->q_stage) (void)hipFree(ix->q_stage);
+    if (ix->q_rm) (void)hipFree(ix->q_rm);
     if (ix->q_rows) (void)hipFree(ix->q_rows);
     for (int b = 0; b < 2; ++b) {
         if (ix->up_pinned[b]) (void)hipHostFree(ix->up_pinned[b]);
@@ -399,15 +403,17 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
                 hipMalloc((void**)&ix->regions, (size_t)ix->max_grid * kSketchCap * 8) != hipSuccess ||
                 hipMalloc((void**)&ix->region_cnt, (size_t)ix->max_grid * 4) != hipSuccess ||
                 hipMalloc((void**)&ix->cand_keys, (size_t)VQA_QUERY_TILE * kSketchCap * sizeof(vqa_key)) != hipSuccess ||
-                hipMalloc((void**)&ix->cand_cnt, VQA_QUERY_TILE * kSketchSubLists * 4) != hipSuccess || hipMalloc((void**)&ix->sketch_flag, 3 * sizeof(int)) != hipSuccess ||
+                hipMalloc((void**)&ix->cand_cnt, (size_t)VQA_QUERY_TILE * kSketchSubLists * kSketchCntStride * 4) != hipSuccess || hipMalloc((void**)&ix->sketch_flag, 3 * sizeof(int)) != hipSuccess ||
                 hipMalloc((void**)&ix->stage_pos, (size_t)VQA_QUERY_TILE * max_k * 8) != hipSuccess ||
-                hipHostMalloc((void**)&ix->sketch_flag_host, 3 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+                hipHostMalloc((void**)&ix->sketch_flag_host, 3 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+                hipHostGetDevicePointer((void**)&ix->sketch_flag_dev_mirror, ix->sketch_flag_host, 0) != hipSuccess) {
                 vqa_set_error("vqa_index_create: allocating the int8 sketch (%zu bytes) failed", ix->rows8_bytes);
                 rc = VQA_ENOMEM;
                 break;
             }
             ix->sketch_flag_host[0] = ix->sketch_flag_host[1] = ix->sketch_flag_host[2] = 0;
             if (const char* cs = getenv("VQA_SKETCH_CASCADE")) ix->cascade = cs[0] != '0';
+            if (const char* sx = getenv("VQA_SKETCH_SX")) ix->sketch_sx5 = sx[0] == '5';
             if (const char* ro = getenv("VQA_SKETCH_ROTATE")) ix->rotate = ro[0] != '0';
             if (const char* ce = getenv("VQA_SKETCH_CENTER")) ix->center = ce[0] != '0';
             ix->center = ix->center && ix->rotate;
@@ -444,6 +450,10 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
                 } else if (hipMemset(ix->rows_rm, 0, ix->rows_bytes) != hipSuccess) {
                     vqa_set_error("vqa_index_create: clearing the row-major copy failed");
                     rc = VQA_EHIP;
+                    break;
+                } else if (hipMalloc(&ix->q_rm, (size_t)VQA_QUERY_TILE * ix->d_pad * eb) != hipSuccess) {
+                    vqa_set_error("vqa_index_create: allocating the row-major query tile failed");
+                    rc = VQA_ENOMEM;
                     break;
                 }
             }
@@ -606,7 +616,7 @@ extern "C" int vqa_index_launch_info(const vqa_index* ix, int32_t B, int32_t k, 
 extern "C" int vqa_index_set_timing(vqa_index* ix, int32_t enabled) {
     VQA_REQUIRE(ix, "vqa_index_set_timing: index is null");
     ix->timing = enabled != 0;
-    ix->ev_used = 0;
+    if (enabled != 2) ix->ev_used = 0;  // 2: resume -- keep the event pairs recorded so far (sampled timing: bench.py brackets every 4th step)
     return VQA_OK;
 }
 
@@ -652,7 +662,8 @@ static ScoreTopkArgs exact_launch_args(const vqa_index* ix, int nq, int k) {
 
 // Seed pass: the plan's first seed_tiles tiles scored by the MODE 0 kernel (sub-maxima per query and tile) and the `rank`-th
 // largest of them per query -> thr_out (ix->thr0 by default), the starting threshold of the launches behind it (`a` carries upper / gate)
-static int seed_pass(vqa_index* ix, const LaunchPlan& p, ScoreTopkArgs a, int rank, const int* gate, hipStream_t stream, float* thr_out = nullptr) {
+static int seed_pass(vqa_index* ix, const LaunchPlan& p, ScoreTopkArgs a, int rank, const int* gate, hipStream_t stream, float* thr_out = nullptr,
+                     const MergeSketchTail* tail = nullptr) {
     a.thr_init = nullptr;
     a.tile_begin = 0;
     a.tile_end = p.seed_tiles;
@@ -662,17 +673,37 @@ static int seed_pass(vqa_index* ix, const LaunchPlan& p, ScoreTopkArgs a, int ra
     int rc = vqa_launch_score_topk(ix->dtype, a, stream);
     if (rc != VQA_OK) return rc;
     return vqa_launch_merge_partials(ix->partial, p.seed_tiles, p.seeds_per_tile, a.nq, rank, nullptr, 0, nullptr, nullptr, nullptr,
-                                     thr_out ? thr_out : ix->thr0, 1.0f, rank, 0, nullptr, true, gate, stream);
+                                     thr_out ? thr_out : ix->thr0, 1.0f, rank, 0, nullptr, true, gate, stream, 0, nullptr, 1, tail);
 }
 
 // One sketch scan of tiles [tile_begin, tile_end) against theta = thr[] and the exact scores of what it leaves: per-query
 // constants -> int8 scan -> re-scoring of its candidate pairs (and of `stage_k` first-stage rows per query, ix->stage_pos) into
 // the queries' candidate lists.  `clear`: 1 / 2 = this is the query tile's first scan (counters and overflow flag start at zero;
 // 2: the first tile of the call), 0 = a later one.
+// the merge in front of a sketch scan can write that scan's per-query constants itself (MergeSketchTail: the cascade), which saves the
+// sketch_qconst launch: `thr` == nullptr then
+static MergeSketchTail qconst_tail(const vqa_index* ix, int clear) {
+    MergeSketchTail t;
+    t.qconst = ix->qconst;
+    t.qscale = ix->qrow;
+    t.qlo = ix->qrow + VQA_QUERY_TILE;
+    t.qnorm = ix->qrow + 2 * VQA_QUERY_TILE;
+    t.qoff = ix->center ? ix->qoff : nullptr;
+    t.fp_margin = vqa_sketch_fp_margin(ix->d_pad, ix->rotate);
+    t.mu_norm = ix->mu_norm;
+    t.cand_cnt = ix->cand_cnt;
+    t.overflow = ix->sketch_flag;
+    t.clear = clear;
+    t.seq = ix->sketch_seq;
+    return t;
+}
+
 static int sketch_scan_rescore(vqa_index* ix, const LaunchPlan& p, const float* thr, int tile_begin, int tile_end, int nq, int stage_k, int clear,
                                bool timed, hipStream_t stream) {
     const int seq = ix->sketch_seq;
-    int rc = vqa_launch_sketch_qconst(thr, ix->qrow, ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, ix->d_pad, ix->qconst,
+    int rc = VQA_OK;
+    if (thr)
+        rc = vqa_launch_sketch_qconst(thr, ix->qrow, ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, ix->d_pad, ix->qconst,
                                       ix->cand_cnt, ix->sketch_flag, clear, seq, ix->rotate, ix->center ? ix->qoff : nullptr, ix->mu_norm, stream);
     if (rc != VQA_OK) return rc;
     SketchScanArgs sk;
@@ -694,20 +725,22 @@ static int sketch_scan_rescore(vqa_index* ix, const LaunchPlan& p, const float* 
     b.grid = p.grid1;
     b.sketch = &sk;
     b.first_stage = tile_end < p.tiles;  // (its own kernel symbol in a trace)
+    b.loop = ix->sketch_sx5 ? 1 : 0;
     timed = timed && ix->timing;
     if (timed && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
     rc = vqa_launch_score_topk(VQA_I8_SKETCH, b, stream);
     if (rc != VQA_OK) return rc;
     if (timed && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
     return vqa_launch_rescore(ix->regions, ix->region_cnt, kSketchCap, p.grid1, stage_k > 0 ? ix->stage_pos : nullptr, nq, stage_k, ix->rows,
-                              ix->rows_rm, ix->q_stage, ix->dtype, ix->d_pad, ix->cand_keys, ix->cand_cnt, kSketchCap, ix->sketch_flag, stream);
+                              ix->rows_rm, ix->q_stage, ix->q_rm, ix->dtype, ix->d_pad, ix->cand_keys, ix->cand_cnt, kSketchCap, ix->sketch_flag, stream);
 }
 
 // the k best of every query's candidate list -> the caller's outputs (os == nullptr: only their k-th score -> ix->thr0).  The
 // caller enqueues its exact fallback behind, gated on ix->sketch_flag.
-static int sketch_select(vqa_index* ix, int nq, int k, float* os, int64_t* oi, int64_t* op, hipStream_t stream) {
+static int sketch_select(vqa_index* ix, int nq, int k, float* os, int64_t* oi, int64_t* op, hipStream_t stream, const MergeSketchTail* tail = nullptr) {
     int rc = vqa_launch_merge_partials(ix->cand_keys, kSketchSubLists, kSketchCap / kSketchSubLists, nq, k, os ? ix->ids : nullptr, ix->id_base, os,
-                                       oi, op, os ? nullptr : ix->thr0, 1.0f, k, 0, nullptr, true, nullptr, stream, kSketchSubLists, ix->cand_cnt);
+                                       oi, op, os ? nullptr : ix->thr0, 1.0f, k, 0, nullptr, true, nullptr, stream, kSketchSubLists, ix->cand_cnt,
+                                       kSketchCntStride, tail);
     return rc;
 }
 
@@ -726,6 +759,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
     const int qeb = q_dtype == VQA_F32 ? 4 : 2;
     const LaunchPlan p = plan_launch(ix, k);
     bool sketch_call = false;  // some query tile of this call ran the sketch search
+    bool mirror_by_kernel = false;  // ... and its last merge reports the overflow flags to the host itself (the cascade)
     for (int q0 = 0; q0 < B; q0 += VQA_QUERY_TILE) {
         const int nq = B - q0 < VQA_QUERY_TILE ? B - q0 : VQA_QUERY_TILE;
         float* os = out_scores + (size_t)q0 * k;
@@ -742,9 +776,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             }
             continue;
         }
-        int rc = vqa_launch_tile_rows(reinterpret_cast<const char*>(q) + (size_t)q0 * ix->d * qeb, q_dtype, 0, VQA_QUERY_TILE, nq,
-                                      ix->d, ix->d_pad, ix->dtype, ix->scale, ix->q_stage, stream);
-        if (rc != VQA_OK) return rc;
+        int rc = VQA_OK;
         // An earlier sketch search of this handle that overflowed into its exact fallback (its flag arrives in the pinned mirror
         // some time after that call; a stale read only delays the reaction by a search) switches the sketch off for a while
         if (ix->sketch && q0 == 0) {
@@ -775,12 +807,25 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
         }
         const int sk_clear = q0 == 0 ? 2 : 1;  // the call's first query tile also clears the OR over the tiles
         const bool use_sketch = any_sketch && k <= max_k && !ix->cascade;  // the round's first form (VQA_SKETCH_CASCADE=0: A/B switch)
-        if (any_sketch) {  // the query tile's int8 sketch (every query its own scale) + ||q_lo||, ||q||
-            rc = vqa_launch_sketch_rows(ix->q_stage, ix->dtype, 0, VQA_QUERY_TILE, ix->d_pad, ix->d_pad8, nullptr, ix->q8_stage, ix->qrow,
+        const void* q_tile = reinterpret_cast<const char*>(q) + (size_t)q0 * ix->d * qeb;
+        if (any_sketch) {
+            // one launch: the query tile in the storage type (tiled for the exact kernels, row-major for the re-scoring) and its int8
+            // sketch (every query its own scale) + ||q_lo||, ||q||, q . mu
+            VqaQueryRows qr;
+            qr.rows = q_tile;
+            qr.src_dtype = q_dtype;
+            qr.valid = nq;
+            qr.d = ix->d;
+            qr.scale = ix->scale;
+            qr.stage = ix->q_stage;
+            qr.rowmajor = ix->q_rm;
+            rc = vqa_launch_sketch_rows(nullptr, ix->dtype, 0, VQA_QUERY_TILE, ix->d_pad, ix->d_pad8, nullptr, ix->q8_stage, ix->qrow,
                                         ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, ix->rotate, ix->center ? ix->mu : nullptr,
-                                        false, ix->qoff, stream);
-            if (rc != VQA_OK) return rc;
+                                        false, ix->qoff, stream, &qr);
+        } else {
+            rc = vqa_launch_tile_rows(q_tile, q_dtype, 0, VQA_QUERY_TILE, nq, ix->d, ix->d_pad, ix->dtype, ix->scale, ix->q_stage, stream);
         }
+        if (rc != VQA_OK) return rc;
         // k <= 12: one pass.  Larger k, first attempt: ONE pass in which every workgroup keeps its local top 12 above the
         // seeded threshold (the k-th largest seed, a valid lower bound of the k-th best score), merged to k results.  The
         // global top-k is inside the union of the local lists unless some workgroup owns more than 12 of them (with 256
@@ -804,16 +849,22 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             pc.grid0 = std::min(pc.seed_tiles, ix->max_grid);
             pc.seeds_per_tile = 2;
             ScoreTopkArgs a = exact_launch_args(ix, nq, k <= max_k ? k : max_k);
-            rc = seed_pass(ix, pc, a, k, nullptr, stream, ix->thr_seed);  // theta0 -> thr_seed
+            // (every merge also does what sits between it and the next scan: the scan's per-query constants from the threshold it
+            // has just selected, the reset of the candidate counters; the call's last one reports the overflow flags to the host)
+            MergeSketchTail t0 = qconst_tail(ix, sk_clear), t1 = qconst_tail(ix, 0), t2;
+            t2.overflow = ix->sketch_flag;
+            t2.flag_mirror = q0 + VQA_QUERY_TILE >= B ? ix->sketch_flag_dev_mirror : nullptr;
+            rc = seed_pass(ix, pc, a, k, nullptr, stream, ix->thr_seed, &t0);  // theta0 -> thr_seed
             if (rc != VQA_OK) return rc;
-            rc = sketch_scan_rescore(ix, p, ix->thr_seed, 0, p.stage_tiles, nq, 0, sk_clear, false, stream);
+            rc = sketch_scan_rescore(ix, p, nullptr, 0, p.stage_tiles, nq, 0, sk_clear, false, stream);
             if (rc != VQA_OK) return rc;
-            rc = sketch_select(ix, nq, k, nullptr, nullptr, nullptr, stream);  // theta1 -> thr0
+            rc = sketch_select(ix, nq, k, nullptr, nullptr, nullptr, stream, &t1);  // theta1 -> thr0
             if (rc != VQA_OK) return rc;
-            rc = sketch_scan_rescore(ix, p, ix->thr0, p.stage_tiles, p.tiles, nq, 0, 0, true, stream);
+            rc = sketch_scan_rescore(ix, p, nullptr, p.stage_tiles, p.tiles, nq, 0, 0, true, stream);
             if (rc != VQA_OK) return rc;
-            rc = sketch_select(ix, nq, k, os, oi, op, stream);
+            rc = sketch_select(ix, nq, k, os, oi, op, stream, &t2);
             if (rc != VQA_OK) return rc;
+            mirror_by_kernel = true;
             if (k <= max_k) {
                 a.thr_init = ix->thr_seed;
                 a.tile_begin = 0;
@@ -908,7 +959,8 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
     }
     // the overflow flags of this call (its last tile's, the OR over the earlier ones, the call's number) -> the pinned mirror a later
     // call's cool-down bookkeeping reads
-    if (sketch_call) VQA_HIP_CHECK(hipMemcpyAsync(ix->sketch_flag_host, ix->sketch_flag, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    if (sketch_call && !mirror_by_kernel)
+        VQA_HIP_CHECK(hipMemcpyAsync(ix->sketch_flag_host, ix->sketch_flag, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
     return VQA_OK;
 }
 
@@ -919,7 +971,7 @@ extern "C" int vqa_index_sketch_stats(vqa_index* ix, int64_t* out) {
     VQA_REQUIRE(ix->sketch, "vqa_index_sketch_stats: the shard keeps no sketch");
     DeviceGuard guard(ix->device);
     VQA_HIP_CHECK(hipDeviceSynchronize());
-    std::vector<unsigned> rc(ix->max_grid), cc(VQA_QUERY_TILE * kSketchSubLists);
+    std::vector<unsigned> rc(ix->max_grid), cc((size_t)VQA_QUERY_TILE * kSketchSubLists * kSketchCntStride);
     int flag[3] = {0, 0, 0};
     VQA_HIP_CHECK(hipMemcpy(rc.data(), ix->region_cnt, rc.size() * 4, hipMemcpyDeviceToHost));
     VQA_HIP_CHECK(hipMemcpy(cc.data(), ix->cand_cnt, cc.size() * 4, hipMemcpyDeviceToHost));
@@ -929,9 +981,9 @@ extern "C" int vqa_index_sketch_stats(vqa_index* ix, int64_t* out) {
         sum += v;
         mx = std::max<int64_t>(mx, v);
     }
-    for (unsigned v : cc) {
-        qsum += v;
-        mq = std::max<int64_t>(mq, v);
+    for (size_t i = 0; i < cc.size(); i += kSketchCntStride) {
+        qsum += cc[i];
+        mq = std::max<int64_t>(mq, cc[i]);
     }
     out[0] = sum;   // candidate pairs the LAST sketch scan of the last query tile left (a cascade: its second, main scan)
     out[1] = mx;    // ... the fullest workgroup region of that scan (capacity kSketchCap)

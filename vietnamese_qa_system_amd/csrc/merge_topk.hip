@@ -74,7 +74,8 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
                                                                        int out_stride, int out_offset,
                                                                        vqa_key* __restrict__ out_last_key, int query_major,
                                                                        const int* __restrict__ gate, int row_lists,
-                                                                       const unsigned* __restrict__ counts) {
+                                                                       const unsigned* __restrict__ counts, int count_stride,
+                                                                       MergeSketchTail tail) {
     if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     vqa_key* keys = reinterpret_cast<vqa_key*>(smem);    // [parts * list_len]
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
         // `parts` in a row)
         const int tpp = parts <= kMergeThreads ? kMergeThreads / parts : 1;
         for (int p = threadIdx.x / tpp; p < parts; p += kMergeThreads / tpp) {
-            const int c = (int)counts[q * parts + p] < list_len ? (int)counts[q * parts + p] : list_len;
+            const unsigned cn = counts[(size_t)(q * parts + p) * count_stride];
+            const int c = (int)cn < list_len ? (int)cn : list_len;
             const vqa_key* src = partial + ((size_t)q * row_lists + p) * list_len;
             for (int j = threadIdx.x % tpp; j < c; j += tpp) {
                 const vqa_key v = src[j];
@@ -143,6 +145,34 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
         if (out_pos) out_pos[o] = pos;
         if (out_thr && r == k - 1) out_thr[q] = empty ? -INFINITY : vqa_key_score(best);
         if (out_last_key && r == k - 1) out_last_key[q] = best;
+    }
+    // ---- the sketch search's cascade (MergeSketchTail): what used to be launches of their own between its scans
+    if (tail.qconst && threadIdx.x == 0) {  // sketch.hip sketch_qconst_kernel, for this block's query, from the k-th score just selected
+        const vqa_key kth = win[k - 1];
+        const float thr = kth == 0ull ? -INFINITY : vqa_key_score(kth);
+        const float qn = tail.qnorm[q];
+        tail.qconst[q] = tail.qoff ? thr - tail.qoff[q] - 2.0f * tail.fp_margin * qn * tail.mu_norm : thr;
+        tail.qconst[256 + q] = tail.qlo[q] + tail.fp_margin * qn;
+        tail.qconst[512 + q] = qn * (1.0f + tail.fp_margin);
+        tail.qconst[768 + q] = 1.0f / tail.qscale[q];
+    }
+    if (tail.clear && tail.cand_cnt) {
+        // the candidate counters of this query -- and, by block 0, of the queries past the batch and the overflow flags
+        for (int j = threadIdx.x; j < kSketchSubLists; j += kMergeThreads) tail.cand_cnt[(size_t)(q * kSketchSubLists + j) * kSketchCntStride] = 0u;
+        if (q == 0) {
+            for (int j = (int)gridDim.x * kSketchSubLists + threadIdx.x; j < VQA_QUERY_TILE * kSketchSubLists; j += kMergeThreads)
+                tail.cand_cnt[(size_t)j * kSketchCntStride] = 0u;
+            if (threadIdx.x == 0) {
+                tail.overflow[1] = tail.clear == 2 ? 0 : (tail.overflow[1] | tail.overflow[0]);
+                tail.overflow[0] = 0;
+                tail.overflow[2] = tail.seq;
+            }
+        }
+    }
+    if (tail.flag_mirror && q == 0 && threadIdx.x == 0) {
+        __hip_atomic_store(tail.flag_mirror, tail.overflow[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(tail.flag_mirror + 1, tail.overflow[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(tail.flag_mirror + 2, tail.overflow[2], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -275,7 +305,7 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
                               const int64_t* ids, int64_t id_base, float* out_scores, int64_t* out_ids, int64_t* out_pos,
                               float* out_thr, float score_scale, int32_t out_stride, int32_t out_offset,
                               vqa_key* out_last_key, bool query_major, const int* gate, hipStream_t stream, int32_t row_lists,
-                              const unsigned* counts) {
+                              const unsigned* counts, int32_t count_stride, const MergeSketchTail* tail) {
     if (row_lists <= 0) row_lists = parts;
     VQA_REQUIRE(row_lists >= parts, "merge_partials: %d lists per row but %d to merge", row_lists, parts);
     VQA_REQUIRE(parts >= 1 && list_len >= 1 && nq >= 1 && nq <= VQA_QUERY_TILE && k >= 1,
@@ -291,7 +321,7 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
         });
         if (rc != VQA_OK) return rc;
     }
-    if (k > 32 && !counts) {  // sort instead of k selection rounds
+    if (k > 32 && !counts && !tail) {  // sort instead of k selection rounds
         int m_pow2 = 1;
         while (m_pow2 < parts * list_len) m_pow2 <<= 1;
         const size_t lds_sort = (size_t)m_pow2 * sizeof(vqa_key);
@@ -307,7 +337,8 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
     hipLaunchKernelGGL(merge_partials_kernel, dim3(nq), dim3(kMergeThreads), lds, stream, partial, parts, list_len, k,
                        reinterpret_cast<const long long*>(ids), (long long)id_base, out_scores,
                        reinterpret_cast<long long*>(out_ids), reinterpret_cast<long long*>(out_pos), out_thr, score_scale,
-                       out_stride, out_offset, out_last_key, query_major ? 1 : 0, gate, row_lists, counts);
+                       out_stride, out_offset, out_last_key, query_major ? 1 : 0, gate, row_lists, counts, count_stride,
+                       tail ? *tail : MergeSketchTail{});
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

@@ -175,7 +175,12 @@ constexpr int kMaxK = kCap - 3;                                         // 12
 constexpr int kSeedsPerTile = 2;  // seed pass: sub-maxima kept per query and tile (one per row half; 8, one per 32 rows, for tiny shards)
 static_assert(kPipeBytes <= 144 * 1024, "ring sizes");
 
+// MODE 2 (sketch scan): no candidate lists in LDS, so the X ring takes a sixth stage (LOOP 0; the scan is bound by the HBM stream, and
+// a stage more in flight per CU is worth ~x % of it: DESIGN.md); shards of more than kSketchMaxTiles6 tiles per workgroup (50M rows on
+// 256 CUs) keep the five-stage ring (LOOP 1), whose spare LDS holds the tile maxima of up to kSketchMaxTiles tiles
+constexpr int kSketchPipe6 = (6 + 3) * kOperandBytes;
 constexpr int kSketchMaxTiles = (kLdsTotal - kPipeBytes - 4 * kQ * 4 - 16) / 16;  // tiles per workgroup of a sketch scan (LDS: 16 B each)
+constexpr int kSketchMaxTiles6 = (kLdsTotal - kSketchPipe6 - 4 * kQ * 4 - 16) / 16;
 constexpr int kOverBit = 1 << 30;  // "an append was refused" flag, kept in bit 30 of cnt[0] (LDS is fully used)
 constexpr int kCntMask = 0xFFFFFF;
 
@@ -392,8 +397,10 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         L.cnt[tid] = 0;
     }
     // MODE 2 (sketch scan): per query theta, ||q_lo||, ||q||, 1 / (s_q s_x) in the list area (4 KiB) + one append counter
-    float* const sk_q = reinterpret_cast<float*>(smem + kPipeBytes);          // [4][256]
-    int* const sk_cnt = reinterpret_cast<int*>(smem + kPipeBytes + 4 * kQ * 4);
+    constexpr int kSxSlot = (MODE == 2 && LOOP == 0) ? 6 : 5;                 // X ring stages of the slot loop
+    constexpr int kSkPipe = (kSxSlot + 3) * kOperandBytes;                    // MODE 2: where the rings end
+    float* const sk_q = reinterpret_cast<float*>(smem + kSkPipe);          // [4][256]
+    int* const sk_cnt = reinterpret_cast<int*>(smem + kSkPipe + 4 * kQ * 4);
     if (MODE == 2) {
         if (tid < kQ) {
             sk_q[tid] = tid < nq ? sk.qconst[tid] : INFINITY;
@@ -408,7 +415,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     const int ntile = first_tile < tile_end ? (tile_end - first_tile + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     const int total = ntile * KT;  // K-steps of this workgroup, numbered kappa = ti * KT + kt
     // MODE 2: (max ||x_hi||, max ||x_lo||, 1 / scale) of every tile this workgroup scans, in LDS (the launcher bounds ntile by kSketchMaxTiles)
-    float4* const sk_tm = reinterpret_cast<float4*>(smem + kPipeBytes + 4 * kQ * 4 + 16);
+    float4* const sk_tm = reinterpret_cast<float4*>(smem + kSkPipe + 4 * kQ * 4 + 16);
     if (MODE == 2)
         for (int t = tid; t < ntile; t += kThreads) sk_tm[t] = sk.tile_info[first_tile + t * (int)gridDim.x];
 
@@ -856,9 +863,9 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     // K-step's issue back to the next tile's first K-step (two issues there, vmcnt(8) in between).
     auto slot_loop = [&](auto loader_q_tag) __attribute__((always_inline)) {
         constexpr bool kQ0 = decltype(loader_q_tag)::value;  // group 0: Q loader, multiplies in slot 2
-        constexpr int SX = 5, SQ = 3;
+        constexpr int SX = kSxSlot, SQ = 3;
         constexpr int kEarly = VQA_SLOT_EARLY;  // row groups (of 8) a group multiplies right after its memory phase, before the barrier
-        static_assert((SX + SQ) * kOperandBytes == kPipeBytes, "slot loop rings fill the pipe area");
+        static_assert((SX + SQ) * kOperandBytes == (MODE == 2 ? kSkPipe : kPipeBytes), "slot loop rings fill the pipe area");
         const uint32_t ring_lds = kQ0 ? smem_lds + SX * kOperandBytes : smem_lds;
         constexpr int kRing = (kQ0 ? SQ : SX) * kOperandBytes;
         const char* src = kQ0 ? reinterpret_cast<const char*>(Qs)
@@ -958,8 +965,8 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
             if constexpr (FIRST) VQA_SLOT_MMA(0, 8);                                                                 \
             else VQA_SLOT_MMA(kEarly, 8);                                                                            \
             VQA_STAMP(1);                                                                                            \
-            if (FIRST && owe) wait_vmcnt<8>();                                                                       \
-            else wait_vmcnt<12>();                                                                                   \
+            if (FIRST && owe) wait_vmcnt<4 * (SX - 3)>();                                                            \
+            else wait_vmcnt<4 * (SX - 2)>();                                                                         \
             VQA_STAMP(2);                                                                                            \
         }                                                                                                            \
         VQA_STAMP(3);                                                                                                \
@@ -1237,10 +1244,18 @@ static int launch_sketch(const ScoreTopkArgs& a, int KT, int lds, hipStream_t st
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<2, VQA_I8_SKETCH, 1, 0>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<2, VQA_I8_SKETCH, 0, 1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<2, VQA_I8_SKETCH, 1, 1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         return VQA_OK;
     });
     if (rc != VQA_OK) return rc;
-    auto kern = a.first_stage ? score_topk_kernel<2, VQA_I8_SKETCH, 1, 0> : score_topk_kernel<2, VQA_I8_SKETCH, 0, 0>;
+    // six X stages (LOOP 0) where the workgroup's tile maxima fit beside them, five (LOOP 1) for the largest shards
+    const int per_wg = (a.tile_end - a.tile_begin + a.grid - 1) / a.grid;
+    const bool six = a.loop != 1 && per_wg <= kSketchMaxTiles6;  // (a.loop == 1: VQA_SKETCH_SX=5 at index create, dev / A-B switch)
+    auto kern = six ? (a.first_stage ? score_topk_kernel<2, VQA_I8_SKETCH, 1, 0> : score_topk_kernel<2, VQA_I8_SKETCH, 0, 0>)
+                    : (a.first_stage ? score_topk_kernel<2, VQA_I8_SKETCH, 1, 1> : score_topk_kernel<2, VQA_I8_SKETCH, 0, 1>);
     hipLaunchKernelGGL(kern, dim3(a.grid), dim3(kThreads), lds, stream, a.x, a.q, nullptr, nullptr, nullptr, (long long)a.n, KT, a.nq, a.k,
                        a.tile_begin, a.tile_end, a.gate, a.grid, 0, 2, *a.sketch);
     VQA_HIP_CHECK(hipGetLastError());

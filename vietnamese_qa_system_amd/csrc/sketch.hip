@@ -10,6 +10,8 @@
 //
 // Reference interface: the scoring inside `embeddings.search` (inference_pipeline/db_utils/heavy_ranker.py:98-101; txtai ->
 // faiss IndexFlatIP: exact inner product with every row); the result is the same, the sketch only decides which rows need it.
+#include <stdlib.h>
+
 #include "vqa_common.h"
 
 namespace {
@@ -32,9 +34,15 @@ __device__ __forceinline__ size_t unit_of(long long row, int u, int KT) {  // 16
 
 // T = _Float16 (8 elements per 16-byte unit; products exact in fp32) or float (4 per unit: fp32 index, fp32 fma chain)
 // RM: X is the shard's ROW-MAJOR copy (VQA_INDEX_RESCORE_ROWS: rows of KT * 64 bytes, the same stored values) -- a pair's row is one
-// contiguous run of whole 128-byte lines instead of 4 KT pieces of 64 bytes at 16 KiB strides.  Unit u holds the same elements in
-// both layouts, so the two forms add the same products in the same order: bit-equal scores.
-template <typename T, bool RM, int UM>
+// contiguous run of whole 128-byte lines instead of 4 KT pieces of 64 bytes at 16 KiB strides -- and Q a row-major copy of the staged
+// query tile (a half wave's load is 512 contiguous bytes instead of eight 64-byte pieces 16 KiB apart: the kernel issues two loads per
+// product, and the query side's were the less coalesced).  Unit u holds the same elements in both layouts, so the two forms add the
+// same products in the same order: bit-equal scores.
+// PH = pairs per half wave and iteration (2: four pairs per half wave measured 25 % slower at d = 768 -- 96 data registers leave
+// fewer waves per SIMD): every load of an iteration -- the rows of its 2 PH pairs and the pair descriptors of the NEXT iteration
+// -- is in flight before the first is consumed.  The kernel is a chain of dependent round trips per iteration -- descriptor, row,
+// counter -- at ~20 waves per CU.
+template <typename T, bool RM, int UM, int PH>
 __global__ __launch_bounds__(256) void rescore_kernel(const unsigned long long* __restrict__ regions, const unsigned* __restrict__ counts,
                                                       int cap, int nregions, const long long* __restrict__ stage_pos, int nq, int k,
                                                       const T* __restrict__ X, const T* __restrict__ Q, int KT,
@@ -61,55 +69,67 @@ __global__ __launch_bounds__(256) void rescore_kernel(const unsigned long long* 
             pos = stage_pos[i];
         }
     };
-    for (int i0 = wave * 4; i0 < total; i0 += nwaves * 4) {
-        // the four pairs of this iteration share a sub-list index: region + position inside it, so that both a query with a few
-        // candidates per region (B = 1: every region's first pairs) and one with thousands in ONE region use all the sub-lists
-        const unsigned sub = (unsigned)(y + (i0 >> 2)) % kSketchSubLists;
-        int q[2];
-        long long pos[2];
-        pair_of(i0 + half, q[0], pos[0]);
-        pair_of(i0 + 2 + half, q[1], pos[1]);
-        float acc[2] = {0.f, 0.f};
-        if constexpr (UM > 0) {
-            unit_t xv[2][UM], qv[2][UM];
+    int q[PH];
+    long long pos[PH];
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < PH; ++p) pair_of(wave * 2 * PH + 2 * p + half, q[p], pos[p]);
+    for (int i0 = wave * 2 * PH; i0 < total; i0 += nwaves * 2 * PH) {
+        float acc[PH];
+#pragma unroll
+        for (int p = 0; p < PH; ++p) acc[p] = 0.f;
+        int qn[PH];
+        long long posn[PH];
+        if constexpr (UM > 0) {
+            unit_t xv[PH][UM], qv[PH][UM];
+#pragma unroll
+            for (int p = 0; p < PH; ++p)
 #pragma unroll
                 for (int j = 0; j < UM; ++j) {
                     const int u = hl + 32 * j;
                     xv[p][j] = qv[p][j] = unit_t{};
                     if (u < units && pos[p] >= 0) {
                         xv[p][j] = *reinterpret_cast<const unit_t*>(X + (RM ? (size_t)pos[p] * units + u : unit_of(pos[p], u, KT)) * EPU);
-                        qv[p][j] = *reinterpret_cast<const unit_t*>(Q + unit_of(q[p], u, KT) * EPU);
+                        qv[p][j] = *reinterpret_cast<const unit_t*>(Q + (RM ? (size_t)q[p] * units + u : unit_of(q[p], u, KT)) * EPU);
                     }
                 }
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
+            for (int p = 0; p < PH; ++p) pair_of(i0 + nwaves * 2 * PH + 2 * p + half, qn[p], posn[p]);  // the next iteration's pairs
+#pragma unroll
+            for (int p = 0; p < PH; ++p)
 #pragma unroll
                 for (int j = 0; j < UM; ++j)
 #pragma unroll
                     for (int e = 0; e < EPU; ++e) acc[p] = __builtin_fmaf((float)xv[p][j][e], (float)qv[p][j][e], acc[p]);
         } else {
-            for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int p = 0; p < PH; ++p) pair_of(i0 + nwaves * 2 * PH + 2 * p + half, qn[p], posn[p]);
+            for (int p = 0; p < PH; ++p)
                 for (int u = hl; u < units && pos[p] >= 0; u += 32) {
                     const unit_t xw = *reinterpret_cast<const unit_t*>(X + (RM ? (size_t)pos[p] * units + u : unit_of(pos[p], u, KT)) * EPU);
-                    const unit_t qw = *reinterpret_cast<const unit_t*>(Q + unit_of(q[p], u, KT) * EPU);
+                    const unit_t qw = *reinterpret_cast<const unit_t*>(Q + (RM ? (size_t)q[p] * units + u : unit_of(q[p], u, KT)) * EPU);
 #pragma unroll
                     for (int e = 0; e < EPU; ++e) acc[p] = __builtin_fmaf((float)xw[e], (float)qw[e], acc[p]);
                 }
         }
 #pragma unroll
-        for (int p = 0; p < 2; ++p) {
+        for (int p = 0; p < PH; ++p) {
 #pragma unroll
             for (int off = 16; off >= 1; off >>= 1) acc[p] += __shfl_xor(acc[p], off, 64);  // inside the half wave
             if (hl == 0 && pos[p] >= 0) {
-                // sub-list `sub` of the query's list ([query][kSketchSubLists][capq / kSketchSubLists]): the appends of one search spread over
-                // 16x the counters and cache lines
+                // sub-list of the query's list ([query][kSketchSubLists][capq / kSketchSubLists]): picked by region + the pair's index in it
+                // (groups of four), so that both a query with a few candidates per region (B = 1: every region's first pairs) and one
+                // with thousands in ONE region use all the sub-lists; the appends of one search spread over 16x the counters
+                const unsigned sub = (unsigned)(y + ((i0 + 2 * p) >> 2)) % kSketchSubLists;
                 const unsigned lane_list = (unsigned)q[p] * kSketchSubLists + sub;
-                const unsigned slot = atomicAdd(cand_cnt + lane_list, 1u);
+                const unsigned slot = atomicAdd(cand_cnt + (size_t)lane_list * kSketchCntStride, 1u);
                 if (slot < (unsigned)sub_cap) cand_keys[(size_t)lane_list * sub_cap + slot] = vqa_make_key(acc[p], (uint32_t)pos[p]);
                 else atomicExch(overflow, 1);
             }
+        }
+#pragma unroll
+        for (int p = 0; p < PH; ++p) {
+            q[p] = qn[p];
+            pos[p] = posn[p];
         }
     }
 }
@@ -142,7 +162,7 @@ __global__ void sketch_qconst_kernel(const float* __restrict__ thr, const float*
     qconst[768 + q] = 1.0f / qscale[q];
     if (clear) {  // (the second scan of a cascade keeps what the first one found)
 #pragma unroll
-        for (int j = 0; j < kSketchSubLists; ++j) cand_cnt[q * kSketchSubLists + j] = 0u;
+        for (int j = 0; j < kSketchSubLists; ++j) cand_cnt[(size_t)(q * kSketchSubLists + j) * kSketchCntStride] = 0u;
         if (q == 0) {
             // overflow[0]: this query tile's flag (gates its exact fallback); overflow[1]: OR over the earlier tiles of the call
             // (clear == 2: the call's first tile), so that the host's cool-down sees an overflow of ANY tile of a B > 256 call
@@ -155,12 +175,16 @@ __global__ void sketch_qconst_kernel(const float* __restrict__ thr, const float*
 
 }  // namespace
 
+float vqa_sketch_fp_margin(int32_t d, bool rotated) {
+    // 2 gamma_d with gamma_d <= d 2^-24 / (1 - d 2^-24) < 1.2e-7 d / 2 ... kept at twice that; a rotated sketch adds the rounding of
+    // the two rotations (13 butterfly stages + the normalisation: 14 2^-24 per side, kept at twice that too)
+    return 2.0f * (float)d * 1.2e-7f + (rotated ? 4.0f * 14.0f * 6e-8f : 0.f);
+}
+
 int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float* qlo, const float* qnorm, int32_t d, float* qconst,
                              unsigned* cand_cnt, int* overflow, int clear, int seq, bool rotated, const float* qoff, float mu_norm,
                              hipStream_t stream) {
-    // 2 gamma_d with gamma_d <= d 2^-24 / (1 - d 2^-24) < 1.2e-7 d / 2 ... kept at twice that; a rotated sketch adds the rounding of
-    // the two rotations (13 butterfly stages + the normalisation: 14 2^-24 per side, kept at twice that too)
-    const float fp_margin = 2.0f * (float)d * 1.2e-7f + (rotated ? 4.0f * 14.0f * 6e-8f : 0.f);
+    const float fp_margin = vqa_sketch_fp_margin(d, rotated);
     hipLaunchKernelGGL(sketch_qconst_kernel, dim3(1), dim3(256), 0, stream, thr, qscale, qlo, qnorm, fp_margin, qconst, cand_cnt, overflow, clear, seq, qoff,
                        mu_norm);
     VQA_HIP_CHECK(hipGetLastError());
@@ -177,13 +201,16 @@ int vqa_launch_rows_to_rowmajor(const void* tiled, int64_t first, int64_t count,
 }
 
 int vqa_launch_rescore(const unsigned long long* regions, const unsigned* counts, int cap, int nregions, const long long* stage_pos,
-                       int nq, int k, const void* x, const void* x_rowmajor, const void* q, int32_t dtype, int32_t d_pad, vqa_key* cand_keys,
-                       unsigned* cand_cnt, int capq, int* overflow, hipStream_t stream) {
+                       int nq, int k, const void* x, const void* x_rowmajor, const void* q, const void* q_rowmajor, int32_t dtype, int32_t d_pad,
+                       vqa_key* cand_keys, unsigned* cand_cnt, int capq, int* overflow, hipStream_t stream) {
+    VQA_REQUIRE(!x_rowmajor || q_rowmajor, "rescore: the row-major form needs both copies");
     VQA_REQUIRE(dtype == VQA_F16 || dtype == VQA_F32, "rescore: storage type %d", dtype);
-    const dim3 grid(32, nregions + 1), block(256);
+    // six workgroups of four waves per region (measured at 10M x 768, 142k / 214k pairs: grid x = 32 / 8 / 6 / 4 / 2 -> 94 / 74 / 58 /
+    // 62 / 85 us for the first stage's pairs; fewer, longer-lived waves amortise the block dispatch, too few leave CUs idle)
+    const dim3 grid(6, nregions + 1), block(256);
 #define VQA_RESCORE_UM(T, RM, UMV, XP, KTV)                                                                                          \
-    hipLaunchKernelGGL((rescore_kernel<T, RM, UMV>), grid, block, 0, stream, regions, counts, cap, nregions, stage_pos, nq, k,       \
-                       reinterpret_cast<const T*>(XP), reinterpret_cast<const T*>(q), KTV, cand_keys, cand_cnt, capq, overflow)
+    hipLaunchKernelGGL((rescore_kernel<T, RM, UMV, 2>), grid, block, 0, stream, regions, counts, cap, nregions, stage_pos, nq, k,    \
+                       reinterpret_cast<const T*>(XP), reinterpret_cast<const T*>(RM ? q_rowmajor : q), KTV, cand_keys, cand_cnt, capq, overflow)
 #define VQA_RESCORE(T, RM, XP, KTV)                                                                                                  \
     do {                                                                                                                             \
         const int per = ((KTV) * 4 + 31) / 32; /* units per lane */                                                                  \

@@ -74,6 +74,9 @@ __host__ __device__ __forceinline__ uint32_t vqa_key_pos(vqa_key k) { return 0xF
 // over all of them.  One counter per query took every append of a search through 8 cache lines of L2 atomics: 110-130 us of a
 // 290 us kernel at 10M rows.
 constexpr int kSketchSubLists = 16;
+// ... and every counter sits on a 128-byte line of its own (stride in counters): atomics to ONE line serialise at the L2, and 4096
+// counters packed into 128 lines still took ~1700 appends per line of a 10M-row search
+constexpr int kSketchCntStride = 32;
 
 struct SketchScanArgs {
     const float4* tile_info = nullptr;  // [tiles] (max ||x_hi||, max ||x_lo||, 1 / scale, scale) of every 256-row tile of the sketch
@@ -103,7 +106,8 @@ struct ScoreTopkArgs {
     int32_t list_offset = 0;    // ... and the slot of this launch's workgroup 0 inside the row (two-stage search: the first
                                 // stage fills slots [0, grid), the main launch [grid, 2 grid) of rows of 2 grid lists)
     bool first_stage = false;   // the first-stage launch of a two-stage search: same code, its own kernel symbol
-    int32_t loop = 0;           // fp16 only: 0 = anti-phase slot loop, 1 = K-step-pair stagger loop (the fp8 structure)
+    int32_t loop = 0;           // fp16: 0 = anti-phase slot loop, 1 = K-step-pair stagger loop (the fp8 structure); sketch scan: 1 = five
+                                // X ring stages instead of six
     const SketchScanArgs* sketch = nullptr;  // not null: MODE 2 over the int8 sketch (x = sketch rows, q = sketch of the query tile)
     bool seed_only = false;  // MODE 0: writes seeds_per_tile sub-maxima per query and tile to `partial` as [query][tile - tile_begin][.]
     int32_t seeds_per_tile = 2;  // 2 (one per 128-row half) or 8 (one per 32-row group: shards of a few tiles, where 2 per tile
@@ -114,6 +118,21 @@ int vqa_score_topk_lds_bytes(int dtype, int k);
 int vqa_score_topk_max_k(int dtype);
 int vqa_score_topk_seeds_per_tile();
 int vqa_score_topk_sketch_max_tiles();  // tiles one workgroup of the sketch scan can take (its tile maxima sit in LDS)
+
+// What a merge of the sketch search's cascade does besides selecting (every pointer null: nothing).  qconst: the per-query constants
+// of the NEXT sketch scan, from this merge's k-th score (what sketch_qconst_kernel computes as a launch of its own), with the reset of
+// the candidate counters / overflow flags when `clear`.  flag_mirror: the search's last merge copies the overflow flags and the
+// call's number to the host-visible mirror (system-scope stores, the number last).
+struct MergeSketchTail {
+    float* qconst = nullptr;
+    const float *qscale = nullptr, *qlo = nullptr, *qnorm = nullptr, *qoff = nullptr;
+    float fp_margin = 0.f, mu_norm = 0.f;
+    unsigned* cand_cnt = nullptr;
+    int* overflow = nullptr;
+    int clear = 0, seq = 0;
+    int* flag_mirror = nullptr;
+};
+float vqa_sketch_fp_margin(int32_t d, bool rotated);  // sketch.hip: the margin vqa_launch_sketch_qconst uses
 
 // `parts` key lists of `list_len` keys per query ([parts][256][list_len], or query-major) -> the k best per query:
 // final [nq, k] (scores, external ids, positions) and/or the k-th best score per query (-inf when fewer exist)
@@ -128,7 +147,9 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
                                                        the first `parts` lists of every row are merged */,
                               const unsigned* counts = nullptr /* [nq][parts] or nullptr (query-major lists): only the first
                                                                   counts[q][part] slots of every list hold keys of this search
-                                                                  (the candidate sub-lists of a sketch search) */);
+                                                                  (the candidate sub-lists of a sketch search) */,
+                              int32_t count_stride = 1 /* counters between two entries of `counts` */,
+                              const MergeSketchTail* tail = nullptr);
 // one-pass large-k check: sets *flag = 1 when some workgroup's list (list_len keys, full) ends ABOVE the query's k-th merged
 // key `kth` -- that list may have dropped a row of the true top-k (capi.hip, vqa_index_search)
 int vqa_launch_verify_wide(const vqa_key* partial, int32_t parts, int32_t list_len, int32_t nq, const vqa_key* kth, int* flag,
@@ -147,11 +168,22 @@ int vqa_launch_untile_rows(const void* tiled, int64_t first, int64_t count, int3
 // TILED fp16 / fp32 rows [first, first + count) -> TILED int8 (K-blocks of 64 elements).  tile_info [tiles][4] floats = (max ||x_hi||,
 // max ||x_lo||, 1 / scale, scale) per 256-row tile: not null (index rows) -> the rows take their tile's scale and raise its two
 // maxima; null (the query tile) -> every row its own max|x| / 127, with per-row scale / ||x_lo|| / ||x|| outputs
+// the query tile of a search, staged AND sketched by one launch (vqa_launch_sketch_rows with `qr`): the caller's row-major rows ->
+// storage type -> the TILED tile `stage` (+ its row-major copy) -> sketch of those stored values
+struct VqaQueryRows {
+    const void* rows = nullptr;  // [valid][d] row-major, device
+    int32_t src_dtype = VQA_F16;  // VQA_F32 | VQA_F16
+    int32_t valid = 0, d = 0;
+    float scale = 1.0f;
+    void* stage = nullptr;     // TILED [256][d_pad] of the storage type
+    void* rowmajor = nullptr;  // [256][d_pad] or nullptr
+};
 int vqa_launch_sketch_rows(const void* tiled, int32_t src_dtype, int64_t first, int64_t count, int32_t d_pad_src, int32_t d_pad8,
                            const float* tile_info, void* out8, float* row_scale, float* row_lo, float* row_norm,
                            bool rotate /* sketch T x instead of x (convert.hip: sketch_rotate); rows and queries alike */,
                            const float* mu /* the shard's centre [d_pad8] or nullptr */, bool center /* index rows: sketch x - mu */,
-                           float* row_off /* query rows: q . mu per row, or nullptr */, hipStream_t stream);
+                           float* row_off /* query rows: q . mu per row, or nullptr */, hipStream_t stream,
+                           const VqaQueryRows* qr = nullptr /* not null: the rows come from qr (first = 0, count = 256), `tiled` is unused */);
 // mean of the `count` rows first, first + stride, first + 2 stride, ... of a TILED array -> mu [d_pad8]
 int vqa_launch_row_mean(const void* tiled, int32_t src_dtype, int64_t first, int64_t count, int64_t stride, int32_t d_pad_src, int32_t d_pad8,
                         float* mu, hipStream_t stream);
@@ -168,6 +200,7 @@ int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float*
                              const float* qoff /* q . mu per query or nullptr */, float mu_norm, hipStream_t stream);
 int vqa_launch_rescore(const unsigned long long* regions, const unsigned* counts, int cap, int nregions, const long long* stage_pos,
                        int nq, int k, const void* x, const void* x_rowmajor /* or nullptr: the tiled rows x are read */, const void* q,
-                       int32_t dtype, int32_t d_pad, vqa_key* cand_keys, unsigned* cand_cnt, int capq, int* overflow, hipStream_t stream);
+                       const void* q_rowmajor /* the staged query tile, row-major (read with x_rowmajor) */, int32_t dtype, int32_t d_pad,
+                       vqa_key* cand_keys, unsigned* cand_cnt, int capq, int* overflow, hipStream_t stream);
 // rows [first, first + count) of a tiled shard -> its row-major copy (rows of row_bytes = padded row length in bytes)
 int vqa_launch_rows_to_rowmajor(const void* tiled, int64_t first, int64_t count, int32_t row_bytes, void* out, hipStream_t stream);

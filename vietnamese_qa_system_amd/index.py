@@ -213,8 +213,9 @@ class DeviceIndex:
                     "vqa_index_search")
         return scores, ids, pos
 
-    def set_timing(self, enabled: bool) -> None:
-        N.check(self._lib.vqa_index_set_timing(self._handle, int(bool(enabled))), "vqa_index_set_timing")
+    def set_timing(self, enabled, *, resume: bool = False) -> None:
+        """Bracket the main scoring launch of every search with an event pair (``resume``: keep the pairs recorded so far)."""
+        N.check(self._lib.vqa_index_set_timing(self._handle, (2 if resume else 1) if enabled else 0), "vqa_index_set_timing")
 
     def get_timing(self) -> Tuple[float, int]:
         """(sum of main scoring-kernel time in ms, launches) since the last call; waits for the last launch."""
