@@ -318,7 +318,7 @@ def main():
         mode = {"fp16": 1, "fp8": 2, "fp32": 0}[args.dtype]
         sketch = bool(info.sketch_scan)
         esize = {"fp16": 2, "fp8": 1, "fp32": 4}[args.dtype]
-        kname = "score_topk_kernel<2, 3, 0, 0>" if sketch else f"score_topk_kernel<1, {mode}, 0, 0>"
+        kname = "score_topk_kernel<2, 3, 0, 1>" if sketch else f"score_topk_kernel<1, {mode}, 0, 0>"
         if sketch:  # the PMC bytes of THAT launch (profiles/traffic.json keeps the exact main launch's under the plain key)
             traffic = None
             if os.path.exists(tpath):

@@ -88,7 +88,7 @@ struct vqa_index {
     bool mu_set = false;
     bool center = true;                     // VQA_SKETCH_CENTER=0: no centring (needs the rotated form)
     bool rotate = true;                     // the sketch is cut from rotated rows (convert.hip: sketch_rotate); VQA_SKETCH_ROTATE=0: from the rows as they are
-    bool sketch_sx5 = false;                // VQA_SKETCH_SX=5: the sketch scan on the five-stage X ring (dev / A-B switch; default six)
+    bool sketch_sx5 = true;                 // the sketch scan's X ring: five stages; VQA_SKETCH_SX=6: six (dev / A-B switch: measured equal)
     bool cascade = true;                    // VQA_SKETCH_CASCADE=0: the exact first stage of the narrow sketch form (dev / A-B switch)
     int* sketch_flag_dev_mirror = nullptr;  // device address of the pinned mirror below (mapped host memory: the cascade's last merge writes it)
     int* sketch_flag_host = nullptr;        // pinned mirror of sketch_flag [3], copied once behind the last query tile of a call (read by LATER calls)
@@ -413,7 +413,7 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
             }
             ix->sketch_flag_host[0] = ix->sketch_flag_host[1] = ix->sketch_flag_host[2] = 0;
             if (const char* cs = getenv("VQA_SKETCH_CASCADE")) ix->cascade = cs[0] != '0';
-            if (const char* sx = getenv("VQA_SKETCH_SX")) ix->sketch_sx5 = sx[0] == '5';
+            if (const char* sx = getenv("VQA_SKETCH_SX")) ix->sketch_sx5 = sx[0] != '6';
             if (const char* ro = getenv("VQA_SKETCH_ROTATE")) ix->rotate = ro[0] != '0';
             if (const char* ce = getenv("VQA_SKETCH_CENTER")) ix->center = ce[0] != '0';
             ix->center = ix->center && ix->rotate;

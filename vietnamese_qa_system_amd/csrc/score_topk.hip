@@ -175,9 +175,10 @@ constexpr int kMaxK = kCap - 3;                                         // 12
 constexpr int kSeedsPerTile = 2;  // seed pass: sub-maxima kept per query and tile (one per row half; 8, one per 32 rows, for tiny shards)
 static_assert(kPipeBytes <= 144 * 1024, "ring sizes");
 
-// MODE 2 (sketch scan): no candidate lists in LDS, so the X ring takes a sixth stage (LOOP 0; the scan is bound by the HBM stream, and
-// a stage more in flight per CU is worth ~x % of it: DESIGN.md); shards of more than kSketchMaxTiles6 tiles per workgroup (50M rows on
-// 256 CUs) keep the five-stage ring (LOOP 1), whose spare LDS holds the tile maxima of up to kSketchMaxTiles tiles
+// MODE 2 (sketch scan): no candidate lists in LDS, so the X ring can take a sixth stage (LOOP 0, VQA_SKETCH_SX=6 at index create).
+// Measured (round 4, interleaved A/B at 10M x 768): 1.4356 vs 1.4317 ms -- nothing: the scan is not waiting for the stream, its MFMA
+// pipe sits at the rate the chip's power management allows.  The five-stage ring (LOOP 1) stays the default;
+// its spare LDS holds the tile maxima of up to kSketchMaxTiles tiles per workgroup (80M-row shards).
 constexpr int kSketchPipe6 = (6 + 3) * kOperandBytes;
 constexpr int kSketchMaxTiles = (kLdsTotal - kPipeBytes - 4 * kQ * 4 - 16) / 16;  // tiles per workgroup of a sketch scan (LDS: 16 B each)
 constexpr int kSketchMaxTiles6 = (kLdsTotal - kSketchPipe6 - 4 * kQ * 4 - 16) / 16;
@@ -1253,7 +1254,7 @@ static int launch_sketch(const ScoreTopkArgs& a, int KT, int lds, hipStream_t st
     if (rc != VQA_OK) return rc;
     // six X stages (LOOP 0) where the workgroup's tile maxima fit beside them, five (LOOP 1) for the largest shards
     const int per_wg = (a.tile_end - a.tile_begin + a.grid - 1) / a.grid;
-    const bool six = a.loop != 1 && per_wg <= kSketchMaxTiles6;  // (a.loop == 1: VQA_SKETCH_SX=5 at index create, dev / A-B switch)
+    const bool six = a.loop != 1 && per_wg <= kSketchMaxTiles6;  // (a.loop == 0: VQA_SKETCH_SX=6 at index create, dev / A-B switch)
     auto kern = six ? (a.first_stage ? score_topk_kernel<2, VQA_I8_SKETCH, 1, 0> : score_topk_kernel<2, VQA_I8_SKETCH, 0, 0>)
                     : (a.first_stage ? score_topk_kernel<2, VQA_I8_SKETCH, 1, 1> : score_topk_kernel<2, VQA_I8_SKETCH, 0, 1>);
     hipLaunchKernelGGL(kern, dim3(a.grid), dim3(kThreads), lds, stream, a.x, a.q, nullptr, nullptr, nullptr, (long long)a.n, KT, a.nq, a.k,
