@@ -42,7 +42,7 @@ extern "C" {
 /* vqa_index_create flags */
 #define VQA_INDEX_HAS_IDS 1 /* reserve the id vector even though ids_or_null is NULL (filled later by vqa_index_set_rows) */
 #define VQA_INDEX_SKETCH 2  /* fp16 / fp32 shards: keep an int8 sketch of the rows beside them (+50 % / +25 % memory).  Large shards (the
-                             * sketch search: >= 16 (fp32: 8) tiles of 256 rows per compute unit; k <= 64) then run their main
+                             * sketch search: >= 16 (fp32: 8) tiles of 256 rows per compute unit; k <= 128) then run their main
                              * launch over the sketch -- v_mfma_i32_16x16x64_i8, half the bytes and twice the matrix rate per
                              * row -- with a rigorous upper bound on every (query, row) score, and score exactly (stored rows, fp32
                              * accumulation) only the pairs the bound cannot exclude: the results are those of the exact scan.

@@ -108,7 +108,8 @@ struct vqa_index {
     std::atomic_flag busy = ATOMIC_FLAG_INIT;  // one search at a time per handle (the workspace is shared)
 };
 
-constexpr int kSketchCap = 16384;  // candidate pairs per workgroup region / keys per query list (expected: 2-4 thousand at 10M rows)
+constexpr int kSketchCap = 32768;  // candidate pairs per workgroup region / keys per query list (10M rows: ~1400 per query at k = 10,
+                                   // ~13 000 at k = 100; the last selection drops the keys below theta1 before it sorts: merge_topk.hip)
 
 struct HandleBusy {  // a second concurrent call on one handle is refused instead of corrupting the shared workspace
     std::atomic_flag& f;
@@ -544,9 +545,9 @@ struct LaunchPlan {
 
 // The sketch search (capi: vqa_index_search) serves large shards -- those the two-stage plan serves -- for k up to kSketchMaxK:
 // txtai's hybrid search asks the dense index for 10 x limit rows (30 at its default limit).  The candidates of a query grow with k
-// (theta sits at rank k: ~860 rows at k = 10, ~2300 at k = 30 of a 10M-row shard) and the exact re-scoring with them; at k = 64
-// the search still takes 3.2 ms against 4.3 ms for the exact one-pass form, at 100 the candidate buffers fill up.
-constexpr int kSketchMaxK = 64;
+// (theta sits at rank k: ~860 rows at k = 10, ~2300 at k = 30, ~13 000 at k = 100 of a 10M-row shard -- half of them from the first
+// stage, whose seed threshold is the weaker one) and the exact re-scoring with them; txtai's hybrid search at limit 10 asks for 100.
+constexpr int kSketchMaxK = 128;
 
 static LaunchPlan plan_launch(const vqa_index* ix, int k = 0) {
     LaunchPlan p;
@@ -853,6 +854,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             // has just selected, the reset of the candidate counters; the call's last one reports the overflow flags to the host)
             MergeSketchTail t0 = qconst_tail(ix, sk_clear), t1 = qconst_tail(ix, 0), t2;
             t2.overflow = ix->sketch_flag;
+            t2.min_score = ix->thr0;  // theta1: what the first selection left there
             t2.flag_mirror = q0 + VQA_QUERY_TILE >= B ? ix->sketch_flag_dev_mirror : nullptr;
             rc = seed_pass(ix, pc, a, k, nullptr, stream, ix->thr_seed, &t0);  // theta0 -> thr_seed
             if (rc != VQA_OK) return rc;
@@ -941,7 +943,9 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
                     // the exact main launch below, gated on the flag.
                     rc = sketch_scan_rescore(ix, p, ix->thr0, p.stage_tiles, p.tiles, nq, kk, sk_clear, true, stream);
                     if (rc != VQA_OK) return rc;
-                    rc = sketch_select(ix, nq, kk, os, oi, op, stream);
+                    MergeSketchTail tf;
+                    tf.overflow = ix->sketch_flag;  // (a list longer than the selection's LDS raises it)
+                    rc = sketch_select(ix, nq, kk, os, oi, op, stream, &tf);
                     if (rc != VQA_OK) return rc;
                     a.gate = ix->sketch_flag;  // the exact main launch + merge below: only when the flag is up
                 }

@@ -75,11 +75,11 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
                                                                        vqa_key* __restrict__ out_last_key, int query_major,
                                                                        const int* __restrict__ gate, int row_lists,
                                                                        const unsigned* __restrict__ counts, int count_stride,
-                                                                       MergeSketchTail tail) {
+                                                                       MergeSketchTail tail, int cap_keys) {
     if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    vqa_key* keys = reinterpret_cast<vqa_key*>(smem);    // [parts * list_len]
-    vqa_key* red = keys + (size_t)parts * list_len;      // [2][4]
+    vqa_key* keys = reinterpret_cast<vqa_key*>(smem);    // [cap_keys] (= parts * list_len unless the lists are longer than LDS: counts form)
+    vqa_key* red = keys + cap_keys;                      // [2][4]
     int* fill = reinterpret_cast<int*>(red + 8);         // keys kept
     const int q = blockIdx.x;
     const int m_all = parts * list_len;
@@ -97,13 +97,18 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
         // (kMergeThreads / parts threads per sub-list, all sub-lists at once: one dependent count load per thread instead of
         // `parts` in a row)
         const int tpp = parts <= kMergeThreads ? kMergeThreads / parts : 1;
+        // keys below the floor cannot be among the k best (MergeSketchTail::min_score); the key of (floor, any position) is >= this one
+        const vqa_key floor_key = tail.min_score ? vqa_make_key(tail.min_score[q], 0xFFFFFFFFu) : 0ull;
         for (int p = threadIdx.x / tpp; p < parts; p += kMergeThreads / tpp) {
             const unsigned cn = counts[(size_t)(q * parts + p) * count_stride];
             const int c = (int)cn < list_len ? (int)cn : list_len;
             const vqa_key* src = partial + ((size_t)q * row_lists + p) * list_len;
             for (int j = threadIdx.x % tpp; j < c; j += tpp) {
                 const vqa_key v = src[j];
-                if (v != 0ull) keys[atomicAdd(fill, 1)] = v;
+                if (v != 0ull && v >= floor_key) {
+                    const int slot = atomicAdd(fill, 1);
+                    if (slot < cap_keys) keys[slot] = v;
+                }
             }
         }
     } else
@@ -119,7 +124,11 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
         else if (v != 0ull) keys[atomicAdd(fill, 1)] = v;
     }
     __syncthreads();
-    const int m = *fill;
+    int m = *fill;
+    if (m > cap_keys) {  // more surviving keys than LDS holds: this selection is not to be trusted -- the search's exact fallback takes over
+        m = cap_keys;
+        if (threadIdx.x == 0 && tail.overflow) atomicExch(tail.overflow, 1);
+    }
     // The winners are collected in LDS and written out after the last round: __syncthreads waits for every outstanding memory
     // operation of the wave, so a global store per round made each round pay a store round trip (~2 us against ~0.6 us of work).
     vqa_key* win = reinterpret_cast<vqa_key*>(fill + 2);  // [k]
@@ -310,7 +319,14 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
     VQA_REQUIRE(row_lists >= parts, "merge_partials: %d lists per row but %d to merge", row_lists, parts);
     VQA_REQUIRE(parts >= 1 && list_len >= 1 && nq >= 1 && nq <= VQA_QUERY_TILE && k >= 1,
                 "merge_partials: bad shape parts=%d list_len=%d nq=%d k=%d", parts, list_len, nq, k);
-    const size_t lds = ((size_t)parts * list_len + 10 + (size_t)k) * sizeof(vqa_key);  // keys, 2 x 4 reduction slots, the fill counter, k winners
+    // (the candidate lists of a sketch search may be longer than LDS: the kernel keeps the keys at or above tail->min_score, up to cap_keys)
+    constexpr int kMaxLdsKeys = 18 * 1024;
+    int cap_keys = parts * list_len;
+    if (counts && cap_keys > kMaxLdsKeys) {
+        VQA_REQUIRE(tail && tail->overflow, "merge_partials: %d x %d candidate keys need an overflow flag", parts, list_len);
+        cap_keys = kMaxLdsKeys;
+    }
+    const size_t lds = ((size_t)cap_keys + 10 + (size_t)k) * sizeof(vqa_key);  // keys, 2 x 4 reduction slots, the fill counter, k winners
     VQA_REQUIRE(lds <= 160 * 1024, "merge_partials: %d lists x %d keys do not fit in LDS", parts, list_len);
     if (lds > 64 * 1024) {
         static VqaPerDeviceOnce once;
@@ -338,7 +354,7 @@ int vqa_launch_merge_partials(const vqa_key* partial, int32_t parts, int32_t lis
                        reinterpret_cast<const long long*>(ids), (long long)id_base, out_scores,
                        reinterpret_cast<long long*>(out_ids), reinterpret_cast<long long*>(out_pos), out_thr, score_scale,
                        out_stride, out_offset, out_last_key, query_major ? 1 : 0, gate, row_lists, counts, count_stride,
-                       tail ? *tail : MergeSketchTail{});
+                       tail ? *tail : MergeSketchTail{}, cap_keys);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

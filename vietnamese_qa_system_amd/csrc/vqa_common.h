@@ -131,6 +131,9 @@ struct MergeSketchTail {
     int* overflow = nullptr;
     int clear = 0, seq = 0;
     int* flag_mirror = nullptr;
+    const float* min_score = nullptr;  // [nq] or nullptr: keys scoring below it are dropped before the selection (the cascade's last merge:
+                                       // theta1, the exact k-th best score of the first stage -- no key below it can be among the k best);
+                                       // a list that still overflows the kernel's LDS raises overflow[0]: the search's exact fallback runs
 };
 float vqa_sketch_fp_margin(int32_t d, bool rotated);  // sketch.hip: the margin vqa_launch_sketch_qconst uses
 
