@@ -545,6 +545,20 @@ def other_configs(torch, np, device, dev_index, n, d, b, k):
                        "recall_check": f"{nv} queries x the first {pre_rows} rows (a prefix-only index), oracle on the same e4m3 codes / on the fp32 rows",
                        "seconds": round(time.perf_counter() - t0, 1)}
     del prefix
+    if n >= 10_000_000:
+        # configs[4]'s per-GPU share: 100M x 768 fp8 over 8 GPUs = 12.5M rows (9.6 GB) per shard
+        t0 = time.perf_counter()
+        n125 = 12_500_000
+        ix8 = DeviceIndex.empty(n125, d, id_base=1, dtype="fp8", device=dev_index)
+        fill(ix8, n125, 0)
+        step_ms, kern_ms = timed_search(torch, ix8, q32, k, 20)
+        info = ix8.launch_info(b, k)
+        ix8.close()
+        out["fp8_e4m3_12p5M_rows_per_gpu_share_of_configs4"] = {
+            "rows": n125, "queries_per_s": round(b / (step_ms * 1e-3), 1), "step_ms": round(step_ms, 4), "kernel_ms": round(kern_ms, 4),
+            "main_launch_frac": round(info.bytes_per_launch / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            **{kk: vv for kk, vv in step_bytes(info, None, n125, d, 1, b, step_ms).items() if kk != "step_bytes_by_launch"},
+            "seconds": round(time.perf_counter() - t0, 1)}
     # ---- configs[1]: fp32 index of 1M rows + the encoder over all B x L positions (padded form).  Default path: the int8 sketch
     # scan + exact fp32 re-scoring (shards of >= 524k rows); beside it the exact scan on the f32 MFMA (VQA_SKETCH=0)
     t0 = time.perf_counter()
