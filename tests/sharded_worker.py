@@ -67,7 +67,9 @@ def main():
         s, i = emb._searcher.search(q, k)
         torch.cuda.synchronize()
         assert torch.equal(i, ref[1]), f"{name}: ids differ on rank {rank}"
-        assert torch.equal(s, ref[0]), f"{name}: scores differ on rank {rank}"
+        assert torch.equal(s, ref[0]), (f"{name}: scores differ on rank {rank}: max |diff| {float((s - ref[0]).abs().max()):.3g} at "
+                                        f"{(s != ref[0]).nonzero()[:4].tolist()} ids {i[s != ref[0]][:12].tolist()}; shard sketch state {emb._index.sketch_state()}"
+                                        + (f" stats {emb._index.sketch_stats()}" if emb._index.sketch_state() >= 0 else ""))
         assert emb._searcher.collectives == before + (1 if collective else 0), f"{name}: the all-gather did not run"
         checks.append(name)
 
@@ -224,6 +226,7 @@ def main():
     assert one.launch_info(24, k).sketch_scan == 1
     s1, i1, _ = one.search(q3t, k)
     torch.cuda.synchronize()
+    assert one.sketch_state() == 0, (one.sketch_state(), one.sketch_stats())  # a fallback would return the exact scan's bits instead
     compare("sketch-shards", e10, q3t, k, (s1.clone(), i1.clone()))
     tie = sorted({123} | {p for lo, _ in b3[1:] for p in (lo - 1, lo, lo + 65_536)})
     assert i1[0, :min(k, len(tie))].cpu().numpy().tolist() == tie[:k], (i1[0].tolist(), tie)

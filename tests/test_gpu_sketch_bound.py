@@ -225,7 +225,7 @@ def test_small_k_fallback_keeps_the_row_that_defines_theta(native_lib, monkeypat
     best rows sit in the first stage: the cascade overflows and its gated exact pass runs.  Its threshold must come from the
     scan's own arithmetic: a threshold summed in the re-scoring kernel's order could exceed the MFMA sum of the very row that
     defines it by an ulp and leave fewer than k results (k = 1: (-inf, -1) for a query with a real best row)."""
-    n, d, b = 200_000, 192, 8   # 25 000 near-duplicates per query: its 16 sub-lists of 1024 candidates overflow
+    n, d, b = 200_000, 192, 4   # 50 000 near-duplicates per query: its 16 sub-lists of 2048 candidates overflow
     rng = np.random.default_rng(99)
     v = rng.standard_normal((b, d)).astype(np.float32)
     v /= np.linalg.norm(v, axis=1, keepdims=True)
@@ -370,4 +370,28 @@ def test_captured_search_replays_on_data_that_overflows(native_lib, monkeypatch)
         s0, p0 = want[name]
         assert np.array_equal(i, p0), name          # ids = positions (id_base 0)
         assert np.abs(s - s0).max() <= 3e-7, name
+    ske.close()
+
+
+@pytest.mark.parametrize("pattern", ["0xCB", "0x7F", "0xFF"])
+def test_dirty_workspaces_and_a_partial_query_tile(native_lib, monkeypatch, pattern):
+    """hipMalloc hands a long-lived process recycled, dirty memory.  VQA_POISON_WORKSPACE fills every workspace a search must write
+    before it reads with a byte pattern (0xCB...: large negative floats, 0x7F7F...: 3.4e38, 0xFF...: NaN): a batch of 24 queries --
+    232 padded query rows whose per-query constants nobody writes -- and batches across the tile limit must still take the sketch
+    search (round 4: a negative garbage 1 / s_q turned the padded queries' +inf threshold into -inf and flooded every region)."""
+    n, d, k = 200_000, 64, 10
+    rng = np.random.default_rng(44)
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    x = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float16)
+    ref = _index(x, monkeypatch, sketch=False)
+    ske = _index(x, monkeypatch, sketch=True, env={"VQA_POISON_WORKSPACE": pattern})
+    for b in (24, 1, 256, 300, 13):
+        q = rng.standard_normal((b, d)).astype(np.float32)
+        q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float16)
+        s0, p0 = _search(ref, q, k)
+        s1, p1 = _search(ske, q, k)
+        st, state = ske.sketch_stats(), ske.sketch_state()
+        assert st["overflow"] == 0 and st["overflow_earlier_tiles"] == 0 and state == 0, (b, st, state)
+        assert np.array_equal(p1, p0) and np.abs(s1 - s0).max() <= 3e-7, b
+    ref.close()
     ske.close()

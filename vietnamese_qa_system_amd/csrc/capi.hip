@@ -459,6 +459,29 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
                 }
             }
         }
+        if (const char* pz = getenv("VQA_POISON_WORKSPACE")) {
+            // test hook: every workspace a search is expected to WRITE before it reads starts as a byte pattern instead of whatever the
+            // allocator hands out (a long-lived process gets recycled, dirty memory; 0xCB... reads as a large negative float)
+            const int byte = (int)strtol(pz, nullptr, 0) & 0xFF;
+            const int max_k2 = vqa_score_topk_max_k(dtype);
+            (void)hipMemset(ix->q_stage, byte, (size_t)VQA_QUERY_TILE * ix->d_pad * eb);
+            (void)hipMemset(ix->partial, byte, (size_t)4 * ix->max_grid * VQA_QUERY_TILE * max_k2 * sizeof(vqa_key));
+            (void)hipMemset(ix->thr0, byte, VQA_QUERY_TILE * sizeof(float));
+            (void)hipMemset(ix->thr_seed, byte, VQA_QUERY_TILE * sizeof(float));
+            (void)hipMemset(ix->upper, byte, VQA_QUERY_TILE * sizeof(vqa_key));
+            if (ix->sketch) {
+                (void)hipMemset(ix->qrow, byte, 3 * VQA_QUERY_TILE * sizeof(float));
+                (void)hipMemset(ix->qconst, byte, 4 * VQA_QUERY_TILE * sizeof(float));
+                (void)hipMemset(ix->regions, byte, (size_t)ix->max_grid * kSketchCap * 8);
+                (void)hipMemset(ix->region_cnt, byte, (size_t)ix->max_grid * 4);
+                (void)hipMemset(ix->cand_keys, byte, (size_t)VQA_QUERY_TILE * kSketchCap * sizeof(vqa_key));
+                (void)hipMemset(ix->cand_cnt, byte, (size_t)VQA_QUERY_TILE * kSketchSubLists * kSketchCntStride * 4);
+                (void)hipMemset(ix->stage_pos, byte, (size_t)VQA_QUERY_TILE * max_k2 * 8);
+                if (ix->qoff) (void)hipMemset(ix->qoff, byte, VQA_QUERY_TILE * 4);
+                if (ix->q_rm) (void)hipMemset(ix->q_rm, byte, (size_t)VQA_QUERY_TILE * ix->d_pad * eb);
+            }
+            (void)hipDeviceSynchronize();
+        }
         if (rows && n > 0) rc = vqa_index_set_rows(ix, 0, n, rows, rows_dtype, ids_or_null);
     } while (0);
     if (rc != VQA_OK) {
@@ -617,7 +640,8 @@ extern "C" int vqa_index_launch_info(const vqa_index* ix, int32_t B, int32_t k, 
 extern "C" int vqa_index_set_timing(vqa_index* ix, int32_t enabled) {
     VQA_REQUIRE(ix, "vqa_index_set_timing: index is null");
     ix->timing = enabled != 0;
-    if (enabled != 2) ix->ev_used = 0;  // 2: resume -- keep the event pairs recorded so far (sampled timing: bench.py brackets every 4th step)
+    if (enabled == 1) ix->ev_used = 0;  // 1: from scratch; 0 / 2: stop / resume -- the pairs recorded so far stay until vqa_index_get_timing
+                                        // (sampled timing: bench.py brackets every 4th step)
     return VQA_OK;
 }
 

@@ -404,10 +404,14 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     int* const sk_cnt = reinterpret_cast<int*>(smem + kSkPipe + 4 * kQ * 4);
     if (MODE == 2) {
         if (tid < kQ) {
-            sk_q[tid] = tid < nq ? sk.qconst[tid] : INFINITY;
-            sk_q[kQ + tid] = sk.qconst[kQ + tid];
-            sk_q[2 * kQ + tid] = sk.qconst[2 * kQ + tid];
-            sk_q[3 * kQ + tid] = sk.qconst[3 * kQ + tid];
+            // queries past the batch never produce a candidate: theta = +inf and benign factors (the rows of qconst past nq are
+            // whatever the device memory held -- the cascade's merges write the constants of the batch's queries only; a negative
+            // garbage 1 / s_q would turn +inf into -inf and flood every region with the zero rows of the padded queries)
+            const bool live = tid < nq;
+            sk_q[tid] = live ? sk.qconst[tid] : INFINITY;
+            sk_q[kQ + tid] = live ? sk.qconst[kQ + tid] : 0.f;
+            sk_q[2 * kQ + tid] = live ? sk.qconst[2 * kQ + tid] : 0.f;
+            sk_q[3 * kQ + tid] = live ? sk.qconst[3 * kQ + tid] : 1.f;
         }
         if (tid == 0) *sk_cnt = 0;
     }
