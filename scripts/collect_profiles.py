@@ -15,7 +15,7 @@ with open(os.path.join(dst, f"{name}_kernel_stats.csv"), "w", newline="") as f:
 summ = json.load(open(os.path.join(src, "pmc_summary.json")))
 bench = summ.pop("bench", None)
 if summ.get("kernel") in (None, "", "void "):
-    summ["kernel"] = next((r[0][:120] for r in rows[1:] if re.search(r"score_topk_kernel<2, 3, 0|score_topk_kernel<1, \d, 0(, \d)?>|score_topk_kernelILi1ELi\dELi0E", r[0])), summ.get("kernel"))
+    summ["kernel"] = next((r[0][:120] for r in rows[1:] if re.search(r"score_topk_kernel<2, 3, 0, \d>|score_topk_kernel<1, \d, 0(, \d)?>|score_topk_kernelILi1ELi\dELi0E", r[0])), summ.get("kernel"))
 json.dump(summ, open(os.path.join(dst, f"{name}_pmc_summary.json"), "w"), indent=1)
 if bench:
     json.dump(bench, open(os.path.join(dst, f"{name}_bench.json"), "w"), indent=1)

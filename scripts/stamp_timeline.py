@@ -31,6 +31,8 @@ for _ in range(12):
 torch.cuda.synchronize()
 lib = N.load()
 KT = (args.d * 2 + 63) // 64 if args.dtype == "fp16" else (args.d + 127) // 128  # fp8: K-step pairs per tile
+if ix.launch_info(256, 10).sketch_scan:  # the stamped launch is the int8 sketch scan: K-steps of 64 one-byte elements
+    KT = (args.d + 127) // 128 * 2
 out = np.zeros((8, 64, 8), dtype=np.uint64)
 lib.vqa_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert lib.vqa_debug_read_stamps(out.ctypes.data, out.size) == 0

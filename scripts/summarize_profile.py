@@ -20,7 +20,7 @@ main_name = None
 # score_topk_kernel<1, DT, 0, L> (<1, DT, 1, L> is the first stage of a two-stage search, <0, ..> the seed pass)
 MAIN = r"score_topk_kernel<1, \d, 0(, \d)?>|score_topk_kernelILi1ELi\dELi0E"
 if any(re.search(r"score_topk_kernel<2, 3", r["Kernel_Name"]) for r in rows("pmc_fetch", "counter_collection.csv")):
-    MAIN = r"score_topk_kernel<2, 3, 0, 0>"
+    MAIN = r"score_topk_kernel<2, 3, 0, \d>"
     out["sketch_scan"] = True
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
     agg = collections.defaultdict(list)
@@ -33,6 +33,17 @@ for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
         out[name] = sum(x[0] for x in v) / len(v)
         out[sub + "_kernel_ms"] = sum(x[1] for x in v) / len(v) / 1e6
 out["kernel"] = main_name
+# every kernel of the search step, from the same passes: mean HBM read / write bytes per launch (the cross-check of bench.py's
+# algorithmic step_bytes_moved: one step = the launches of one vqa_index_search)
+per = collections.defaultdict(lambda: collections.defaultdict(list))
+for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    for r in rows(sub, "counter_collection.csv"):
+        m = re.search(r"(score_topk_kernel<[^>]*>|rescore_kernel|merge_partials_kernel|sketch_rows_kernel|tile_rows_kernel|sketch_qconst_kernel)", r["Kernel_Name"])
+        if m and r["Counter_Name"] == ctr:
+            per[m.group(1)][ctr].append(float(r["Counter_Value"]))
+out["per_kernel_hbm_bytes_per_launch"] = {
+    k: {"launches_seen": len(v.get("FETCH_SIZE", [])), "read_corrected": round(sum(v.get("FETCH_SIZE", [0])) / max(len(v.get("FETCH_SIZE", [])), 1) * 2048),
+        "write": round(sum(v.get("WRITE_SIZE", [0])) / max(len(v.get("WRITE_SIZE", [])), 1) * 1024)} for k, v in per.items()}
 if "FETCH_SIZE" in out:
     out["hbm_read_bytes_corrected"] = out["FETCH_SIZE"] * 1024 * 2
 if "WRITE_SIZE" in out:
