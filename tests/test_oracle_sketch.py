@@ -41,7 +41,7 @@ def test_sketch_bound_never_falls_below_the_true_score(name, x):
 def test_sketch_bound_prunes_unit_vectors():
     """d = 768 unit vectors: the slack is about half a standard deviation of the scores.  At this toy size the threshold (10th
     best of 410 rows: 2 sigma) still lets 8 % of the pairs through; at 10M rows it sits at 4.3 sigma and 1e-4 of them survive
-    (220 000 of 2.3e9: the GPU path's regime, DESIGN.md section 4 K1s)."""
+    (220 000 of 2.3e9: the GPU path's regime, DESIGN.md section 4.1)."""
     rng = np.random.default_rng(2)
     n, d, b = 4096, 768, 16
     x = R.l2_normalize(rng.standard_normal((n, d)).astype(np.float32)).astype(np.float16).astype(np.float32)
