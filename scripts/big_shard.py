@@ -39,6 +39,10 @@ torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / args.steps * 1e3
 ok = bool(np.array_equal(p[:64, 0].cpu().numpy(), needles)) and bool((s[:64, 0] > 0.99).all())
 print(json.dumps({"rows": n, "index_gb": round(n * d * 2 / 1e9, 1), "build_s": round(build_s, 1), "ms_per_batch": round(ms, 3),
-                  "queries_per_s": round(b / ms * 1e3, 1), "hbm_gbs": round(n * d * 2 / ms / 1e6, 1), "needles_found_first": ok,
-                  "sketch_scan": int(ix.launch_info(b, k).sketch_scan), "hbm_allocated_gb": round(torch.cuda.memory_allocated() / 1e9, 1),
+                  "queries_per_s": round(b / ms * 1e3, 1), "needles_found_first": ok,
+                  "sketch_scan": int(ix.launch_info(b, k).sketch_scan),
+                  # bytes of the dominant launch as that launch reads them (one byte per element through the int8 sketch), never the fp16
+                  # shard size over a step that does not read it
+                  "main_launch_gb": round(ix.launch_info(b, k).rows_per_launch * d * (1 if ix.launch_info(b, k).sketch_scan else 2) / 1e9, 1),
+                  "step_gbs_of_main_launch_bytes": round(ix.launch_info(b, k).rows_per_launch * d * (1 if ix.launch_info(b, k).sketch_scan else 2) / ms / 1e6, 1), "hbm_allocated_gb": round(torch.cuda.memory_allocated() / 1e9, 1),
                   "hbm_in_use_gb": round((torch.cuda.mem_get_info()[1] - torch.cuda.mem_get_info()[0]) / 1e9, 1)}))
