@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VQA_VERSION 106 /* 0.1.6: vqa_index_sketch_stats, vqa_index_get_sketch_tile; 0.1.5: vqa_index_sketch_state; 0.1.4: VQA_INDEX_RESCORE_ROWS, vqa_index_device_bytes; 0.1.3: VQA_INDEX_SKETCH */
+#define VQA_VERSION 107 /* 0.1.7: vqa_index_get_sketch_split; 0.1.6: vqa_index_sketch_stats, vqa_index_get_sketch_tile; 0.1.5: vqa_index_sketch_state; 0.1.4: VQA_INDEX_RESCORE_ROWS, vqa_index_device_bytes; 0.1.3: VQA_INDEX_SKETCH */
 
 /* error codes */
 #define VQA_OK 0
@@ -119,9 +119,12 @@ int32_t vqa_index_sketch_state(const vqa_index* index);
  * the call's earlier tiles, capacity of a region, capacity of a sub-list }.  bench.py derives a step's physical bytes from it.
  * vqa_index_get_sketch_tile: the int8 codes of one 256-row tile as host [256, d8] row-major (d8 = d rounded up to 128), its
  * (max ||x_hi||, max ||x_lo||, 1 / scale, scale) and, optionally, the shard's centre mu [d8] (zeros when the sketch is not centred):
- * what the bound of the sketch search is computed from, for tests that restate it independently. */
+ * what the bound of the sketch search is computed from, for tests that restate it independently.
+ * vqa_index_get_sketch_split: the tile's max |w . x_lo| and, optionally, w [d8] -- the rotated, normalised centre along which the
+ * bound's slack term |z . x_lo| is split into |alpha| |w . x_lo| + ||z - alpha w|| ||x_lo|| (zeros when the shard does not split). */
 int vqa_index_sketch_stats(vqa_index* index, int64_t* out /* [8] */);
 int vqa_index_get_sketch_tile(vqa_index* index, int64_t tile, int8_t* out_codes, float* out_info /* [4] */, float* out_mu_or_null);
+int vqa_index_get_sketch_split(vqa_index* index, int64_t tile, float* out_c /* [1] */, float* out_w_or_null /* [d8] */);
 
 /* ---- search: replaces the scoring + top-k inside Embeddings.search / batchsearch (heavy_ranker.py:98,100) ---
  * q: [B, d] DEVICE pointer, element type q_dtype (VQA_F32 or VQA_F16; converted to the index storage type with

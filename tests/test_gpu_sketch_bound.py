@@ -216,7 +216,55 @@ def test_device_sketch_of_a_tile_dominates_the_true_residues(native_lib, monkeyp
         slack = 14 * 2.0 ** -24 * np.linalg.norm(yv, axis=1).max() if rot else 0.0  # the rotation's own fp32 rounding (joins the margin)
         assert hi <= info[0] <= hi * 1.0001 + 1e-12, (hi, info[0])
         assert lo - slack <= info[1] <= (lo + slack) * 1.0001 + 1e-12, (lo, info[1])
+        # the split of the slack term |z . x_lo| along w = T mu / ||T mu||: the tile's max |w . x_lo| must dominate the float64 value
+        # (any w and any C >= max |w . x_lo| keep the bound valid: |z . x_lo| <= |alpha| C + ||z - alpha w|| ||x_lo|| for every alpha)
+        c, w = ske.sketch_split(tile)
+        if centred:
+            tw = t @ mu.astype(np.float64)
+            assert np.abs(w - tw / np.linalg.norm(tw)).max() < 1e-5 and abs(np.linalg.norm(w.astype(np.float64)) - 1.0) < 1e-5
+            cw = np.abs((yv - s * codes.astype(np.float64)) @ w.astype(np.float64)).max()
+            assert cw - slack <= c <= (cw + slack) * 1.001 + 2e-4 * lo, (cw, c)
+            assert c < 0.5 * info[1]  # a quantisation residue is nearly orthogonal to a fixed direction: that is the point of the split
+        else:
+            assert c == 0.0 and not np.any(w)
     ske.close()
+
+
+def test_split_slack_term_prunes_collapsed_embeddings_and_changes_no_result(native_lib, monkeypatch):
+    """Embeddings that share one large common component (mean cosine 0.9: what an untrained encoder emits): the queries are mostly
+    alpha w, so splitting the slack term |z . x_lo| along w removes most of ||q|| ||x_lo||.  Same rows and scores as without the
+    split and as the exact scan; fewer candidate pairs."""
+    n, d, b, k = 300_000, 768, 64, 10
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    c = torch.randn((1, d), generator=g, device="cuda")
+    c /= c.norm()
+
+    def draw(m):
+        v = torch.randn((m, d), generator=g, device="cuda")
+        v = 3.0 * c + v / v.norm(dim=1, keepdim=True)
+        return (v / v.norm(dim=1, keepdim=True)).half().cpu().numpy()
+
+    x, q = draw(n), draw(b)
+    pairs = {}
+    res = {}
+    for name, env in (("split", {}), ("plain", {"VQA_SKETCH_SPLIT": "0"})):
+        ske = _index(x, monkeypatch, sketch=True, env=env)
+        res[name] = _search(ske, q.astype(np.float32), k)
+        st = ske.sketch_stats()
+        assert st["overflow"] == 0 and ske.sketch_state() == 0, (name, st)
+        pairs[name] = st["rescored_pairs"]
+        ske.close()
+        monkeypatch.delenv("VQA_SKETCH_SPLIT", raising=False)
+    ref = _index(x, monkeypatch, sketch=False)
+    s0, p0 = _search(ref, q.astype(np.float32), k)
+    ref.close()
+    assert np.array_equal(res["split"][0], res["plain"][0]) and np.array_equal(res["split"][1], res["plain"][1])
+    assert np.abs(res["split"][0] - s0).max() < 1e-6  # re-scoring vs MFMA summation order, scores near 0.9
+    gap = np.minimum(np.abs(np.diff(s0, axis=1, prepend=np.inf)), np.abs(np.diff(s0, axis=1, append=-np.inf)))
+    clear = gap > 2e-6  # rows whose neighbours in the ranking are further away than the two arithmetics differ
+    assert clear.mean() > 0.9 and np.array_equal(res["split"][1][clear], p0[clear])
+    assert pairs["split"] < 0.5 * pairs["plain"], pairs
 
 
 @pytest.mark.parametrize("k", [1, 2, 10])

@@ -72,9 +72,10 @@ struct vqa_index {
     size_t rows8_bytes = 0;
     void* rows_rm = nullptr;     // VQA_INDEX_RESCORE_ROWS: row-major copy of the stored rows (rows_bytes), read by the sketch search's re-scoring
     float* tile_info = nullptr;     // [tiles][4]: max ||x_hi||, max ||x_lo||, 1 / scale, scale of every 256-row tile (x_int = rint(x / scale))
+    float* tile_c = nullptr;        // [tiles] (behind tile_info, same allocation): max |w . x_lo| of every tile -- the split slack term
     void* q8_stage = nullptr;       // sketch of the staged query tile
-    float* qrow = nullptr;          // [3][256] per query: scale, ||q_lo||, ||q||
-    float* qconst = nullptr;        // [4][256] the scan's per-query constants
+    float* qrow = nullptr;          // [5][256] per query: scale, ||q_lo||, ||q||, |alpha| = |z . w|, ||z - alpha w||
+    float* qconst = nullptr;        // [kSketchQRows][256] the scan's per-query constants
     unsigned long long* regions = nullptr;  // [max_grid][kSketchCap] candidate pairs per workgroup of the scan
     unsigned* region_cnt = nullptr;         // [max_grid]
     vqa_key* cand_keys = nullptr;           // [256][kSketchCap] exact (score, position) keys per query
@@ -83,6 +84,9 @@ struct vqa_index {
                                             // [1] = OR of [0] over the EARLIER query tiles of the call, [2] = the call's number (sketch_qconst_kernel)
     long long* stage_pos = nullptr;         // [256][max_k] row positions of the first stage's top-k
     float* mu = nullptr;                    // [d_pad8] centre of the shard (mean of the rows of its first fill), subtracted before the sketch
+    float* wdir = nullptr;                  // [d_pad8] (behind mu, same allocation) w = T mu / ||T mu||: the slack term |z . x_lo| of the bound is split
+                                            // along it (convert.hip sketch_rows_kernel); VQA_SKETCH_SPLIT=0: not (dev / A-B switch)
+    bool split = true;
     float* qoff = nullptr;                  // [256] q . mu of the query tile
     float mu_norm = 0.f;
     bool mu_set = false;
@@ -276,12 +280,20 @@ extern "C" int vqa_index_set_rows(vqa_index* ix, int64_t first, int64_t count, c
             for (float v : h) n2 += (double)v * v;
             ix->mu_norm = (float)(std::sqrt(n2) * (1.0 + 1e-6));
             ix->mu_set = true;
+            if (ix->wdir) {
+                rcm = vqa_launch_center_dir(ix->mu, ix->d_pad8, ix->rotate, ix->wdir, nullptr);
+                if (rcm != VQA_OK) return rcm;
+            }
         }
-        int rc = vqa_launch_tile_scales(ix->rows, ix->dtype, t0, t1 - t0 + 1, ix->d_pad, ix->d_pad8, ix->tile_info, ix->rotate, ix->center ? ix->mu : nullptr, nullptr);
+        int rc = vqa_launch_tile_scales(ix->rows, ix->dtype, t0, t1 - t0 + 1, ix->d_pad, ix->d_pad8, ix->tile_info, ix->rotate, ix->center ? ix->mu : nullptr, nullptr,
+                                        ix->tile_c);
         if (rc != VQA_OK) return rc;
         const int64_t r0 = t0 * 256, r1 = std::min<int64_t>(ix->n, (t1 + 1) * 256);
+        SketchSplit sp;
+        sp.wdir = ix->wdir;
+        sp.tile_c = ix->tile_c;
         rc = vqa_launch_sketch_rows(ix->rows, ix->dtype, r0, r1 - r0, ix->d_pad, ix->d_pad8, ix->tile_info, ix->rows8, nullptr, nullptr,
-                                    nullptr, ix->rotate, ix->center ? ix->mu : nullptr, true, nullptr, nullptr);
+                                    nullptr, ix->rotate, ix->center ? ix->mu : nullptr, true, nullptr, nullptr, nullptr, ix->wdir ? &sp : nullptr);
         if (rc != VQA_OK) return rc;
         if (ix->rows_rm) {  // the same stored values, row-major
             rc = vqa_launch_rows_to_rowmajor(ix->rows, first, count, ix->d_pad * elem_bytes(ix->dtype), ix->rows_rm, nullptr);
@@ -398,9 +410,9 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
             ix->d_pad8 = (d + 127) / 128 * 128;
             ix->rows8_bytes = (size_t)tiles * 256 * ix->d_pad8;
             const size_t qc = VQA_QUERY_TILE * sizeof(float);
-            if (hipMalloc(&ix->rows8, ix->rows8_bytes) != hipSuccess || hipMalloc((void**)&ix->tile_info, (size_t)tiles * 16) != hipSuccess ||
+            if (hipMalloc(&ix->rows8, ix->rows8_bytes) != hipSuccess || hipMalloc((void**)&ix->tile_info, (size_t)tiles * 20) != hipSuccess ||
                 hipMalloc(&ix->q8_stage, (size_t)VQA_QUERY_TILE * ix->d_pad8) != hipSuccess ||
-                hipMalloc((void**)&ix->qrow, 3 * qc) != hipSuccess || hipMalloc((void**)&ix->qconst, 4 * qc) != hipSuccess ||
+                hipMalloc((void**)&ix->qrow, 5 * qc) != hipSuccess || hipMalloc((void**)&ix->qconst, kSketchQRows * qc) != hipSuccess ||
                 hipMalloc((void**)&ix->regions, (size_t)ix->max_grid * kSketchCap * 8) != hipSuccess ||
                 hipMalloc((void**)&ix->region_cnt, (size_t)ix->max_grid * 4) != hipSuccess ||
                 hipMalloc((void**)&ix->cand_keys, (size_t)VQA_QUERY_TILE * kSketchCap * sizeof(vqa_key)) != hipSuccess ||
@@ -418,16 +430,20 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
             if (const char* ro = getenv("VQA_SKETCH_ROTATE")) ix->rotate = ro[0] != '0';
             if (const char* ce = getenv("VQA_SKETCH_CENTER")) ix->center = ce[0] != '0';
             ix->center = ix->center && ix->rotate;
-            if (ix->center && (hipMalloc((void**)&ix->mu, (size_t)ix->d_pad8 * 4) != hipSuccess ||
+            ix->tile_c = ix->tile_info + (size_t)tiles * 4;
+            if (ix->center && (hipMalloc((void**)&ix->mu, (size_t)ix->d_pad8 * 8) != hipSuccess ||
                                hipMalloc((void**)&ix->qoff, VQA_QUERY_TILE * 4) != hipSuccess ||
-                               hipMemset(ix->mu, 0, (size_t)ix->d_pad8 * 4) != hipSuccess)) {
+                               hipMemset(ix->mu, 0, (size_t)ix->d_pad8 * 8) != hipSuccess)) {
                 vqa_set_error("vqa_index_create: allocating the sketch's centre failed");
                 rc = VQA_ENOMEM;
                 break;
             }
+            if (const char* sp = getenv("VQA_SKETCH_SPLIT")) ix->split = sp[0] != '0';
+            ix->split = ix->split && ix->center;
+            if (ix->split) ix->wdir = ix->mu + ix->d_pad8;
             if (const char* cd = getenv("VQA_SKETCH_COOLDOWN")) ix->sketch_cooldown_len = atoi(cd) > 0 ? atoi(cd) : 0;
             ix->sketch_cooldown_cur = ix->sketch_cooldown_len;
-            if (hipMemset(ix->rows8, 0, ix->rows8_bytes) != hipSuccess || hipMemset(ix->tile_info, 0, (size_t)tiles * 16) != hipSuccess ||
+            if (hipMemset(ix->rows8, 0, ix->rows8_bytes) != hipSuccess || hipMemset(ix->tile_info, 0, (size_t)tiles * 20) != hipSuccess ||
                 hipMemset(ix->sketch_flag, 0, 3 * sizeof(int)) != hipSuccess ||
                 hipMemset(ix->q8_stage, 0, (size_t)VQA_QUERY_TILE * ix->d_pad8) != hipSuccess) {
                 vqa_set_error("vqa_index_create: clearing the int8 sketch failed");
@@ -470,8 +486,8 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
             (void)hipMemset(ix->thr_seed, byte, VQA_QUERY_TILE * sizeof(float));
             (void)hipMemset(ix->upper, byte, VQA_QUERY_TILE * sizeof(vqa_key));
             if (ix->sketch) {
-                (void)hipMemset(ix->qrow, byte, 3 * VQA_QUERY_TILE * sizeof(float));
-                (void)hipMemset(ix->qconst, byte, 4 * VQA_QUERY_TILE * sizeof(float));
+                (void)hipMemset(ix->qrow, byte, 5 * VQA_QUERY_TILE * sizeof(float));
+                (void)hipMemset(ix->qconst, byte, kSketchQRows * VQA_QUERY_TILE * sizeof(float));
                 (void)hipMemset(ix->regions, byte, (size_t)ix->max_grid * kSketchCap * 8);
                 (void)hipMemset(ix->region_cnt, byte, (size_t)ix->max_grid * 4);
                 (void)hipMemset(ix->cand_keys, byte, (size_t)VQA_QUERY_TILE * kSketchCap * sizeof(vqa_key));
@@ -714,6 +730,10 @@ static MergeSketchTail qconst_tail(const vqa_index* ix, int clear) {
     t.qlo = ix->qrow + VQA_QUERY_TILE;
     t.qnorm = ix->qrow + 2 * VQA_QUERY_TILE;
     t.qoff = ix->center ? ix->qoff : nullptr;
+    if (ix->wdir) {
+        t.qalpha = ix->qrow + 3 * VQA_QUERY_TILE;
+        t.qrnorm = ix->qrow + 4 * VQA_QUERY_TILE;
+    }
     t.fp_margin = vqa_sketch_fp_margin(ix->d_pad, ix->rotate);
     t.mu_norm = ix->mu_norm;
     t.cand_cnt = ix->cand_cnt;
@@ -729,11 +749,13 @@ static int sketch_scan_rescore(vqa_index* ix, const LaunchPlan& p, const float* 
     int rc = VQA_OK;
     if (thr)
         rc = vqa_launch_sketch_qconst(thr, ix->qrow, ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, ix->d_pad, ix->qconst,
-                                      ix->cand_cnt, ix->sketch_flag, clear, seq, ix->rotate, ix->center ? ix->qoff : nullptr, ix->mu_norm, stream);
+                                      ix->cand_cnt, ix->sketch_flag, clear, seq, ix->rotate, ix->center ? ix->qoff : nullptr, ix->mu_norm, stream,
+                                      ix->wdir ? ix->qrow + 3 * VQA_QUERY_TILE : nullptr, ix->wdir ? ix->qrow + 4 * VQA_QUERY_TILE : nullptr);
     if (rc != VQA_OK) return rc;
     SketchScanArgs sk;
     sk.tile_info = reinterpret_cast<const float4*>(ix->tile_info);
     sk.qconst = ix->qconst;
+    sk.tile_c = ix->wdir ? ix->tile_c : nullptr;
     sk.regions = ix->regions;
     sk.counts = ix->region_cnt;
     sk.overflow = ix->sketch_flag;
@@ -844,9 +866,13 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             qr.scale = ix->scale;
             qr.stage = ix->q_stage;
             qr.rowmajor = ix->q_rm;
+            SketchSplit sp;  // + |alpha|, ||z_r||: the query's share of the split slack term
+            sp.wdir = ix->wdir;
+            sp.row_alpha = ix->qrow + 3 * VQA_QUERY_TILE;
+            sp.row_rnorm = ix->qrow + 4 * VQA_QUERY_TILE;
             rc = vqa_launch_sketch_rows(nullptr, ix->dtype, 0, VQA_QUERY_TILE, ix->d_pad, ix->d_pad8, nullptr, ix->q8_stage, ix->qrow,
                                         ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, ix->rotate, ix->center ? ix->mu : nullptr,
-                                        false, ix->qoff, stream, &qr);
+                                        false, ix->qoff, stream, &qr, ix->wdir ? &sp : nullptr);
         } else {
             rc = vqa_launch_tile_rows(q_tile, q_dtype, 0, VQA_QUERY_TILE, nq, ix->d, ix->d_pad, ix->dtype, ix->scale, ix->q_stage, stream);
         }
@@ -1046,6 +1072,22 @@ extern "C" int vqa_index_get_sketch_tile(vqa_index* ix, int64_t tile, int8_t* ou
     if (out_mu_or_null) {
         if (ix->mu) VQA_HIP_CHECK(hipMemcpy(out_mu_or_null, ix->mu, (size_t)ix->d_pad8 * 4, hipMemcpyDeviceToHost));
         else memset(out_mu_or_null, 0, (size_t)ix->d_pad8 * 4);
+    }
+    return VQA_OK;
+}
+
+extern "C" int vqa_index_get_sketch_split(vqa_index* ix, int64_t tile, float* out_c, float* out_w_or_null) {
+    VQA_REQUIRE(ix && out_c, "vqa_index_get_sketch_split: null pointer");
+    VQA_REQUIRE(ix->sketch, "vqa_index_get_sketch_split: the shard keeps no sketch");
+    const int64_t tiles = (ix->n + 255) / 256;
+    VQA_REQUIRE(tile >= 0 && tile < tiles, "vqa_index_get_sketch_split: tile %lld outside [0, %lld)", (long long)tile, (long long)tiles);
+    DeviceGuard guard(ix->device);
+    VQA_HIP_CHECK(hipDeviceSynchronize());
+    if (ix->wdir) VQA_HIP_CHECK(hipMemcpy(out_c, ix->tile_c + tile, 4, hipMemcpyDeviceToHost));
+    else *out_c = 0.f;
+    if (out_w_or_null) {
+        if (ix->wdir) VQA_HIP_CHECK(hipMemcpy(out_w_or_null, ix->wdir, (size_t)ix->d_pad8 * 4, hipMemcpyDeviceToHost));
+        else memset(out_w_or_null, 0, (size_t)ix->d_pad8 * 4);
     }
     return VQA_OK;
 }

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
                                                           float* __restrict__ row_scale, float* __restrict__ row_lo,
                                                           float* __restrict__ row_norm, unsigned* tile_max /* = tile_info */,
                                                           const float* __restrict__ mu, int center, float* __restrict__ row_off,
-                                                          QueryStage qs) {
+                                                          QueryStage qs, SketchSplit sp) {
     const int lane = threadIdx.x & 63;
     const long long ri = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ri >= count) return;
@@ -336,6 +336,46 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
         row_off[ri] = 0.f;
     }
     if constexpr (ROT) sketch_rotate<NG>(x, lane, units8 * 16);
+    // The slack term |z . x_lo| of the bound (z = the rotated query) is split along w = the shard's rotated, normalised centre:
+    // z = alpha w + z_r  =>  |z . x_lo| <= |alpha| |w . x_lo| + ||z_r|| ||x_lo||.  x_lo is a quantisation residue, nearly orthogonal to any
+    // fixed direction (|w . x_lo| ~ ||x_lo|| / sqrt(d)), while the queries of a corpus whose embeddings share a large common component
+    // are mostly alpha w (alpha ~ the mean cosine): the term shrinks from ||q|| ||x_lo|| to about ||z_r|| ||x_lo||.  The identity holds for
+    // ANY vector w and ANY number alpha as long as z_r is z - alpha w: nothing here has to be exact except that subtraction (its
+    // rounding, <= 2^-23 ||z|| ||x_lo||, rides in the margin).  Query rows report |alpha| and ||z_r||, index rows raise their tile's
+    // max |w . x_lo| (below, with the codes).
+    if (sp.wdir && !tile_info && (sp.row_alpha || sp.row_rnorm)) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < kMaxPer; ++i) {
+            const int u = lane + 64 * i;
+            if (u >= units8) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a = __builtin_fmaf(x[i][e], sp.wdir[16 * u + e], a);
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+        float r2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < kMaxPer; ++i) {
+            const int u = lane + 64 * i;
+            if (u >= units8) continue;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float zr = x[i][e] - a * sp.wdir[16 * u + e];
+                r2 += zr * zr;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) r2 += __shfl_xor(r2, off, 64);
+        if (lane == 0) {
+            const float up = 1.0f + 1.0f / 65536.0f;
+            float aa = fabsf(a) * up, rn = sqrtf(r2) * up;
+            if (!(aa < INFINITY)) aa = INFINITY;
+            if (!(rn < INFINITY)) rn = INFINITY;
+            if (sp.row_alpha) sp.row_alpha[ri] = aa;
+            if (sp.row_rnorm) sp.row_rnorm[ri] = rn;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < kMaxPer; ++i)
 #pragma unroll
@@ -346,7 +386,8 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
         for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
         s = amax > 0.f ? amax / 127.0f : 1.0f;
     }
-    float hi2 = 0.f, lo2 = 0.f, n2 = 0.f;
+    float hi2 = 0.f, lo2 = 0.f, n2 = 0.f, wl = 0.f;
+    const bool split = sp.wdir && sp.tile_c && tile_info;
 #pragma unroll
     for (int i = 0; i < kMaxPer; ++i) {
         const int u = lane + 64 * i;
@@ -364,6 +405,7 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
             hi2 += hi * hi;
             lo2 += lo * lo;
             n2 += x[i][e] * x[i][e];
+            if (split) wl = __builtin_fmaf(lo, sp.wdir[16 * u + e], wl);
         }
         *reinterpret_cast<uint4*>(out8 + tiled_unit(row, u >> 2, u & 3, KT8) * 16) = o.v;
     }
@@ -372,6 +414,7 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
         hi2 += __shfl_xor(hi2, off, 64);
         lo2 += __shfl_xor(lo2, off, 64);
         n2 += __shfl_xor(n2, off, 64);
+        wl += __shfl_xor(wl, off, 64);
     }
     if (lane == 0) {
         const float up = 1.0f + 1.0f / 65536.0f;
@@ -386,6 +429,11 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
         if (tile_max) {  // [tiles][4]: (max ||x_hi||, max ||x_lo||, 1 / scale, scale), read as float4 by the sketch scan
             atomicMax(tile_max + 4 * (row >> 8), __builtin_bit_cast(unsigned, hi));
             atomicMax(tile_max + 4 * (row >> 8) + 1, __builtin_bit_cast(unsigned, lo));
+            if (split) {  // |w . x_lo| of this row, rounded up: the fp32 dot errs by at most gamma_d ||x_lo|| ||w||, ||w|| <= 1 + 1e-6
+                float c = (fabsf(wl) + (float)(units8 * 16) * 1.3e-7f * lo) * up;
+                if (!(c < INFINITY)) c = INFINITY;
+                atomicMax(reinterpret_cast<unsigned*>(sp.tile_c) + (row >> 8), __builtin_bit_cast(unsigned, c));
+            }
         }
     }
 }
@@ -394,7 +442,8 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
 // with its reciprocal to tile_info[tile] = (0, 0, 1 / scale, scale) -- the two maxima are cleared for sketch_rows_kernel to fill
 template <typename SRC, bool ROT, int NG>
 __global__ __launch_bounds__(256) void tile_scale_kernel(const SRC* __restrict__ tiled, long long tile0, int KTS, int KT8,
-                                                         float* __restrict__ tile_info, const float* __restrict__ mu) {
+                                                         float* __restrict__ tile_info, const float* __restrict__ mu,
+                                                         float* __restrict__ tile_c) {
     constexpr int EPU = 16 / (int)sizeof(SRC);
     __shared__ float red[4];
     const long long tile = tile0 + blockIdx.x;
@@ -446,6 +495,36 @@ __global__ __launch_bounds__(256) void tile_scale_kernel(const SRC* __restrict__
         o[1] = 0.f;
         o[2] = 1.0f / s;
         o[3] = s;
+        if (tile_c) tile_c[tile] = 0.f;
+    }
+}
+
+// w = T mu / ||T mu|| (zeros when the centre is zero): the direction the slack term of the bound is split along (sketch_rows_kernel); one wave
+template <bool ROT, int NG>
+__global__ __launch_bounds__(64) void center_dir_kernel(const float* __restrict__ mu, int units8, float* __restrict__ wdir) {
+    const int lane = threadIdx.x;
+    float x[NG][16];
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int u = lane + 64 * i;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x[i][e] = u < units8 ? mu[16 * u + e] : 0.f;
+    }
+    if constexpr (ROT) sketch_rotate<NG>(x, lane, units8 * 16);
+    float n2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NG; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) n2 += x[i][e] * x[i][e];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) n2 += __shfl_xor(n2, off, 64);
+    const float inv = n2 > 1e-30f && n2 < INFINITY ? rsqrtf(n2) : 0.f;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+        const int u = lane + 64 * i;
+        if (u >= units8) continue;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) wdir[16 * u + e] = x[i][e] * inv;
     }
 }
 
@@ -563,8 +642,9 @@ extern "C" int vqa_normalize_convert(const float* rows, int64_t n, int32_t d, in
 
 int vqa_launch_sketch_rows(const void* tiled, int32_t src_dtype, int64_t first, int64_t count, int32_t d_pad_src, int32_t d_pad8,
                            const float* tile_info, void* out8, float* row_scale, float* row_lo, float* row_norm, bool rotate,
-                           const float* mu, bool center, float* row_off, hipStream_t stream, const VqaQueryRows* qr) {
+                           const float* mu, bool center, float* row_off, hipStream_t stream, const VqaQueryRows* qr, const SketchSplit* split) {
     if (count == 0) return VQA_OK;
+    const SketchSplit sp = split ? *split : SketchSplit();
     QueryStage qs;
     if (qr) {
         VQA_REQUIRE(qr->rows && qr->stage && (qr->src_dtype == VQA_F32 || qr->src_dtype == VQA_F16) && first == 0 && count == VQA_QUERY_TILE,
@@ -584,7 +664,7 @@ int vqa_launch_sketch_rows(const void* tiled, int32_t src_dtype, int64_t first, 
 #define VQA_SKROWS_NG(T, ROT, NGV, KTSV)                                                                                          \
     hipLaunchKernelGGL((sketch_rows_kernel<T, ROT, NGV>), grid, dim3(256), 0, stream, reinterpret_cast<const T*>(tiled), (long long)first, \
                        (long long)count, KTSV, d_pad8 / 64, tile_info, reinterpret_cast<int8_t*>(out8), row_scale, row_lo, row_norm, tmax, mu,  \
-                       center ? 1 : 0, row_off, qs)
+                       center ? 1 : 0, row_off, qs, sp)
 #define VQA_SKROWS(T, ROT, KTSV)                                                                                                  \
     do {                                                                                                                          \
         if (d_pad8 <= 1024) VQA_SKROWS_NG(T, ROT, 1, KTSV);                                                                       \
@@ -606,12 +686,12 @@ int vqa_launch_sketch_rows(const void* tiled, int32_t src_dtype, int64_t first, 
 }
 
 int vqa_launch_tile_scales(const void* tiled, int32_t src_dtype, int64_t tile0, int64_t ntiles, int32_t d_pad_src, int32_t d_pad8,
-                           float* tile_info, bool rotate, const float* mu, hipStream_t stream) {
+                           float* tile_info, bool rotate, const float* mu, hipStream_t stream, float* tile_c) {
     if (ntiles == 0) return VQA_OK;
     VQA_REQUIRE(rotate || !mu, "tile_scales: a centre needs the rotated form");
 #define VQA_TSCALE_NG(T, ROT, NGV, KTSV)                                                                                       \
     hipLaunchKernelGGL((tile_scale_kernel<T, ROT, NGV>), dim3((unsigned)ntiles), dim3(256), 0, stream, reinterpret_cast<const T*>(tiled), \
-                       (long long)tile0, KTSV, d_pad8 / 64, tile_info, mu)
+                       (long long)tile0, KTSV, d_pad8 / 64, tile_info, mu, tile_c)
 #define VQA_TSCALE(T, ROT, KTSV)                                                                                               \
     do {                                                                                                                       \
         if (d_pad8 <= 1024) VQA_TSCALE_NG(T, ROT, 1, KTSV);                                                                    \
@@ -628,6 +708,23 @@ int vqa_launch_tile_scales(const void* tiled, int32_t src_dtype, int64_t tile0, 
     }
 #undef VQA_TSCALE
 #undef VQA_TSCALE_NG
+    VQA_HIP_CHECK(hipGetLastError());
+    return VQA_OK;
+}
+
+int vqa_launch_center_dir(const float* mu, int32_t d_pad8, bool rotate, float* wdir, hipStream_t stream) {
+    VQA_REQUIRE(mu && wdir && d_pad8 % 16 == 0 && d_pad8 / 16 <= 8 * 64, "center_dir: bad arguments");
+    const int units8 = d_pad8 / 16;
+#define VQA_CDIR(ROT)                                                                                                        \
+    do {                                                                                                                     \
+        if (d_pad8 <= 1024) hipLaunchKernelGGL((center_dir_kernel<ROT, 1>), dim3(1), dim3(64), 0, stream, mu, units8, wdir);   \
+        else if (d_pad8 <= 2048) hipLaunchKernelGGL((center_dir_kernel<ROT, 2>), dim3(1), dim3(64), 0, stream, mu, units8, wdir); \
+        else if (d_pad8 <= 4096) hipLaunchKernelGGL((center_dir_kernel<ROT, 4>), dim3(1), dim3(64), 0, stream, mu, units8, wdir); \
+        else hipLaunchKernelGGL((center_dir_kernel<ROT, 8>), dim3(1), dim3(64), 0, stream, mu, units8, wdir);                   \
+    } while (0)
+    if (rotate) VQA_CDIR(true);
+    else VQA_CDIR(false);
+#undef VQA_CDIR
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

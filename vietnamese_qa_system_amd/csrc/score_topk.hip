@@ -180,8 +180,8 @@ static_assert(kPipeBytes <= 144 * 1024, "ring sizes");
 // pipe sits at the rate the chip's power management allows.  The five-stage ring (LOOP 1) stays the default;
 // its spare LDS holds the tile maxima of up to kSketchMaxTiles tiles per workgroup (80M-row shards).
 constexpr int kSketchPipe6 = (6 + 3) * kOperandBytes;
-constexpr int kSketchMaxTiles = (kLdsTotal - kPipeBytes - 4 * kQ * 4 - 16) / 16;  // tiles per workgroup of a sketch scan (LDS: 16 B each)
-constexpr int kSketchMaxTiles6 = (kLdsTotal - kSketchPipe6 - 4 * kQ * 4 - 16) / 16;
+constexpr int kSketchMaxTiles = (kLdsTotal - kPipeBytes - kSketchQRows * kQ * 4 - 16) / 16;  // tiles per workgroup of a sketch scan (LDS: 16 B each)
+constexpr int kSketchMaxTiles6 = (kLdsTotal - kSketchPipe6 - kSketchQRows * kQ * 4 - 16) / 16;
 constexpr int kOverBit = 1 << 30;  // "an append was refused" flag, kept in bit 30 of cnt[0] (LDS is fully used)
 constexpr int kCntMask = 0xFFFFFF;
 
@@ -400,8 +400,8 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     // MODE 2 (sketch scan): per query theta, ||q_lo||, ||q||, 1 / (s_q s_x) in the list area (4 KiB) + one append counter
     constexpr int kSxSlot = (MODE == 2 && LOOP == 0) ? 6 : 5;                 // X ring stages of the slot loop
     constexpr int kSkPipe = (kSxSlot + 3) * kOperandBytes;                    // MODE 2: where the rings end
-    float* const sk_q = reinterpret_cast<float*>(smem + kSkPipe);          // [4][256]
-    int* const sk_cnt = reinterpret_cast<int*>(smem + kSkPipe + 4 * kQ * 4);
+    float* const sk_q = reinterpret_cast<float*>(smem + kSkPipe);          // [kSketchQRows][256]
+    int* const sk_cnt = reinterpret_cast<int*>(smem + kSkPipe + kSketchQRows * kQ * 4);
     if (MODE == 2) {
         if (tid < kQ) {
             // queries past the batch never produce a candidate: theta = +inf and benign factors (the rows of qconst past nq are
@@ -412,6 +412,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
             sk_q[kQ + tid] = live ? sk.qconst[kQ + tid] : 0.f;
             sk_q[2 * kQ + tid] = live ? sk.qconst[2 * kQ + tid] : 0.f;
             sk_q[3 * kQ + tid] = live ? sk.qconst[3 * kQ + tid] : 1.f;
+            sk_q[4 * kQ + tid] = live ? sk.qconst[4 * kQ + tid] : 0.f;
         }
         if (tid == 0) *sk_cnt = 0;
     }
@@ -420,9 +421,13 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     const int ntile = first_tile < tile_end ? (tile_end - first_tile + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     const int total = ntile * KT;  // K-steps of this workgroup, numbered kappa = ti * KT + kt
     // MODE 2: (max ||x_hi||, max ||x_lo||, 1 / scale) of every tile this workgroup scans, in LDS (the launcher bounds ntile by kSketchMaxTiles)
-    float4* const sk_tm = reinterpret_cast<float4*>(smem + kSkPipe + 4 * kQ * 4 + 16);
+    float4* const sk_tm = reinterpret_cast<float4*>(smem + kSkPipe + kSketchQRows * kQ * 4 + 16);
     if (MODE == 2)
-        for (int t = tid; t < ntile; t += kThreads) sk_tm[t] = sk.tile_info[first_tile + t * (int)gridDim.x];
+        for (int t = tid; t < ntile; t += kThreads) {  // .w: max |w . x_lo| of the tile (the split slack term) in place of the scale, which the scan does not use
+            float4 ti = sk.tile_info[first_tile + t * (int)gridDim.x];
+            ti.w = sk.tile_c ? sk.tile_c[first_tile + t * (int)gridDim.x] : 0.f;
+            sk_tm[t] = ti;
+        }
 
     // ---- LDS-DMA.  X and Q are stored in the TILED layout (convert.hip): the slice of one tile and K-step is a
     // contiguous 16 KiB block that already is the swizzled LDS image.  vmcnt retires in issue order per wave, so the
@@ -696,7 +701,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     // compaction, no workgroup barrier.
     auto sketch_epilogue = [&](const f32x4 (&acc)[8][4], uint32_t row0, int ti) __attribute__((always_inline)) {
         const float4 tmax = sk_tm[ti];
-        const float a_hi = tmax.x, b_lo = tmax.y, inv_sx = tmax.z;
+        const float a_hi = tmax.x, b_lo = tmax.y, inv_sx = tmax.z, c_w = tmax.w;
         float T[4];
         int mi32[4];
 #pragma unroll
@@ -704,7 +709,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
             const int q = wn * 64 + ni * 16 + c;
             // (the fp32 summation error of the exact scores against the real-number dot product the bound speaks of rides in the two
             // per-query factors: sketch_qconst_kernel)
-            const float num = sk_q[q] - sk_q[kQ + q] * a_hi - sk_q[2 * kQ + q] * b_lo;
+            const float num = sk_q[q] - sk_q[kQ + q] * a_hi - sk_q[2 * kQ + q] * b_lo - sk_q[4 * kQ + q] * c_w;
             const float t = num * sk_q[3 * kQ + q] * inv_sx;
             T[ni] = t - fabsf(t) * 4e-6f - 0.5f;  // every rounding of this line errs towards MORE candidates; D is an integer
         }

@@ -143,12 +143,13 @@ __global__ __launch_bounds__(256) void rows_to_rowmajor_kernel(const uint4* __re
     for (int u = threadIdx.x & 63; u < KT * 4; u += 64) out[(size_t)r * (KT * 4) + u] = tiled[unit_of(r, u, KT)];
 }
 
-// per query: theta (the exact k-th best score of the first stage), ||q_lo||, ||q|| (1 + fp margin), 1 / s_q -> qconst [4][256]; clears the
-// candidate counters and the overflow flag of this search
+// per query: theta (the exact k-th best score of the first stage), ||q_lo||, ||z_r|| (+ fp margin), 1 / s_q, |alpha| -> qconst [5][256];
+// clears the candidate counters and the overflow flag of this search
 __global__ void sketch_qconst_kernel(const float* __restrict__ thr, const float* __restrict__ qscale, const float* __restrict__ qlo,
                                      const float* __restrict__ qnorm, float fp_margin, float* __restrict__ qconst,
                                      unsigned* __restrict__ cand_cnt, int* __restrict__ overflow, int clear, int seq,
-                                     const float* __restrict__ qoff, float mu_norm) {
+                                     const float* __restrict__ qoff, float mu_norm, const float* __restrict__ qalpha,
+                                     const float* __restrict__ qrnorm) {
     const int q = threadIdx.x;
     // a centred sketch bounds q . (x - mu): the threshold moves by q . mu (fp32 dot: its rounding and that of x - mu, <= 2 gamma_d
     // ||q|| ||mu||, err towards more candidates)
@@ -156,10 +157,12 @@ __global__ void sketch_qconst_kernel(const float* __restrict__ thr, const float*
     // The scores a search returns -- and theta -- are fp32 sums, the bound speaks of the real-number dot product: both differ
     // from it by at most gamma_d ||q|| ||x|| (d terms, unit roundoff 2^-24 per fma; for the MFMA's internal order as well),
     // ||x|| <= ||x_hi|| + ||x_lo||.  fp_margin = 2 gamma_d rides on BOTH slack terms: ||q_lo|| A + ||q|| B + fp_margin ||q|| (A + B)
-    // = (||q_lo|| + fp_margin ||q||) A + ||q|| (1 + fp_margin) B.
+    // = (||q_lo|| + fp_margin ||q||) A + (||q|| + fp_margin ||q||) B.  With the slack term split along the centre direction (convert.hip
+    // sketch_rows_kernel: z = alpha w + z_r) the B term reads |alpha| C + (||z_r|| + fp_margin ||q||) B, C = max_tile |w . x_lo|.
     qconst[256 + q] = qlo[q] + fp_margin * qnorm[q];
-    qconst[512 + q] = qnorm[q] * (1.0f + fp_margin);
+    qconst[512 + q] = (qrnorm ? qrnorm[q] : qnorm[q]) + fp_margin * qnorm[q];
     qconst[768 + q] = 1.0f / qscale[q];
+    qconst[1024 + q] = qalpha ? qalpha[q] : 0.f;
     if (clear) {  // (the second scan of a cascade keeps what the first one found)
 #pragma unroll
         for (int j = 0; j < kSketchSubLists; ++j) cand_cnt[(size_t)(q * kSketchSubLists + j) * kSketchCntStride] = 0u;
@@ -183,10 +186,10 @@ float vqa_sketch_fp_margin(int32_t d, bool rotated) {
 
 int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float* qlo, const float* qnorm, int32_t d, float* qconst,
                              unsigned* cand_cnt, int* overflow, int clear, int seq, bool rotated, const float* qoff, float mu_norm,
-                             hipStream_t stream) {
+                             hipStream_t stream, const float* qalpha, const float* qrnorm) {
     const float fp_margin = vqa_sketch_fp_margin(d, rotated);
     hipLaunchKernelGGL(sketch_qconst_kernel, dim3(1), dim3(256), 0, stream, thr, qscale, qlo, qnorm, fp_margin, qconst, cand_cnt, overflow, clear, seq, qoff,
-                       mu_norm);
+                       mu_norm, qalpha, qrnorm);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

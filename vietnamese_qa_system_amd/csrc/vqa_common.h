@@ -78,9 +78,11 @@ constexpr int kSketchSubLists = 16;
 // counters packed into 128 lines still took ~1700 appends per line of a 10M-row search
 constexpr int kSketchCntStride = 32;
 
+constexpr int kSketchQRows = 5;  // per-query constants of a sketch scan
 struct SketchScanArgs {
     const float4* tile_info = nullptr;  // [tiles] (max ||x_hi||, max ||x_lo||, 1 / scale, scale) of every 256-row tile of the sketch
-    const float* qconst = nullptr;      // [4][256]: theta (exact lower bound of the k-th best score), ||q_lo||, ||q||, 1 / s_q
+    const float* qconst = nullptr;      // [kSketchQRows][256]: theta (exact lower bound of the k-th best score), ||q_lo||, ||z_r||, 1 / s_q, |alpha|
+    const float* tile_c = nullptr;      // [tiles] max |w . x_lo| of every tile (the split slack term, convert.hip) or nullptr (taken as 0)
     unsigned long long* regions = nullptr;  // [grid][cap] candidate (query << 32 | row position) pairs, one region per workgroup
     unsigned* counts = nullptr;         // [grid] pairs written per region
     int* overflow = nullptr;            // set when a region filled up: the caller's exact fallback scan runs
@@ -126,6 +128,7 @@ int vqa_score_topk_sketch_max_tiles();  // tiles one workgroup of the sketch sca
 struct MergeSketchTail {
     float* qconst = nullptr;
     const float *qscale = nullptr, *qlo = nullptr, *qnorm = nullptr, *qoff = nullptr;
+    const float *qalpha = nullptr, *qrnorm = nullptr;  // the split slack term: |alpha|, ||z_r|| per query (nullptr: 0, ||q||)
     float fp_margin = 0.f, mu_norm = 0.f;
     unsigned* cand_cnt = nullptr;
     int* overflow = nullptr;
@@ -173,6 +176,14 @@ int vqa_launch_untile_rows(const void* tiled, int64_t first, int64_t count, int3
 // maxima; null (the query tile) -> every row its own max|x| / 127, with per-row scale / ||x_lo|| / ||x|| outputs
 // the query tile of a search, staged AND sketched by one launch (vqa_launch_sketch_rows with `qr`): the caller's row-major rows ->
 // storage type -> the TILED tile `stage` (+ its row-major copy) -> sketch of those stored values
+// The slack term |z . x_lo| split along w (convert.hip sketch_rows_kernel): index rows raise tile_c[tile] = max |w . x_lo|, query rows
+// report |alpha| = |z . w| and ||z - alpha w||
+struct SketchSplit {
+    const float* wdir = nullptr;  // [d_pad8] the shard's rotated, normalised centre (vqa_launch_center_dir) or nullptr: no split
+    float* tile_c = nullptr;      // [tiles], index rows
+    float* row_alpha = nullptr;   // [count], query rows
+    float* row_rnorm = nullptr;   // [count], query rows
+};
 struct VqaQueryRows {
     const void* rows = nullptr;  // [valid][d] row-major, device
     int32_t src_dtype = VQA_F16;  // VQA_F32 | VQA_F16
@@ -186,13 +197,16 @@ int vqa_launch_sketch_rows(const void* tiled, int32_t src_dtype, int64_t first, 
                            bool rotate /* sketch T x instead of x (convert.hip: sketch_rotate); rows and queries alike */,
                            const float* mu /* the shard's centre [d_pad8] or nullptr */, bool center /* index rows: sketch x - mu */,
                            float* row_off /* query rows: q . mu per row, or nullptr */, hipStream_t stream,
-                           const VqaQueryRows* qr = nullptr /* not null: the rows come from qr (first = 0, count = 256), `tiled` is unused */);
+                           const VqaQueryRows* qr = nullptr /* not null: the rows come from qr (first = 0, count = 256), `tiled` is unused */,
+                           const SketchSplit* split = nullptr);
+// w = T mu / ||T mu|| [d_pad8] (zeros for a zero centre)
+int vqa_launch_center_dir(const float* mu, int32_t d_pad8, bool rotate, float* wdir, hipStream_t stream);
 // mean of the `count` rows first, first + stride, first + 2 stride, ... of a TILED array -> mu [d_pad8]
 int vqa_launch_row_mean(const void* tiled, int32_t src_dtype, int64_t first, int64_t count, int64_t stride, int32_t d_pad_src, int32_t d_pad8,
                         float* mu, hipStream_t stream);
 // scale (= max |x| / 127) of tiles [tile0, tile0 + ntiles) of a TILED fp16 / fp32 array into tile_info; clears their two maxima
 int vqa_launch_tile_scales(const void* tiled, int32_t src_dtype, int64_t tile0, int64_t ntiles, int32_t d_pad_src, int32_t d_pad8,
-                           float* tile_info, bool rotate, const float* mu, hipStream_t stream);
+                           float* tile_info, bool rotate, const float* mu, hipStream_t stream, float* tile_c = nullptr /* cleared too */);
 // sketch search: per-query constants of the scan + reset of the candidate counters; exact scores of the candidate pairs
 int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float* qlo, const float* qnorm, int32_t d, float* qconst,
                              unsigned* cand_cnt, int* overflow /* [3]: this tile's flag, OR over the call's earlier tiles, seq */,
@@ -200,7 +214,8 @@ int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float*
                                           first); 2: the same for the first query tile of a call (overflow[1] = 0) */,
                              int seq /* written to overflow[2] when clearing: the call these flags belong to */,
                              bool rotated /* the sketch is of rotated rows: the rotation's rounding joins the margin */,
-                             const float* qoff /* q . mu per query or nullptr */, float mu_norm, hipStream_t stream);
+                             const float* qoff /* q . mu per query or nullptr */, float mu_norm, hipStream_t stream,
+                             const float* qalpha = nullptr, const float* qrnorm = nullptr /* the split slack term or nullptr: 0, ||q|| */);
 int vqa_launch_rescore(const unsigned long long* regions, const unsigned* counts, int cap, int nregions, const long long* stage_pos,
                        int nq, int k, const void* x, const void* x_rowmajor /* or nullptr: the tiled rows x are read */, const void* q,
                        const void* q_rowmajor /* the staged query tile, row-major (read with x_rowmajor) */, int32_t dtype, int32_t d_pad,

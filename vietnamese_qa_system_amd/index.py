@@ -250,6 +250,14 @@ class DeviceIndex:
                 "vqa_index_get_sketch_tile")
         return codes, info, mu
 
+    def sketch_split(self, tile: int) -> Tuple[float, np.ndarray]:
+        """(max |w . x_lo| of the tile, w [d8]): the split of the bound's slack term along the shard's rotated centre direction."""
+        d8 = (self.d + 127) // 128 * 128
+        c = np.zeros((1,), dtype=np.float32)
+        w = np.empty((d8,), dtype=np.float32)
+        N.check(self._lib.vqa_index_get_sketch_split(self._handle, int(tile), c.ctypes.data, w.ctypes.data), "vqa_index_get_sketch_split")
+        return float(c[0]), w
+
     def launch_info(self, b: int, k: int) -> N.LaunchInfo:
         info = N.LaunchInfo()
         N.check(self._lib.vqa_index_launch_info(self._handle, int(b), int(k), ctypes.byref(info)), "vqa_index_launch_info")
