@@ -121,10 +121,14 @@ int32_t vqa_index_sketch_state(const vqa_index* index);
  * (max ||x_hi||, max ||x_lo||, 1 / scale, scale) and, optionally, the shard's centre mu [d8] (zeros when the sketch is not centred):
  * what the bound of the sketch search is computed from, for tests that restate it independently.
  * vqa_index_get_sketch_split: the tile's max |w . x_lo| and, optionally, w [d8] -- the rotated, normalised centre along which the
- * bound's slack term |z . x_lo| is split into |alpha| |w . x_lo| + ||z - alpha w|| ||x_lo|| (zeros when the shard does not split). */
+ * bound's slack term |z . x_lo| is split into |alpha| |w . x_lo| + ||z - alpha w|| ||x_lo|| (zeros when the shard does not split).
+ * Shards whose rows collapse onto the centre direction (||mu|| >= 0.85 at the first fill: an untrained or strongly anisotropic
+ * encoder) take the PER-ROW form instead (*out_per_row = 1): rows and queries are projected off w before they are sketched, every row
+ * keeps beta = w . y (out_beta: the tile's 256 values; out_c: its max |beta|) and the scan adds alpha beta per (query, row). */
 int vqa_index_sketch_stats(vqa_index* index, int64_t* out /* [8] */);
 int vqa_index_get_sketch_tile(vqa_index* index, int64_t tile, int8_t* out_codes, float* out_info /* [4] */, float* out_mu_or_null);
-int vqa_index_get_sketch_split(vqa_index* index, int64_t tile, float* out_c /* [1] */, float* out_w_or_null /* [d8] */);
+int vqa_index_get_sketch_split(vqa_index* index, int64_t tile, float* out_c /* [1] */, float* out_w_or_null /* [d8] */,
+                               float* out_beta_or_null /* [256] */, int32_t* out_per_row_or_null);
 
 /* ---- search: replaces the scoring + top-k inside Embeddings.search / batchsearch (heavy_ranker.py:98,100) ---
  * q: [B, d] DEVICE pointer, element type q_dtype (VQA_F32 or VQA_F16; converted to the index storage type with

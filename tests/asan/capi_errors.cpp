@@ -63,7 +63,7 @@ int main() {
         float info4[4];
         EXPECT(vqa_index_sketch_stats(nullptr, st) == VQA_EINVAL);
         EXPECT(vqa_index_get_sketch_tile(nullptr, 0, codes, info4, nullptr) == VQA_EINVAL);
-        EXPECT(vqa_index_get_sketch_split(nullptr, 0, info4, nullptr) == VQA_EINVAL);
+        EXPECT(vqa_index_get_sketch_split(nullptr, 0, info4, nullptr, nullptr, nullptr) == VQA_EINVAL);
         EXPECT(vqa_index_sketch_state(nullptr) == -1 && vqa_index_device_bytes(nullptr) == -1);
     }
     EXPECT(vqa_index_set_timing(nullptr, 1) == VQA_EINVAL);

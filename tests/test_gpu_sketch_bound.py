@@ -175,6 +175,16 @@ def test_aligned_residues_at_the_thresholds_in_the_rotated_space(native_lib, mon
     assert p1[0].tolist() == best
 
 
+def _same_rows_outside_near_ties(s1, p1, ref, q, k):
+    """rows of (s1, p1) against the exact scan `ref` asked for k + 1 rows: equal wherever a rank's score is further than 2e-6 from
+    both neighbours of the exact list (the k-th against the (k+1)-th too); scores within 1e-6 everywhere"""
+    s0, p0 = _search(ref, q, k + 1)
+    assert np.abs(s1 - s0[:, :k]).max() < 1e-6
+    gap = np.minimum(np.abs(np.diff(s0, axis=1, prepend=np.inf)), np.abs(np.diff(s0, axis=1, append=-np.inf)))[:, :k]
+    clear = gap > 2e-6
+    assert clear.mean() > 0.8 and np.array_equal(p1[clear], p0[:, :k][clear]), (clear.mean(), int((p1 != p0[:, :k])[clear].sum()))
+
+
 @pytest.mark.parametrize("env,d", [({"VQA_SKETCH_ROTATE": "0"}, 200), ({}, 768), ({"VQA_SKETCH_CENTER": "0"}, 96)])
 def test_device_sketch_of_a_tile_dominates_the_true_residues(native_lib, monkeypatch, env, d):
     """codes, scale and the two maxima of a tile as the DEVICE holds them, against float64: with y = T (x - mu) (T, mu as the mode
@@ -218,7 +228,8 @@ def test_device_sketch_of_a_tile_dominates_the_true_residues(native_lib, monkeyp
         assert lo - slack <= info[1] <= (lo + slack) * 1.0001 + 1e-12, (lo, info[1])
         # the split of the slack term |z . x_lo| along w = T mu / ||T mu||: the tile's max |w . x_lo| must dominate the float64 value
         # (any w and any C >= max |w . x_lo| keep the bound valid: |z . x_lo| <= |alpha| C + ||z - alpha w|| ||x_lo|| for every alpha)
-        c, w = ske.sketch_split(tile)
+        c, w, _, per_row = ske.sketch_split(tile)
+        assert not per_row
         if centred:
             tw = t @ mu.astype(np.float64)
             assert np.abs(w - tw / np.linalg.norm(tw)).max() < 1e-5 and abs(np.linalg.norm(w.astype(np.float64)) - 1.0) < 1e-5
@@ -256,14 +267,10 @@ def test_split_slack_term_prunes_collapsed_embeddings_and_changes_no_result(nati
         pairs[name] = st["rescored_pairs"]
         ske.close()
         monkeypatch.delenv("VQA_SKETCH_SPLIT", raising=False)
-    ref = _index(x, monkeypatch, sketch=False)
-    s0, p0 = _search(ref, q.astype(np.float32), k)
-    ref.close()
     assert np.array_equal(res["split"][0], res["plain"][0]) and np.array_equal(res["split"][1], res["plain"][1])
-    assert np.abs(res["split"][0] - s0).max() < 1e-6  # re-scoring vs MFMA summation order, scores near 0.9
-    gap = np.minimum(np.abs(np.diff(s0, axis=1, prepend=np.inf)), np.abs(np.diff(s0, axis=1, append=-np.inf)))
-    clear = gap > 2e-6  # rows whose neighbours in the ranking are further away than the two arithmetics differ
-    assert clear.mean() > 0.9 and np.array_equal(res["split"][1][clear], p0[clear])
+    ref = _index(x, monkeypatch, sketch=False)
+    _same_rows_outside_near_ties(res["split"][0], res["split"][1], ref, q.astype(np.float32), k)  # re-scoring vs MFMA summation order
+    ref.close()
     assert pairs["split"] < 0.5 * pairs["plain"], pairs
 
 
@@ -443,3 +450,83 @@ def test_dirty_workspaces_and_a_partial_query_tile(native_lib, monkeypatch, patt
         assert np.array_equal(p1, p0) and np.abs(s1 - s0).max() <= 3e-7, b
     ref.close()
     ske.close()
+
+
+def _collapsed(n, b, d, weight, seed):
+    """unit rows sharing one large common component: mean cosine weight^2 / (1 + weight^2) (3.0: 0.9)"""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    c = torch.randn((1, d), generator=g, device="cuda")
+    c /= c.norm()
+
+    def draw(m):
+        v = torch.randn((m, d), generator=g, device="cuda")
+        v = weight * c + v / v.norm(dim=1, keepdim=True)
+        return (v / v.norm(dim=1, keepdim=True)).half().cpu().numpy()
+
+    return draw(n), draw(b)
+
+
+@pytest.mark.parametrize("pattern", ["", "0xCB"])
+def test_per_row_form_on_collapsed_embeddings(native_lib, monkeypatch, pattern):
+    """Rows collapsed onto their centre direction (mean cosine 0.9 >= 0.85) switch the shard to the per-row form at its first fill: rows
+    and queries are projected off w before they are sketched, the scan adds alpha beta per (query, row).  (a) what the device keeps
+    for a tile, against float64: beta = w . y, the codes / maxima are those of y - beta w, the tile's c >= max |beta| -- with these the
+    bound follows for every query by z . y = alpha (w . y) + z_r . y, z_r . y = beta (z_r . w) + z_r . y_r; (b) the search returns the
+    exact scan's rows with fewer candidates than the split form; 300 queries = a second, partial query tile; poisoned workspaces."""
+    n, d, b, k = 300_000, 768, 300, 10
+    x, q = _collapsed(n, b, d, 3.0, 91)
+    if pattern:
+        monkeypatch.setenv("VQA_POISON_WORKSPACE", pattern)
+    ske = _index(x, monkeypatch, sketch=True)
+    t = _rotation(d)
+    for tile in (0, 500, (n - 1) // 256):
+        codes, info, mu = ske.sketch_tile(tile)
+        c, w, beta, per_row = ske.sketch_split(tile)
+        assert per_row
+        rows = x[tile * 256:(tile + 1) * 256].astype(np.float64)
+        valid = rows.shape[0]
+        y = (rows - mu.astype(np.float64)) @ t.T
+        w64 = w.astype(np.float64)
+        assert np.abs(beta[:valid] - y @ w64).max() < 2e-6 and c >= np.abs(beta[:valid]).max()
+        yr = y - beta[:valid, None].astype(np.float64) * w64[None, :]  # with the DEVICE's beta: the identity y = beta w + y_r is what counts
+        s = float(info[3])
+        sc = s * codes[:valid].astype(np.float64)
+        slack = 14 * 2.0 ** -24 * np.linalg.norm(y, axis=1).max()
+        assert np.linalg.norm(sc, axis=1).max() <= info[0] * (1 + 1e-6)
+        assert np.linalg.norm(yr - sc, axis=1).max() <= info[1] + slack
+        assert np.abs(codes).max() <= 127 and np.linalg.norm(yr, axis=1).mean() < 0.5  # a third of the unit norm is left to sketch
+    s1, p1 = _search(ske, q.astype(np.float32), k)
+    st = ske.sketch_stats()
+    assert st["overflow"] == 0 and st["overflow_earlier_tiles"] == 0 and ske.sketch_state() == 0, st
+    pairs = st["rescored_pairs"]
+    ske.close()
+    monkeypatch.delenv("VQA_POISON_WORKSPACE", raising=False)
+    split = _index(x, monkeypatch, sketch=True, env={"VQA_SKETCH_PER_ROW": "0"})
+    assert not split.sketch_split(0)[3]
+    s2, p2 = _search(split, q.astype(np.float32), k)
+    pairs_split = split.sketch_stats()["rescored_pairs"]
+    split.close()
+    monkeypatch.delenv("VQA_SKETCH_PER_ROW", raising=False)
+    assert np.array_equal(s1, s2) and np.array_equal(p1, p2)  # both score the survivors with the same kernel
+    assert pairs < 0.6 * pairs_split, (pairs, pairs_split)
+    ref = _index(x, monkeypatch, sketch=False)
+    _same_rows_outside_near_ties(s1, p1, ref, q.astype(np.float32), k)
+    ref.close()
+
+
+def test_per_row_form_needs_six_k_steps(native_lib, monkeypatch):
+    """rows of fewer than six 64-element K-steps keep the split form however collapsed they are (the tile's betas land in LDS behind
+    the counted waits of K-steps 1-4)"""
+    n, d, b, k = 200_000, 256, 64, 10
+    x, q = _collapsed(n, b, d, 3.0, 92)
+    ske = _index(x, monkeypatch, sketch=True, env={"VQA_SKETCH_PER_ROW": "1"})
+    assert not ske.sketch_split(0)[3]
+    s1, p1 = _search(ske, q.astype(np.float32), k)
+    assert ske.sketch_stats()["overflow"] == 0
+    ske.close()
+    monkeypatch.delenv("VQA_SKETCH_PER_ROW", raising=False)
+    ref = _index(x, monkeypatch, sketch=False)
+    _same_rows_outside_near_ties(s1, p1, ref, q.astype(np.float32), k)
+    ref.close()
+

@@ -104,7 +104,7 @@ def load() -> ctypes.CDLL:
     lib.vqa_index_sketch_state.restype = c.c_int32
     lib.vqa_index_sketch_stats.argtypes = [c.c_void_p, c.POINTER(c.c_int64)]
     lib.vqa_index_get_sketch_tile.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p]
-    lib.vqa_index_get_sketch_split.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p]
+    lib.vqa_index_get_sketch_split.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]
     lib.vqa_index_search.argtypes = [c.c_void_p, c.c_void_p, c.c_int32, c.c_int32, c.c_int32, c.c_void_p, c.c_void_p,
                                      c.c_void_p, c.c_void_p]
     lib.vqa_merge_topk.argtypes = [c.c_void_p, c.c_void_p, c.c_int64, c.c_int64, c.c_int32, c.c_int32, c.c_int32, c.c_int32,

@@ -87,6 +87,10 @@ struct vqa_index {
     float* wdir = nullptr;                  // [d_pad8] (behind mu, same allocation) w = T mu / ||T mu||: the slack term |z . x_lo| of the bound is split
                                             // along it (convert.hip sketch_rows_kernel); VQA_SKETCH_SPLIT=0: not (dev / A-B switch)
     bool split = true;
+    float* beta = nullptr;                  // [tiles * 256] per-row form: beta = w . y of every row (the scan adds alpha beta per (query, row))
+    bool per_row = false;                   // decided with the centre, at the first fill: ||mu|| >= 0.85 (rows collapsed onto one direction;
+                                            // unit rows: the mean cosine to the centroid) and rows of >= 6 K-steps; VQA_SKETCH_PER_ROW=0 / 1 forces it
+    int per_row_env = -1;
     float* qoff = nullptr;                  // [256] q . mu of the query tile
     float mu_norm = 0.f;
     bool mu_set = false;
@@ -156,6 +160,7 @@ extern "C" void vqa_index_destroy(vqa_index* ix) {
         if (p) (void)hipFree(p);
     if (ix->rows_rm) (void)hipFree(ix->rows_rm);
     if (ix->mu) (void)hipFree(ix->mu);
+    if (ix->beta) (void)hipFree(ix->beta);
     if (ix->qoff) (void)hipFree(ix->qoff);
     if (ix->sketch_flag_host) (void)hipHostFree(ix->sketch_flag_host);
     if (ix->partial) (void)hipFree(ix->partial);
@@ -283,15 +288,19 @@ extern "C" int vqa_index_set_rows(vqa_index* ix, int64_t first, int64_t count, c
             if (ix->wdir) {
                 rcm = vqa_launch_center_dir(ix->mu, ix->d_pad8, ix->rotate, ix->wdir, nullptr);
                 if (rcm != VQA_OK) return rcm;
+                // rows collapsed onto the centre direction (an untrained / anisotropic encoder): the per-row form (convert.hip sketch_rows_kernel)
+                ix->per_row = ix->beta && (ix->per_row_env == 1 || (ix->per_row_env < 0 && n2 >= 0.85 * 0.85));
             }
         }
         int rc = vqa_launch_tile_scales(ix->rows, ix->dtype, t0, t1 - t0 + 1, ix->d_pad, ix->d_pad8, ix->tile_info, ix->rotate, ix->center ? ix->mu : nullptr, nullptr,
-                                        ix->tile_c);
+                                        ix->tile_c, ix->per_row ? ix->wdir : nullptr);
         if (rc != VQA_OK) return rc;
         const int64_t r0 = t0 * 256, r1 = std::min<int64_t>(ix->n, (t1 + 1) * 256);
         SketchSplit sp;
         sp.wdir = ix->wdir;
         sp.tile_c = ix->tile_c;
+        sp.per_row = ix->per_row ? 1 : 0;
+        sp.beta = ix->per_row ? ix->beta : nullptr;
         rc = vqa_launch_sketch_rows(ix->rows, ix->dtype, r0, r1 - r0, ix->d_pad, ix->d_pad8, ix->tile_info, ix->rows8, nullptr, nullptr,
                                     nullptr, ix->rotate, ix->center ? ix->mu : nullptr, true, nullptr, nullptr, nullptr, ix->wdir ? &sp : nullptr);
         if (rc != VQA_OK) return rc;
@@ -441,6 +450,13 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
             if (const char* sp = getenv("VQA_SKETCH_SPLIT")) ix->split = sp[0] != '0';
             ix->split = ix->split && ix->center;
             if (ix->split) ix->wdir = ix->mu + ix->d_pad8;
+            if (const char* pr = getenv("VQA_SKETCH_PER_ROW")) ix->per_row_env = pr[0] == '1' ? 1 : pr[0] == '0' ? 0 : -1;
+            if (ix->split && ix->d_pad8 / 64 >= 6 && ix->per_row_env != 0 &&
+                (hipMalloc((void**)&ix->beta, (size_t)tiles * 256 * 4) != hipSuccess || hipMemset(ix->beta, 0, (size_t)tiles * 256 * 4) != hipSuccess)) {
+                vqa_set_error("vqa_index_create: allocating the per-row betas failed");
+                rc = VQA_ENOMEM;
+                break;
+            }
             if (const char* cd = getenv("VQA_SKETCH_COOLDOWN")) ix->sketch_cooldown_len = atoi(cd) > 0 ? atoi(cd) : 0;
             ix->sketch_cooldown_cur = ix->sketch_cooldown_len;
             if (hipMemset(ix->rows8, 0, ix->rows8_bytes) != hipSuccess || hipMemset(ix->tile_info, 0, (size_t)tiles * 20) != hipSuccess ||
@@ -734,8 +750,8 @@ static MergeSketchTail qconst_tail(const vqa_index* ix, int clear) {
         t.qalpha = ix->qrow + 3 * VQA_QUERY_TILE;
         t.qrnorm = ix->qrow + 4 * VQA_QUERY_TILE;
     }
-    t.fp_margin = vqa_sketch_fp_margin(ix->d_pad, ix->rotate);
-    t.mu_norm = ix->mu_norm;
+    t.fp_margin = vqa_sketch_fp_margin(ix->d_pad, ix->rotate, ix->per_row);
+    t.mu_margin = 3e-7f * ix->mu_norm;
     t.cand_cnt = ix->cand_cnt;
     t.overflow = ix->sketch_flag;
     t.clear = clear;
@@ -749,13 +765,14 @@ static int sketch_scan_rescore(vqa_index* ix, const LaunchPlan& p, const float* 
     int rc = VQA_OK;
     if (thr)
         rc = vqa_launch_sketch_qconst(thr, ix->qrow, ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, ix->d_pad, ix->qconst,
-                                      ix->cand_cnt, ix->sketch_flag, clear, seq, ix->rotate, ix->center ? ix->qoff : nullptr, ix->mu_norm, stream,
-                                      ix->wdir ? ix->qrow + 3 * VQA_QUERY_TILE : nullptr, ix->wdir ? ix->qrow + 4 * VQA_QUERY_TILE : nullptr);
+                                      ix->cand_cnt, ix->sketch_flag, clear, seq, ix->rotate, ix->center ? ix->qoff : nullptr, 3e-7f * ix->mu_norm, stream,
+                                      ix->wdir ? ix->qrow + 3 * VQA_QUERY_TILE : nullptr, ix->wdir ? ix->qrow + 4 * VQA_QUERY_TILE : nullptr, ix->per_row);
     if (rc != VQA_OK) return rc;
     SketchScanArgs sk;
     sk.tile_info = reinterpret_cast<const float4*>(ix->tile_info);
     sk.qconst = ix->qconst;
     sk.tile_c = ix->wdir ? ix->tile_c : nullptr;
+    sk.beta = ix->per_row ? ix->beta : nullptr;
     sk.regions = ix->regions;
     sk.counts = ix->region_cnt;
     sk.overflow = ix->sketch_flag;
@@ -870,6 +887,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             sp.wdir = ix->wdir;
             sp.row_alpha = ix->qrow + 3 * VQA_QUERY_TILE;
             sp.row_rnorm = ix->qrow + 4 * VQA_QUERY_TILE;
+            sp.per_row = ix->per_row ? 1 : 0;
             rc = vqa_launch_sketch_rows(nullptr, ix->dtype, 0, VQA_QUERY_TILE, ix->d_pad, ix->d_pad8, nullptr, ix->q8_stage, ix->qrow,
                                         ix->qrow + VQA_QUERY_TILE, ix->qrow + 2 * VQA_QUERY_TILE, ix->rotate, ix->center ? ix->mu : nullptr,
                                         false, ix->qoff, stream, &qr, ix->wdir ? &sp : nullptr);
@@ -1076,7 +1094,8 @@ extern "C" int vqa_index_get_sketch_tile(vqa_index* ix, int64_t tile, int8_t* ou
     return VQA_OK;
 }
 
-extern "C" int vqa_index_get_sketch_split(vqa_index* ix, int64_t tile, float* out_c, float* out_w_or_null) {
+extern "C" int vqa_index_get_sketch_split(vqa_index* ix, int64_t tile, float* out_c, float* out_w_or_null, float* out_beta_or_null,
+                                          int32_t* out_per_row_or_null) {
     VQA_REQUIRE(ix && out_c, "vqa_index_get_sketch_split: null pointer");
     VQA_REQUIRE(ix->sketch, "vqa_index_get_sketch_split: the shard keeps no sketch");
     const int64_t tiles = (ix->n + 255) / 256;
@@ -1089,5 +1108,10 @@ extern "C" int vqa_index_get_sketch_split(vqa_index* ix, int64_t tile, float* ou
         if (ix->wdir) VQA_HIP_CHECK(hipMemcpy(out_w_or_null, ix->wdir, (size_t)ix->d_pad8 * 4, hipMemcpyDeviceToHost));
         else memset(out_w_or_null, 0, (size_t)ix->d_pad8 * 4);
     }
+    if (out_beta_or_null) {
+        if (ix->per_row) VQA_HIP_CHECK(hipMemcpy(out_beta_or_null, ix->beta + tile * 256, 256 * 4, hipMemcpyDeviceToHost));
+        else memset(out_beta_or_null, 0, 256 * 4);
+    }
+    if (out_per_row_or_null) *out_per_row_or_null = ix->per_row ? 1 : 0;
     return VQA_OK;
 }

@@ -315,7 +315,9 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
     }
     }
     if (mu) {
-        float dot = 0.f;
+        // q . mu in DOUBLE: the scan's threshold moves by it, and an fp32 dot of d terms errs by gamma_d ||q|| ||mu|| -- for embeddings
+        // collapsed onto their centre (||mu|| ~ 1) that alone was a third of the bound's slack.  768 fp64 fmas per query and search.
+        double dot = 0.0;
 #pragma unroll
         for (int i = 0; i < kMaxPer; ++i) {
             const int u = lane + 64 * i;
@@ -324,13 +326,13 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
             for (int e = 0; e < 16; ++e) {
                 const float m = mu[16 * u + e];
                 if (center) x[i][e] -= m;
-                else dot = __builtin_fmaf(x[i][e], m, dot);
+                else dot = __builtin_fma((double)x[i][e], (double)m, dot);
             }
         }
         if (!center) {
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) dot += __shfl_xor(dot, off, 64);
-            if (lane == 0 && row_off) row_off[ri] = dot;
+            if (lane == 0 && row_off) row_off[ri] = (float)dot;
         }
     } else if (lane == 0 && row_off) {
         row_off[ri] = 0.f;
@@ -343,7 +345,13 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
     // ANY vector w and ANY number alpha as long as z_r is z - alpha w: nothing here has to be exact except that subtraction (its
     // rounding, <= 2^-23 ||z|| ||x_lo||, rides in the margin).  Query rows report |alpha| and ||z_r||, index rows raise their tile's
     // max |w . x_lo| (below, with the codes).
-    if (sp.wdir && !tile_info && (sp.row_alpha || sp.row_rnorm)) {
+    // Per-row form (sp.per_row; shards whose embeddings collapse onto the centre direction, mean cosine >= 0.85): the rank-one part leaves
+    // the sketch altogether.  With y = beta w + y_r per row (beta = w . y) and z = alpha w + z_r per query,
+    //     z . y = alpha (w . y) + beta (z_r . w) + z_r . y_r,
+    // the sketch is cut from y_r and z_r -- a quarter of the norm, a quarter of the quantisation step --, the scan adds alpha beta per
+    // (query, row) in its epilogue (score_topk.hip LOOP 2) and beta (z_r . w), of the order of the rounding of alpha, rides in the margin.
+    float full2 = -1.f;  // ||z||^2 before a projection (the margins speak of the whole query)
+    if (sp.wdir && (sp.per_row || (!tile_info && (sp.row_alpha || sp.row_rnorm)))) {
         float a = 0.f;
 #pragma unroll
         for (int i = 0; i < kMaxPer; ++i) {
@@ -354,7 +362,8 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
-        float r2 = 0.f;
+        if (!(fabsf(a) < INFINITY)) a = 0.f;  // a row with NaN / Inf: no projection (its norms are infinite anyway)
+        float r2 = 0.f, f2 = 0.f;
 #pragma unroll
         for (int i = 0; i < kMaxPer; ++i) {
             const int u = lane + 64 * i;
@@ -363,17 +372,27 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
             for (int e = 0; e < 16; ++e) {
                 const float zr = x[i][e] - a * sp.wdir[16 * u + e];
                 r2 += zr * zr;
+                f2 += x[i][e] * x[i][e];
+                if (sp.per_row) x[i][e] = zr;
             }
         }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) r2 += __shfl_xor(r2, off, 64);
+        for (int off = 32; off >= 1; off >>= 1) {
+            r2 += __shfl_xor(r2, off, 64);
+            f2 += __shfl_xor(f2, off, 64);
+        }
+        if (sp.per_row) full2 = f2;
         if (lane == 0) {
             const float up = 1.0f + 1.0f / 65536.0f;
-            float aa = fabsf(a) * up, rn = sqrtf(r2) * up;
-            if (!(aa < INFINITY)) aa = INFINITY;
+            float aa = sp.per_row ? a : fabsf(a) * up, rn = sqrtf(r2) * up;
             if (!(rn < INFINITY)) rn = INFINITY;
-            if (sp.row_alpha) sp.row_alpha[ri] = aa;
-            if (sp.row_rnorm) sp.row_rnorm[ri] = rn;
+            if (!tile_info) {
+                if (sp.row_alpha) sp.row_alpha[ri] = aa;
+                if (sp.row_rnorm) sp.row_rnorm[ri] = rn;
+            } else if (sp.beta) {  // index rows: beta of the row, and the tile's max |beta| (a bound on ||y|| - ||y_r|| for the margins)
+                sp.beta[row] = a;
+                atomicMax(reinterpret_cast<unsigned*>(sp.tile_c) + (row >> 8), __builtin_bit_cast(unsigned, fabsf(a) * up));
+            }
         }
     }
 #pragma unroll
@@ -387,7 +406,7 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
         s = amax > 0.f ? amax / 127.0f : 1.0f;
     }
     float hi2 = 0.f, lo2 = 0.f, n2 = 0.f, wl = 0.f;
-    const bool split = sp.wdir && sp.tile_c && tile_info;
+    const bool split = sp.wdir && sp.tile_c && tile_info && !sp.per_row;
 #pragma unroll
     for (int i = 0; i < kMaxPer; ++i) {
         const int u = lane + 64 * i;
@@ -418,7 +437,7 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
     }
     if (lane == 0) {
         const float up = 1.0f + 1.0f / 65536.0f;
-        float hi = sqrtf(hi2) * up, lo = sqrtf(lo2) * up + 1e-30f, nn = sqrtf(n2) * up;
+        float hi = sqrtf(hi2) * up, lo = sqrtf(lo2) * up + 1e-30f, nn = sqrtf(full2 >= 0.f ? full2 : n2) * up;
         // a row holding NaN / Inf cannot be bounded: an infinite norm sends its whole tile (or query) to the candidates
         if (!(hi < INFINITY)) hi = INFINITY;
         if (!(lo < INFINITY)) lo = INFINITY;
@@ -443,7 +462,7 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
 template <typename SRC, bool ROT, int NG>
 __global__ __launch_bounds__(256) void tile_scale_kernel(const SRC* __restrict__ tiled, long long tile0, int KTS, int KT8,
                                                          float* __restrict__ tile_info, const float* __restrict__ mu,
-                                                         float* __restrict__ tile_c) {
+                                                         float* __restrict__ tile_c, const float* __restrict__ proj_w) {
     constexpr int EPU = 16 / (int)sizeof(SRC);
     __shared__ float red[4];
     const long long tile = tile0 + blockIdx.x;
@@ -470,6 +489,26 @@ __global__ __launch_bounds__(256) void tile_scale_kernel(const SRC* __restrict__
                 }
             }
             sketch_rotate<NG>(x, lane, units8 * 16);
+            if (proj_w) {  // per-row form: the sketch is cut from y - (w . y) w -- the same arithmetic, in the same order, as sketch_rows_kernel
+                float a = 0.f;
+#pragma unroll
+                for (int i = 0; i < NG; ++i) {
+                    const int u = lane + 64 * i;
+                    if (u >= units8) continue;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) a = __builtin_fmaf(x[i][e], proj_w[16 * u + e], a);
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) a += __shfl_xor(a, off, 64);
+                if (!(fabsf(a) < INFINITY)) a = 0.f;
+#pragma unroll
+                for (int i = 0; i < NG; ++i) {
+                    const int u = lane + 64 * i;
+                    if (u >= units8) continue;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) x[i][e] = x[i][e] - a * proj_w[16 * u + e];
+                }
+            }
 #pragma unroll
             for (int i = 0; i < NG; ++i)
 #pragma unroll
@@ -686,12 +725,13 @@ int vqa_launch_sketch_rows(const void* tiled, int32_t src_dtype, int64_t first, 
 }
 
 int vqa_launch_tile_scales(const void* tiled, int32_t src_dtype, int64_t tile0, int64_t ntiles, int32_t d_pad_src, int32_t d_pad8,
-                           float* tile_info, bool rotate, const float* mu, hipStream_t stream, float* tile_c) {
+                           float* tile_info, bool rotate, const float* mu, hipStream_t stream, float* tile_c, const float* proj_w) {
     if (ntiles == 0) return VQA_OK;
+    VQA_REQUIRE(rotate || !proj_w, "tile_scales: the per-row form needs the rotated, centred sketch");
     VQA_REQUIRE(rotate || !mu, "tile_scales: a centre needs the rotated form");
 #define VQA_TSCALE_NG(T, ROT, NGV, KTSV)                                                                                       \
     hipLaunchKernelGGL((tile_scale_kernel<T, ROT, NGV>), dim3((unsigned)ntiles), dim3(256), 0, stream, reinterpret_cast<const T*>(tiled), \
-                       (long long)tile0, KTSV, d_pad8 / 64, tile_info, mu, tile_c)
+                       (long long)tile0, KTSV, d_pad8 / 64, tile_info, mu, tile_c, proj_w)
 #define VQA_TSCALE(T, ROT, KTSV)                                                                                               \
     do {                                                                                                                       \
         if (d_pad8 <= 1024) VQA_TSCALE_NG(T, ROT, 1, KTSV);                                                                    \

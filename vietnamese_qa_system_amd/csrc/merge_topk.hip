@@ -160,11 +160,12 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
         const vqa_key kth = win[k - 1];
         const float thr = kth == 0ull ? -INFINITY : vqa_key_score(kth);
         const float qn = tail.qnorm[q];
-        tail.qconst[q] = tail.qoff ? thr - tail.qoff[q] - 2.0f * tail.fp_margin * qn * tail.mu_norm : thr;
+        tail.qconst[q] = tail.qoff ? thr - tail.qoff[q] - tail.mu_margin * qn : thr;
         tail.qconst[256 + q] = tail.qlo[q] + tail.fp_margin * qn;
         tail.qconst[512 + q] = (tail.qrnorm ? tail.qrnorm[q] : qn) + tail.fp_margin * qn;
         tail.qconst[768 + q] = 1.0f / tail.qscale[q];
         tail.qconst[1024 + q] = tail.qalpha ? tail.qalpha[q] : 0.f;
+        tail.qconst[1280 + q] = tail.fp_margin * qn;
     }
     if (tail.clear && tail.cand_cnt) {
         // the candidate counters of this query -- and, by block 0, of the queries past the batch and the overflow flags

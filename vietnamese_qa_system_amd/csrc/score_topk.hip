@@ -180,8 +180,9 @@ static_assert(kPipeBytes <= 144 * 1024, "ring sizes");
 // pipe sits at the rate the chip's power management allows.  The five-stage ring (LOOP 1) stays the default;
 // its spare LDS holds the tile maxima of up to kSketchMaxTiles tiles per workgroup (80M-row shards).
 constexpr int kSketchPipe6 = (6 + 3) * kOperandBytes;
-constexpr int kSketchMaxTiles = (kLdsTotal - kPipeBytes - kSketchQRows * kQ * 4 - 16) / 16;  // tiles per workgroup of a sketch scan (LDS: 16 B each)
-constexpr int kSketchMaxTiles6 = (kLdsTotal - kSketchPipe6 - kSketchQRows * kQ * 4 - 16) / 16;
+constexpr int kSketchBetaBytes = kTileRows * 4;  // LOOP 2: the per-row betas of the tile being scanned
+constexpr int kSketchMaxTiles = (kLdsTotal - kPipeBytes - kSketchQRows * kQ * 4 - 16 - kSketchBetaBytes) / 16;  // tiles per workgroup of a sketch scan (LDS: 16 B each)
+constexpr int kSketchMaxTiles6 = (kLdsTotal - kSketchPipe6 - kSketchQRows * kQ * 4 - 16 - kSketchBetaBytes) / 16;
 constexpr int kOverBit = 1 << 30;  // "an append was refused" flag, kept in bit 30 of cnt[0] (LDS is fully used)
 constexpr int kCntMask = 0xFFFFFF;
 
@@ -323,6 +324,20 @@ __device__ __forceinline__ void glds16x4(const void* sbase, uint32_t voff, uint3
     }
 }
 
+// one wave-instruction of LDS-DMA: 64 lanes x 16 B = 1 KiB at sbase + voff -> LDS lds_dst (the per-row betas of one tile, LOOP 2)
+__device__ __forceinline__ void glds16x1(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, %2\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(sbase), "s"(lds_dst)
+        : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -398,7 +413,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         L.cnt[tid] = 0;
     }
     // MODE 2 (sketch scan): per query theta, ||q_lo||, ||q||, 1 / (s_q s_x) in the list area (4 KiB) + one append counter
-    constexpr int kSxSlot = (MODE == 2 && LOOP == 0) ? 6 : 5;                 // X ring stages of the slot loop
+    constexpr int kSxSlot = (MODE == 2 && LOOP == 0) ? 6 : 5;                 // X ring stages of the slot loop (LOOP 2: five + the per-row betas)
     constexpr int kSkPipe = (kSxSlot + 3) * kOperandBytes;                    // MODE 2: where the rings end
     float* const sk_q = reinterpret_cast<float*>(smem + kSkPipe);          // [kSketchQRows][256]
     int* const sk_cnt = reinterpret_cast<int*>(smem + kSkPipe + kSketchQRows * kQ * 4);
@@ -413,6 +428,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
             sk_q[2 * kQ + tid] = live ? sk.qconst[2 * kQ + tid] : 0.f;
             sk_q[3 * kQ + tid] = live ? sk.qconst[3 * kQ + tid] : 1.f;
             sk_q[4 * kQ + tid] = live ? sk.qconst[4 * kQ + tid] : 0.f;
+            sk_q[5 * kQ + tid] = live ? sk.qconst[5 * kQ + tid] : 0.f;
         }
         if (tid == 0) *sk_cnt = 0;
     }
@@ -421,7 +437,9 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     const int ntile = first_tile < tile_end ? (tile_end - first_tile + (int)gridDim.x - 1) / (int)gridDim.x : 0;
     const int total = ntile * KT;  // K-steps of this workgroup, numbered kappa = ti * KT + kt
     // MODE 2: (max ||x_hi||, max ||x_lo||, 1 / scale) of every tile this workgroup scans, in LDS (the launcher bounds ntile by kSketchMaxTiles)
-    float4* const sk_tm = reinterpret_cast<float4*>(smem + kSkPipe + kSketchQRows * kQ * 4 + 16);
+    constexpr bool kBeta = MODE == 2 && LOOP == 2;  // per-row form: alpha beta added per (query, row) in the tile epilogue
+    float* const sk_beta = reinterpret_cast<float*>(smem + kSkPipe + kSketchQRows * kQ * 4 + 16);  // [256] betas of the current tile
+    float4* const sk_tm = reinterpret_cast<float4*>(smem + kSkPipe + kSketchQRows * kQ * 4 + 16 + kSketchBetaBytes);
     if (MODE == 2)
         for (int t = tid; t < ntile; t += kThreads) {  // .w: max |w . x_lo| of the tile (the split slack term) in place of the scale, which the scan does not use
             float4 ti = sk.tile_info[first_tile + t * (int)gridDim.x];
@@ -702,13 +720,57 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     auto sketch_epilogue = [&](const f32x4 (&acc)[8][4], uint32_t row0, int ti) __attribute__((always_inline)) {
         const float4 tmax = sk_tm[ti];
         const float a_hi = tmax.x, b_lo = tmax.y, inv_sx = tmax.z, c_w = tmax.w;
+        if constexpr (kBeta) {
+            // per-row form: the test is D + (alpha / (s_q s_t)) beta_row >= T, element by element (one cvt + one fma each).  One query
+            // column at a time and the betas of four rows at a time, so that next to nothing stays live beside the accumulators
+            // (the kernel sits at its 256 registers: hipcc spills ~90 of them otherwise).
+            const float* brow = sk_beta + wm * 128 + g * 4;
+            unsigned long long* region = sk.regions + (size_t)blockIdx.x * sk.cap;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int q = wn * 64 + ni * 16 + c;
+                const float num = sk_q[q] - sk_q[kQ + q] * a_hi - sk_q[2 * kQ + q] * b_lo - sk_q[5 * kQ + q] * c_w;  // c_w: the tile's max |beta|
+                const float inv = sk_q[3 * kQ + q] * inv_sx;
+                const float t = num * inv;
+                const float ab = sk_q[4 * kQ + q] * inv;  // alpha / (s_q s_t): D + ab beta is the bound's integer part
+                const float Tn = t - (fabsf(t) + fabsf(ab) * c_w) * 8e-6f - 1.0f;  // + the roundings of ab and of the fma below
+                float mx = -INFINITY;
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(brow + mi * 16);
+                    const i32x4 v = __builtin_bit_cast(i32x4, acc[mi][ni]);
+                    const float v0 = __builtin_fmaf(ab, b4.x, (float)v[0]), v1 = __builtin_fmaf(ab, b4.y, (float)v[1]);
+                    const float v2 = __builtin_fmaf(ab, b4.z, (float)v[2]), v3 = __builtin_fmaf(ab, b4.w, (float)v[3]);
+                    mx = fmaxf(mx, fmaxf(fmaxf(v0, v1), fmaxf(v2, v3)));
+                }
+                if (mx >= Tn) {
+                    const unsigned long long qhi = (unsigned long long)q << 32;
+#pragma unroll
+                    for (int mi = 0; mi < 8; ++mi) {
+                        const i32x4 v = __builtin_bit_cast(i32x4, acc[mi][ni]);
+                        const float4 b4 = *reinterpret_cast<const float4*>(brow + mi * 16);
+                        const float bj[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t pos = row0 + (uint32_t)(wm * 128 + mi * 16 + g * 4 + j);
+                            if (__builtin_fmaf(ab, bj[j], (float)v[j]) >= Tn && (long long)pos < N) {
+                                const int slot = atomicAdd(sk_cnt, 1);
+                                if (slot < sk.cap) region[slot] = qhi | pos;
+                            }
+                        }
+                    }
+                }
+                VQA_SB();
+            }
+            return;
+        }
         float T[4];
         int mi32[4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const int q = wn * 64 + ni * 16 + c;
-            // (the fp32 summation error of the exact scores against the real-number dot product the bound speaks of rides in the two
-            // per-query factors: sketch_qconst_kernel)
+            // (the fp32 summation error of the exact scores against the real-number dot product the bound speaks of rides in the
+            // per-query factors: sketch_qconst_kernel; c_w: the tile's max |w . x_lo| against |alpha|, the split slack term)
             const float num = sk_q[q] - sk_q[kQ + q] * a_hi - sk_q[2 * kQ + q] * b_lo - sk_q[4 * kQ + q] * c_w;
             const float t = num * sk_q[3 * kQ + q] * inv_sx;
             T[ni] = t - fabsf(t) * 4e-6f - 0.5f;  // every rounding of this line errs towards MORE candidates; D is an integer
@@ -996,6 +1058,13 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
             }                                                                                                        \
             if (MODE == 1 && LAST) owe = true;                                                                       \
             else issue();                                                                                            \
+            if constexpr (kBeta && FIRST) { /* the tile's 256 betas -> LDS: one more LDS-DMA piece of ONE wave.  It sits in that wave's */ \
+                /* in-order vmcnt stream behind this K-step's pieces: the counted waits of the next three K-steps become stricter by  */ \
+                /* one piece for it, never laxer, and the wait of K-step 4 covers it -- the epilogue reads it behind K-step KT - 1 >= 5 */ \
+                if (lw == 0)                                                                                         \
+                    glds16x1(sk.beta + ((size_t)first_tile + (size_t)ti * gridDim.x) * kTileRows, (uint32_t)lane * 16,  \
+                             smem_lds + (uint32_t)(reinterpret_cast<char*>(sk_beta) - smem));                        \
+            }                                                                                                        \
             VQA_STAMP(6);                                                                                            \
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
             if constexpr (!LAST) VQA_SLOT_MMA(0, kEarly);                                                            \
@@ -1258,14 +1327,19 @@ static int launch_sketch(const ScoreTopkArgs& a, int KT, int lds, hipStream_t st
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<2, VQA_I8_SKETCH, 1, 1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<2, VQA_I8_SKETCH, 0, 2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(score_topk_kernel<2, VQA_I8_SKETCH, 1, 2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         return VQA_OK;
     });
     if (rc != VQA_OK) return rc;
     // six X stages (LOOP 0) where the workgroup's tile maxima fit beside them, five (LOOP 1) for the largest shards
     const int per_wg = (a.tile_end - a.tile_begin + a.grid - 1) / a.grid;
     const bool six = a.loop != 1 && per_wg <= kSketchMaxTiles6;  // (a.loop == 0: VQA_SKETCH_SX=6 at index create, dev / A-B switch)
-    auto kern = six ? (a.first_stage ? score_topk_kernel<2, VQA_I8_SKETCH, 1, 0> : score_topk_kernel<2, VQA_I8_SKETCH, 0, 0>)
-                    : (a.first_stage ? score_topk_kernel<2, VQA_I8_SKETCH, 1, 1> : score_topk_kernel<2, VQA_I8_SKETCH, 0, 1>);
+    auto kern = a.sketch->beta ? (a.first_stage ? score_topk_kernel<2, VQA_I8_SKETCH, 1, 2> : score_topk_kernel<2, VQA_I8_SKETCH, 0, 2>)
+                : six          ? (a.first_stage ? score_topk_kernel<2, VQA_I8_SKETCH, 1, 0> : score_topk_kernel<2, VQA_I8_SKETCH, 0, 0>)
+                               : (a.first_stage ? score_topk_kernel<2, VQA_I8_SKETCH, 1, 1> : score_topk_kernel<2, VQA_I8_SKETCH, 0, 1>);
     hipLaunchKernelGGL(kern, dim3(a.grid), dim3(kThreads), lds, stream, a.x, a.q, nullptr, nullptr, nullptr, (long long)a.n, KT, a.nq, a.k,
                        a.tile_begin, a.tile_end, a.gate, a.grid, 0, 2, *a.sketch);
     VQA_HIP_CHECK(hipGetLastError());
@@ -1283,6 +1357,8 @@ int vqa_launch_score_topk(int dtype, const ScoreTopkArgs& a, hipStream_t stream)
                     (a.tile_end - a.tile_begin + a.grid - 1) / a.grid, kSketchMaxTiles);
         VQA_REQUIRE(a.sketch->tile_info && a.sketch->qconst && a.sketch->regions && a.sketch->counts && a.sketch->overflow && a.sketch->cap > 0,
                     "score_topk: incomplete sketch arguments");
+        VQA_REQUIRE(!a.sketch->beta || (a.sketch->tile_c && a.d_pad / kRowBytes >= 6),
+                    "score_topk: the per-row form needs the tiles' max |beta| and rows of at least six K-steps");
         return launch_sketch(a, a.d_pad / kRowBytes, vqa_score_topk_lds_bytes(dtype, a.k), stream);
     }
     VQA_REQUIRE(dtype == VQA_F16 || dtype == VQA_FP8_E4M3 || dtype == VQA_F32, "score_topk: storage type %d", dtype);

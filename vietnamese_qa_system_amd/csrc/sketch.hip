@@ -148,12 +148,12 @@ __global__ __launch_bounds__(256) void rows_to_rowmajor_kernel(const uint4* __re
 __global__ void sketch_qconst_kernel(const float* __restrict__ thr, const float* __restrict__ qscale, const float* __restrict__ qlo,
                                      const float* __restrict__ qnorm, float fp_margin, float* __restrict__ qconst,
                                      unsigned* __restrict__ cand_cnt, int* __restrict__ overflow, int clear, int seq,
-                                     const float* __restrict__ qoff, float mu_norm, const float* __restrict__ qalpha,
+                                     const float* __restrict__ qoff, float mu_margin, const float* __restrict__ qalpha,
                                      const float* __restrict__ qrnorm) {
     const int q = threadIdx.x;
-    // a centred sketch bounds q . (x - mu): the threshold moves by q . mu (fp32 dot: its rounding and that of x - mu, <= 2 gamma_d
-    // ||q|| ||mu||, err towards more candidates)
-    qconst[q] = qoff ? thr[q] - qoff[q] - 2.0f * fp_margin * qnorm[q] * mu_norm : thr[q];
+    // a centred sketch bounds q . (x - mu): the threshold moves by q . mu (an fp64 dot rounded once to fp32, and this subtraction:
+    // mu_margin = 3e-7 ||mu|| per unit of ||q||; the rounding of x - mu itself, 2^-24 ||x - mu||, rides in fp_margin)
+    qconst[q] = qoff ? thr[q] - qoff[q] - mu_margin * qnorm[q] : thr[q];
     // The scores a search returns -- and theta -- are fp32 sums, the bound speaks of the real-number dot product: both differ
     // from it by at most gamma_d ||q|| ||x|| (d terms, unit roundoff 2^-24 per fma; for the MFMA's internal order as well),
     // ||x|| <= ||x_hi|| + ||x_lo||.  fp_margin = 2 gamma_d rides on BOTH slack terms: ||q_lo|| A + ||q|| B + fp_margin ||q|| (A + B)
@@ -162,7 +162,8 @@ __global__ void sketch_qconst_kernel(const float* __restrict__ thr, const float*
     qconst[256 + q] = qlo[q] + fp_margin * qnorm[q];
     qconst[512 + q] = (qrnorm ? qrnorm[q] : qnorm[q]) + fp_margin * qnorm[q];
     qconst[768 + q] = 1.0f / qscale[q];
-    qconst[1024 + q] = qalpha ? qalpha[q] : 0.f;
+    qconst[1024 + q] = qalpha ? qalpha[q] : 0.f;  // |alpha| (split slack term) or the signed alpha (per-row form)
+    qconst[1280 + q] = fp_margin * qnorm[q];       // per-row form: the margin's factor on the tile's max |beta|
     if (clear) {  // (the second scan of a cascade keeps what the first one found)
 #pragma unroll
         for (int j = 0; j < kSketchSubLists; ++j) cand_cnt[(size_t)(q * kSketchSubLists + j) * kSketchCntStride] = 0u;
@@ -178,18 +179,21 @@ __global__ void sketch_qconst_kernel(const float* __restrict__ thr, const float*
 
 }  // namespace
 
-float vqa_sketch_fp_margin(int32_t d, bool rotated) {
+float vqa_sketch_fp_margin(int32_t d, bool rotated, bool per_row) {
     // 2 gamma_d with gamma_d <= d 2^-24 / (1 - d 2^-24) < 1.2e-7 d / 2 ... kept at twice that; a rotated sketch adds the rounding of
     // the two rotations (13 butterfly stages + the normalisation: 14 2^-24 per side, kept at twice that too)
-    return 2.0f * (float)d * 1.2e-7f + (rotated ? 4.0f * 14.0f * 6e-8f : 0.f);
+    // per-row form: beta = fl(w . y) (gamma_d ||y||, times |alpha| <= ||q||), the two element-wise projections (2^-23 each) and
+    // beta (z_r . w) with |z_r . w| <= (gamma_d + 3e-6) ||z|| stand between z . y = alpha beta + z_r . y_r and what the kernels compute:
+    // 2 gamma_d + 4e-6 more, on A + B and on the tile's max |beta| (qconst row 5) alike
+    return 2.0f * (float)d * 1.2e-7f + (rotated ? 4.0f * 14.0f * 6e-8f : 0.f) + (per_row ? (float)d * 1.2e-7f + 4e-6f : 0.f);
 }
 
 int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float* qlo, const float* qnorm, int32_t d, float* qconst,
-                             unsigned* cand_cnt, int* overflow, int clear, int seq, bool rotated, const float* qoff, float mu_norm,
-                             hipStream_t stream, const float* qalpha, const float* qrnorm) {
-    const float fp_margin = vqa_sketch_fp_margin(d, rotated);
+                             unsigned* cand_cnt, int* overflow, int clear, int seq, bool rotated, const float* qoff, float mu_margin,
+                             hipStream_t stream, const float* qalpha, const float* qrnorm, bool per_row) {
+    const float fp_margin = vqa_sketch_fp_margin(d, rotated, per_row);
     hipLaunchKernelGGL(sketch_qconst_kernel, dim3(1), dim3(256), 0, stream, thr, qscale, qlo, qnorm, fp_margin, qconst, cand_cnt, overflow, clear, seq, qoff,
-                       mu_norm, qalpha, qrnorm);
+                       mu_margin, qalpha, qrnorm);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

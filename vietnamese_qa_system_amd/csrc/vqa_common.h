@@ -78,11 +78,13 @@ constexpr int kSketchSubLists = 16;
 // counters packed into 128 lines still took ~1700 appends per line of a 10M-row search
 constexpr int kSketchCntStride = 32;
 
-constexpr int kSketchQRows = 5;  // per-query constants of a sketch scan
+constexpr int kSketchQRows = 6;  // per-query constants of a sketch scan
 struct SketchScanArgs {
     const float4* tile_info = nullptr;  // [tiles] (max ||x_hi||, max ||x_lo||, 1 / scale, scale) of every 256-row tile of the sketch
     const float* qconst = nullptr;      // [kSketchQRows][256]: theta (exact lower bound of the k-th best score), ||q_lo||, ||z_r||, 1 / s_q, |alpha|
-    const float* tile_c = nullptr;      // [tiles] max |w . x_lo| of every tile (the split slack term, convert.hip) or nullptr (taken as 0)
+    const float* tile_c = nullptr;      // [tiles] max |w . x_lo| of every tile (the split slack term, convert.hip) or nullptr (taken as 0);
+                                        // per-row form: max |beta| of the tile
+    const float* beta = nullptr;        // per-row form (LOOP 2): [tiles * 256] beta = w . y of every row; qconst row 4 = signed alpha, row 5 = margin factor
     unsigned long long* regions = nullptr;  // [grid][cap] candidate (query << 32 | row position) pairs, one region per workgroup
     unsigned* counts = nullptr;         // [grid] pairs written per region
     int* overflow = nullptr;            // set when a region filled up: the caller's exact fallback scan runs
@@ -129,7 +131,7 @@ struct MergeSketchTail {
     float* qconst = nullptr;
     const float *qscale = nullptr, *qlo = nullptr, *qnorm = nullptr, *qoff = nullptr;
     const float *qalpha = nullptr, *qrnorm = nullptr;  // the split slack term: |alpha|, ||z_r|| per query (nullptr: 0, ||q||)
-    float fp_margin = 0.f, mu_norm = 0.f;
+    float fp_margin = 0.f, mu_margin = 0.f;  // mu_margin: 3e-7 ||mu|| (the rounding of q . mu, an fp64 dot, and of theta - q . mu)
     unsigned* cand_cnt = nullptr;
     int* overflow = nullptr;
     int clear = 0, seq = 0;
@@ -138,7 +140,7 @@ struct MergeSketchTail {
                                        // theta1, the exact k-th best score of the first stage -- no key below it can be among the k best);
                                        // a list that still overflows the kernel's LDS raises overflow[0]: the search's exact fallback runs
 };
-float vqa_sketch_fp_margin(int32_t d, bool rotated);  // sketch.hip: the margin vqa_launch_sketch_qconst uses
+float vqa_sketch_fp_margin(int32_t d, bool rotated, bool per_row = false);  // sketch.hip: the margin vqa_launch_sketch_qconst uses
 
 // `parts` key lists of `list_len` keys per query ([parts][256][list_len], or query-major) -> the k best per query:
 // final [nq, k] (scores, external ids, positions) and/or the k-th best score per query (-inf when fewer exist)
@@ -183,6 +185,10 @@ struct SketchSplit {
     float* tile_c = nullptr;      // [tiles], index rows
     float* row_alpha = nullptr;   // [count], query rows
     float* row_rnorm = nullptr;   // [count], query rows
+    // per-row form: rows and queries are projected off w before they are sketched; index rows store beta = w . y (beta [tiles * 256],
+    // tile_c = max |beta|), query rows report the SIGNED alpha; the scan adds alpha beta per (query, row) (score_topk.hip LOOP 2)
+    int per_row = 0;
+    float* beta = nullptr;
 };
 struct VqaQueryRows {
     const void* rows = nullptr;  // [valid][d] row-major, device
@@ -206,7 +212,8 @@ int vqa_launch_row_mean(const void* tiled, int32_t src_dtype, int64_t first, int
                         float* mu, hipStream_t stream);
 // scale (= max |x| / 127) of tiles [tile0, tile0 + ntiles) of a TILED fp16 / fp32 array into tile_info; clears their two maxima
 int vqa_launch_tile_scales(const void* tiled, int32_t src_dtype, int64_t tile0, int64_t ntiles, int32_t d_pad_src, int32_t d_pad8,
-                           float* tile_info, bool rotate, const float* mu, hipStream_t stream, float* tile_c = nullptr /* cleared too */);
+                           float* tile_info, bool rotate, const float* mu, hipStream_t stream, float* tile_c = nullptr /* cleared too */,
+                           const float* proj_w = nullptr /* per-row form: the scale of y - (w . y) w */);
 // sketch search: per-query constants of the scan + reset of the candidate counters; exact scores of the candidate pairs
 int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float* qlo, const float* qnorm, int32_t d, float* qconst,
                              unsigned* cand_cnt, int* overflow /* [3]: this tile's flag, OR over the call's earlier tiles, seq */,
@@ -214,8 +221,9 @@ int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float*
                                           first); 2: the same for the first query tile of a call (overflow[1] = 0) */,
                              int seq /* written to overflow[2] when clearing: the call these flags belong to */,
                              bool rotated /* the sketch is of rotated rows: the rotation's rounding joins the margin */,
-                             const float* qoff /* q . mu per query or nullptr */, float mu_norm, hipStream_t stream,
-                             const float* qalpha = nullptr, const float* qrnorm = nullptr /* the split slack term or nullptr: 0, ||q|| */);
+                             const float* qoff /* q . mu per query or nullptr */, float mu_margin /* 3e-7 ||mu|| */, hipStream_t stream,
+                             const float* qalpha = nullptr, const float* qrnorm = nullptr /* the split slack term or nullptr: 0, ||q|| */,
+                             bool per_row = false);
 int vqa_launch_rescore(const unsigned long long* regions, const unsigned* counts, int cap, int nregions, const long long* stage_pos,
                        int nq, int k, const void* x, const void* x_rowmajor /* or nullptr: the tiled rows x are read */, const void* q,
                        const void* q_rowmajor /* the staged query tile, row-major (read with x_rowmajor) */, int32_t dtype, int32_t d_pad,

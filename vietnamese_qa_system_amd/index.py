@@ -250,13 +250,17 @@ class DeviceIndex:
                 "vqa_index_get_sketch_tile")
         return codes, info, mu
 
-    def sketch_split(self, tile: int) -> Tuple[float, np.ndarray]:
-        """(max |w . x_lo| of the tile, w [d8]): the split of the bound's slack term along the shard's rotated centre direction."""
+    def sketch_split(self, tile: int) -> Tuple[float, np.ndarray, np.ndarray, bool]:
+        """(c, w [d8], beta [256], per_row): the shard's rotated centre direction w and, split form, the tile's max |w . x_lo| -- or,
+        per-row form (rows collapsed onto w), the tile's max |beta| and its rows' beta = w . y (``include/vqa_retrieval.h``)."""
         d8 = (self.d + 127) // 128 * 128
         c = np.zeros((1,), dtype=np.float32)
         w = np.empty((d8,), dtype=np.float32)
-        N.check(self._lib.vqa_index_get_sketch_split(self._handle, int(tile), c.ctypes.data, w.ctypes.data), "vqa_index_get_sketch_split")
-        return float(c[0]), w
+        beta = np.empty((256,), dtype=np.float32)
+        per_row = ctypes.c_int32(0)
+        N.check(self._lib.vqa_index_get_sketch_split(self._handle, int(tile), c.ctypes.data, w.ctypes.data, beta.ctypes.data,
+                                                     ctypes.addressof(per_row)), "vqa_index_get_sketch_split")
+        return float(c[0]), w, beta, bool(per_row.value)
 
     def launch_info(self, b: int, k: int) -> N.LaunchInfo:
         info = N.LaunchInfo()
