@@ -688,6 +688,7 @@ def non_isotropic_legs(torch, np, device, dev_index, b, k):
         s1, _, p1 = ske.search(q, k, return_positions=True)
         torch.cuda.synchronize(device)
         stats, state_first = ske.sketch_stats(), ske.sketch_state()
+        per_row = bool(ske.sketch_split(0)[3])
         sk_ms, sk_kern = timed_search(torch, ske, q, k, 20)
         state = ske.sketch_state()
         li = ske.launch_info(b, k)
@@ -700,7 +701,11 @@ def non_isotropic_legs(torch, np, device, dev_index, b, k):
         n = int(x.shape[0])
         xs = x[:: max(1, n // 4096)].float()
         cen = xs.mean(0)
-        return {"rows": n, "sketch_scan": bool(li.sketch_scan), "candidate_pairs_main_scan": stats["last_scan_pairs"],
+        return {"rows": n, "sketch_scan": bool(li.sketch_scan),
+                # "per-row": rows collapsed onto their centre direction (||centroid|| >= 0.85) -- rows and queries are projected off it before
+                # they are sketched and the scan adds the rank-one term per (query, row); "centre-split": every other centred shard
+                "bound_form": "per-row" if per_row else "centre-split",
+                "candidate_pairs_main_scan": stats["last_scan_pairs"],
                 "rescored_pairs": stats["rescored_pairs"], "pairs_per_query": round(stats["rescored_pairs"] / b, 1),
                 "overflow_first_search": stats["overflow"], "sketch_state_after_first_search": state_first,
                 "sketch_state_after_25_searches": state,

@@ -414,3 +414,48 @@ def sketch_upper_bounds(q: np.ndarray, x: np.ndarray, tile: int = 256, transform
     main = sq[:, None].astype(np.float64) * sx[t_of][None, :].astype(np.float64) * d_int
     slack = qlo[:, None].astype(np.float64) * hi_max[t_of][None, :] + qn[:, None].astype(np.float64) * lo_max[t_of][None, :]
     return main + slack
+
+
+def sketch_upper_bounds_centre_split(q: np.ndarray, x: np.ndarray, tile: int = 256, mu=None, per_row: bool = False) -> np.ndarray:
+    """[b, n] upper bounds of q . x with the rank-one structure of embeddings that share a large common component taken out of
+    the slack (csrc/convert.hip sketch_rows_kernel, csrc/score_topk.hip MODE 2).  w = T mu / ||T mu||, y = T (x - mu), z = T q,
+    alpha = z . w, z_r = z - alpha w.
+    * split form (``per_row=False``; every centred shard): the sketches are those of y and z as before, only the slack term
+      |z . x_lo| <= ||z|| ||x_lo|| becomes |alpha| max_tile |w . x_lo| + ||z_r|| max_tile ||x_lo|| (x_lo is a quantisation residue:
+      nearly orthogonal to any fixed direction);
+    * per-row form (shards with ||mu|| >= 0.85): beta = w . y per row, y_r = y - beta w; the sketches are cut from y_r and z_r and
+      z . y = alpha beta + beta (z_r . w) + z_r . y_r: the scan adds alpha beta per (query, row), the middle term is rounding-sized."""
+    x64, q64 = np.asarray(x, dtype=np.float64), np.asarray(q, dtype=np.float64)
+    mu = x64[: min(len(x64), 65536)].mean(axis=0) if mu is None else np.asarray(mu, dtype=np.float64)
+    off = (q64 @ mu)[:, None]
+    z, y = sketch_transform(q64), sketch_transform(x64, mu)
+    w = sketch_transform(mu[None, :])[0]
+    w = w / max(np.linalg.norm(w), 1e-300)
+    alpha = z @ w
+    zr = z - alpha[:, None] * w[None, :]
+    t_of = np.arange(x64.shape[0]) // tile
+    margin = 4e-6 * np.linalg.norm(z, axis=1)[:, None] * (np.linalg.norm(y, axis=1)[None, :] + np.linalg.norm(mu))  # fp32 storage of the transformed vectors
+    if per_row:
+        beta = y @ w
+        yr = (y - beta[:, None] * w[None, :]).astype(np.float32)
+        zr32 = zr.astype(np.float32)
+        xi, sx, hi_max, lo_max = sketch_rows(yr, tile)
+        qi, sq, qlo, _ = sketch_queries(zr32)
+        d_int = qi.astype(np.int64) @ xi.astype(np.int64).T
+        main = sq[:, None].astype(np.float64) * sx[t_of][None, :].astype(np.float64) * d_int
+        rn = np.linalg.norm(zr32.astype(np.float64), axis=1) * (1 + 2.0 ** -16)
+        slack = qlo[:, None].astype(np.float64) * hi_max[t_of][None, :] + rn[:, None] * lo_max[t_of][None, :]
+        cross = np.abs(zr @ w)[:, None] * np.abs(beta)[None, :]  # beta (z_r . w): zero in exact arithmetic, kept for rigour
+        return off + alpha[:, None] * beta[None, :] + main + slack + cross + margin
+    y32, z32 = y.astype(np.float32), z.astype(np.float32)
+    xi, sx, hi_max, lo_max = sketch_rows(y32, tile)
+    qi, sq, qlo, _ = sketch_queries(z32)
+    d_int = qi.astype(np.int64) @ xi.astype(np.int64).T
+    main = sq[:, None].astype(np.float64) * sx[t_of][None, :].astype(np.float64) * d_int
+    lo = y32.astype(np.float64) - sx[t_of][:, None].astype(np.float64) * xi.astype(np.float64)
+    tiles = (x64.shape[0] + tile - 1) // tile
+    c_max = np.array([np.abs(lo[t * tile:(t + 1) * tile] @ w).max() for t in range(tiles)]) * (1 + 2.0 ** -16)
+    rn = np.linalg.norm(zr, axis=1) * (1 + 2.0 ** -16)
+    slack = qlo[:, None].astype(np.float64) * hi_max[t_of][None, :] + np.abs(alpha)[:, None] * c_max[t_of][None, :] + rn[:, None] * lo_max[t_of][None, :]
+    return off + main + slack + margin
+

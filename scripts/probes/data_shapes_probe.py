@@ -37,6 +37,8 @@ def make(kind, m):
         x[:, 77] += 0.7; x[:, 588] += 0.7
     elif kind == "common component (mean cosine 0.5)":
         x = unit(x) + torch.ones(d, device=dev) / d ** 0.5
+    elif kind.startswith("common component (mean cosine 0.9)"):
+        x = unit(x) + 3.0 * torch.ones(d, device=dev) / d ** 0.5
     elif kind == "1000 clusters, within-cluster sigma 0.3":
         c = shared(kind, lambda: unit(torch.randn((1000, d), generator=g, device=dev)))
         x = c[torch.randint(0, 1000, (m,), generator=g, device=dev)] + 0.3 * x / d ** 0.5
@@ -59,20 +61,28 @@ def timed(ix, q):
     return (time.perf_counter() - t0) / 10 * 1e3
 
 
-for kind in ("isotropic", "two outlier dimensions (20x)", "two constant outlier dimensions (mean cosine 0.5)", "common component (mean cosine 0.5)", "1000 clusters, within-cluster sigma 0.3",
-             "50 tight clusters, sigma 0.05", "low rank 32 + 10 % noise"):
+for kind in ("isotropic", "two outlier dimensions (20x)", "two constant outlier dimensions (mean cosine 0.5)", "common component (mean cosine 0.5)",
+             "common component (mean cosine 0.9)", "common component (mean cosine 0.9), per-row form off", "common component (mean cosine 0.9), split off too",
+             "1000 clusters, within-cluster sigma 0.3", "50 tight clusters, sigma 0.05", "low rank 32 + 10 % noise"):
     x = torch.cat([make(kind, 1 << 19) for _ in range(0, n, 1 << 19)])[:n]
     q = make(kind, b)
+    os.environ.pop("VQA_SKETCH_PER_ROW", None); os.environ.pop("VQA_SKETCH_SPLIT", None)
+    if "form off" in kind or "split off" in kind:
+        os.environ["VQA_SKETCH_PER_ROW"] = "0"
+    if "split off" in kind:
+        os.environ["VQA_SKETCH_SPLIT"] = "0"
     ske = DeviceIndex(x, dtype="fp16", sketch=True)
     s1, i1, _ = ske.search(q, k); torch.cuda.synchronize()
     st = ske.sketch_stats(); out = (st['last_scan_pairs'], st['largest_region'], st['longest_sublist'], st['overflow'])
     state = ske.sketch_state()
     t_s = timed(ske, q)
+    if ske.sketch_split(0)[3]:
+        kind += " [per-row form]"
     ske.close()
     ref = DeviceIndex(x, dtype="fp16", sketch=False)
     s0, i0, _ = ref.search(q, k); torch.cuda.synchronize()
     t_e = timed(ref, q)
     ref.close()
     same = bool(torch.equal(i0, i1))
-    print(f"{kind:44s}: main-scan pairs {out[0]:9d}  overflow {out[3]}  state after {state:3d}  sketch {t_s:.3f} ms  exact {t_e:.3f} ms  same ids {same}  max |ds| {float((s0 - s1).abs().max()):.1e}", flush=True)
+    print(f"{kind:62s}: main-scan pairs {out[0]:9d}  overflow {out[3]}  state after {state:3d}  sketch {t_s:.3f} ms  exact {t_e:.3f} ms  same ids {same}  max |ds| {float((s0 - s1).abs().max()):.1e}", flush=True)
     del x

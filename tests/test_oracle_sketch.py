@@ -117,3 +117,51 @@ def test_transformed_sketch_prunes_anisotropic_rows():
     plain = (R.sketch_upper_bounds(q, x) >= thr).mean()
     rotated = (R.sketch_upper_bounds(q, x, transform=True) >= thr).mean()
     assert rotated < 0.25 * plain and rotated < 0.2, (plain, rotated)
+
+
+def _collapsed(n, b, d, weight, seed):
+    """unit rows and queries that share ONE large common component (mean cosine weight^2 / (1 + weight^2))"""
+    rng = np.random.default_rng(seed)
+    c = rng.standard_normal(d)
+    c /= np.linalg.norm(c)
+
+    def draw(m):
+        v = rng.standard_normal((m, d))
+        v = weight * c + v / np.linalg.norm(v, axis=1, keepdims=True)
+        return (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float16)
+
+    return draw(n), draw(b)
+
+
+def test_centre_split_and_per_row_bounds_on_collapsed_embeddings():
+    """Rows that share one large common component (mean cosine 0.9: what an untrained encoder emits).  Both refinements of the bound
+    stay above the float64 score of every pair, and each prunes more than the one before: plain transformed sketch -> slack term
+    split along the centre direction -> per-row rank-one term."""
+    n, d, b, k = 8192, 768, 16, 10
+    x, q = _collapsed(n, b, d, 3.0, 5)
+    true = q.astype(np.float64) @ x.astype(np.float64).T
+    theta = np.sort(true, axis=1)[:, -k]
+    counts, slack = {}, {}
+    for name, ub in (("plain", R.sketch_upper_bounds(q.astype(np.float32), x.astype(np.float32), transform=True)),
+                     ("split", R.sketch_upper_bounds_centre_split(q, x)),
+                     ("per_row", R.sketch_upper_bounds_centre_split(q, x, per_row=True))):
+        assert (ub >= true).all(), name
+        counts[name] = int((ub >= theta[:, None]).sum())
+        slack[name] = float((ub - true).mean())
+    assert slack["per_row"] < 0.6 * slack["split"] < 0.6 * slack["plain"], slack
+    assert counts["per_row"] < counts["split"] < counts["plain"], counts
+
+
+def test_centre_split_changes_nothing_for_isotropic_rows():
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((2048, 128))
+    x = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float16)
+    q = x[:8] + 0  # queries drawn like the rows
+    true = q.astype(np.float64) @ x.astype(np.float64).T
+    for per_row in (False, True):
+        ub = R.sketch_upper_bounds_centre_split(q, x, per_row=per_row)
+        assert (ub >= true).all()
+    plain = R.sketch_upper_bounds(q.astype(np.float32), x.astype(np.float32), transform=True)
+    split = R.sketch_upper_bounds_centre_split(q, x)
+    assert np.abs(split - plain).max() < 0.2 * (plain - true).mean()  # the same bound to within a fraction of its slack
+
