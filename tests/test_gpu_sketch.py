@@ -78,7 +78,9 @@ def test_wide_sketch_search_equals_the_exact_scan(native_lib, monkeypatch, n, d,
     ske = _index(x, monkeypatch, sketch=True, ids=ids)
     li = ske.launch_info(b, k)
     assert ref.launch_info(b, k).sketch_scan == 0 and li.sketch_scan == 1 and ske.launch_info(b, 129).sketch_scan == 0
-    assert li.first_stage_rows == 256 * 256 and li.rows_per_launch == n - 65536 and li.bytes_per_launch == (n - 65536) * d
+    # k >= 16: a second cascade stage of twice the first one's tiles stands in front of the main launch
+    staged = 65536 * (3 if k >= 16 and (n + 255) // 256 >= 4 * 256 else 1)  # (where the shard leaves the main launch a tile per workgroup)
+    assert li.first_stage_rows == staged and li.rows_per_launch == n - staged and li.bytes_per_launch == (n - staged) * d
     s0, i0, p0 = _search(ref, q, k)
     s1, i1, p1 = _search(ske, q, k)
     s2, _, p2 = _search(ske, q, k)
@@ -263,6 +265,31 @@ def test_random_geometries_against_the_exact_scan(native_lib, monkeypatch):
         assert np.all(np.abs(s1[diff] - s0[diff]) <= TIE_TOL) and diff.mean() < 0.01, (case, n, d, k, b, dtype, int(diff.sum()))
         nd = min(k, len(set(planted.tolist())))
         assert sorted(p1[0, :nd].tolist()) == sorted(set(planted.tolist()))[:nd], (case, n, d, k, b, dtype)
+
+
+def test_third_cascade_level_changes_no_bit(native_lib, monkeypatch):
+    """k >= 16 on a shard large enough: [first stage | a second stage of twice its tiles | the rest], the second stage against the first
+    one's exact k-th best, the rest against the k-th best of both.  Same keys in the same lists as with two levels (only fewer
+    of them): rows and scores bit for bit; exact duplicates in all three stages."""
+    n, d, b, k = 330_000, 128, 19, 30
+    rng = np.random.default_rng(12)
+    x, q = _unit(rng, n, d), _unit(rng, b, d)
+    for r in (70_000, 196_607, 196_608, 300_000):  # first stage: rows < 65 536, second: < 196 608
+        x[r] = x[5]
+    q[0] = x[5]
+    three = _index(x, monkeypatch, sketch=True)
+    assert three.launch_info(b, k).first_stage_rows == 3 * 65536 and three.launch_info(b, 10).first_stage_rows == 65536
+    s3, _, p3 = _search(three, q, k)
+    assert three.sketch_stats()["overflow"] == 0
+    three.close()
+    monkeypatch.setenv("VQA_SKETCH_MID_K", "0")
+    two = _index(x, monkeypatch, sketch=True)
+    assert two.launch_info(b, k).first_stage_rows == 65536
+    s2, _, p2 = _search(two, q, k)
+    two.close()
+    monkeypatch.delenv("VQA_SKETCH_MID_K")
+    assert np.array_equal(p3, p2) and np.array_equal(s3, s2)
+    assert p3[0, :5].tolist() == [5, 70_000, 196_607, 196_608, 300_000] and len(set(s3[0, :5].tolist())) == 1
 
 
 @pytest.mark.parametrize("dtype,d,k", [("fp16", 200, 10), ("fp16", 768, 30), ("fp32", 96, 12)])

@@ -97,6 +97,7 @@ struct vqa_index {
     bool center = true;                     // VQA_SKETCH_CENTER=0: no centring (needs the rotated form)
     bool rotate = true;                     // the sketch is cut from rotated rows (convert.hip: sketch_rotate); VQA_SKETCH_ROTATE=0: from the rows as they are
     bool sketch_sx5 = true;                 // the sketch scan's X ring: five stages; VQA_SKETCH_SX=6: six (dev / A-B switch: measured equal)
+    int mid_k = 16, mid_pct = 200;          // a second cascade stage of mid_pct % of the first one's tiles for k >= mid_k (VQA_SKETCH_MID_K, 0: never; VQA_SKETCH_MID_PCT)
     bool cascade = true;                    // VQA_SKETCH_CASCADE=0: the exact first stage of the narrow sketch form (dev / A-B switch)
     int* sketch_flag_dev_mirror = nullptr;  // device address of the pinned mirror below (mapped host memory: the cascade's last merge writes it)
     int* sketch_flag_host = nullptr;        // pinned mirror of sketch_flag [3], copied once behind the last query tile of a call (read by LATER calls)
@@ -435,6 +436,8 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
             }
             ix->sketch_flag_host[0] = ix->sketch_flag_host[1] = ix->sketch_flag_host[2] = 0;
             if (const char* cs = getenv("VQA_SKETCH_CASCADE")) ix->cascade = cs[0] != '0';
+            if (const char* mk = getenv("VQA_SKETCH_MID_K")) ix->mid_k = atoi(mk);
+            if (const char* mp = getenv("VQA_SKETCH_MID_PCT")) ix->mid_pct = atoi(mp) > 0 ? atoi(mp) : 200;
             if (const char* sx = getenv("VQA_SKETCH_SX")) ix->sketch_sx5 = sx[0] != '6';
             if (const char* ro = getenv("VQA_SKETCH_ROTATE")) ix->rotate = ro[0] != '0';
             if (const char* ce = getenv("VQA_SKETCH_CENTER")) ix->center = ce[0] != '0';
@@ -594,6 +597,7 @@ struct LaunchPlan {
     int grid0 = 0;  // its workgroups (a few tiles each)
     int grid1 = 0;  // workgroups of the main pass
     int stage_tiles = 0;  // two-stage search (k <= 12, large shards): tiles of the FIRST stage, 0 = one stage
+    int mid_tiles = 0;    // sketch cascade, large k: tiles of a SECOND stage behind the first (0 = two levels)
     int seeds_per_tile = 2;  // 8 for shards of fewer than 24 tiles (a 1000-row shard has 4: 8 seeds per query would leave the
                              // thresholds at -inf and every list flooding: 0.43 ms per search instead of 0.08)
 };
@@ -641,6 +645,13 @@ static LaunchPlan plan_launch(const vqa_index* ix, int k = 0) {
             const int half = p.seed_tiles / 2 > 0 ? p.seed_tiles / 2 : 1;
             p.seed_tiles = half;
             p.grid0 = p.seed_tiles < ix->max_grid ? p.seed_tiles : ix->max_grid;
+            // Sketch cascade, a third level for large k: most candidates of the main scan are admitted by the weakness of theta1 (the
+            // k-th best of only 10 % of the rows), not by the bound's slack -- against the k-th best of 30 % of the rows the same bound
+            // leaves 2.7x fewer (scripts/probes/decomp_probe.py) -- and their number grows with k.  [first | 2 x first | rest].
+            if (ix->sketch && ix->cascade && ix->mid_k > 0 && k >= ix->mid_k && k <= kSketchMaxK) {
+                const int mid = (int)((long long)p.stage_tiles * ix->mid_pct / 100 / p.grid1) * p.grid1;
+                if (mid > 0 && p.stage_tiles + mid + p.grid1 <= p.tiles) p.mid_tiles = mid;
+            }
         }
     }
     return p;
@@ -659,7 +670,7 @@ extern "C" int vqa_index_launch_info(const vqa_index* ix, int32_t B, int32_t k, 
     out->lds_bytes = vqa_score_topk_lds_bytes(ix->dtype, k);
     out->rows_per_tile = 256;
     out->sketch_scan = sketch_active(ix, p, k) ? 1 : 0;
-    out->first_stage_rows = (k <= vqa_score_topk_max_k(ix->dtype) || out->sketch_scan) ? (int64_t)p.stage_tiles * 256 : 0;
+    out->first_stage_rows = (k <= vqa_score_topk_max_k(ix->dtype) || out->sketch_scan) ? (int64_t)(p.stage_tiles + (out->sketch_scan ? p.mid_tiles : 0)) * 256 : 0;
     out->rows_per_launch = ix->n - out->first_stage_rows;
     out->pad_ = 0;
     out->bytes_per_launch = out->rows_per_launch * (int64_t)ix->d * (out->sketch_scan ? 1 : elem_bytes(ix->dtype));
@@ -930,7 +941,17 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             if (rc != VQA_OK) return rc;
             rc = sketch_select(ix, nq, k, nullptr, nullptr, nullptr, stream, &t1);  // theta1 -> thr0
             if (rc != VQA_OK) return rc;
-            rc = sketch_scan_rescore(ix, p, nullptr, p.stage_tiles, p.tiles, nq, 0, 0, true, stream);
+            int main_begin = p.stage_tiles;
+            if (p.mid_tiles > 0) {  // large k: a second stage against theta1 -> theta2 = the exact k-th best of the first two stages' rows
+                main_begin += p.mid_tiles;
+                rc = sketch_scan_rescore(ix, p, nullptr, p.stage_tiles, main_begin, nq, 0, 0, false, stream);
+                if (rc != VQA_OK) return rc;
+                MergeSketchTail tm = qconst_tail(ix, 0);
+                tm.min_score = ix->thr0;  // keys below theta1 cannot matter any more (read while the lists are gathered, before theta2 is written)
+                rc = sketch_select(ix, nq, k, nullptr, nullptr, nullptr, stream, &tm);  // theta2 -> thr0
+                if (rc != VQA_OK) return rc;
+            }
+            rc = sketch_scan_rescore(ix, p, nullptr, main_begin, p.tiles, nq, 0, 0, true, stream);
             if (rc != VQA_OK) return rc;
             rc = sketch_select(ix, nq, k, os, oi, op, stream, &t2);
             if (rc != VQA_OK) return rc;
