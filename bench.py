@@ -455,13 +455,14 @@ def step_bytes(info, stats, n, d, esize, b, step_ms):
     if stats is None:  # exact search: seed rows once more + every row of the shard once (first stage + main launch)
         parts = {"query_staging": qbytes, "exact_seed_rows": seed, "exact_scan_rows": n * d * esize}
     else:
-        # the cascade (vqa_index_search): exact seeds over 2 tiles per workgroup, int8 scan of the first stage, exact re-scoring of its
+        # the cascade (vqa_index_search): exact seeds over 2 tiles per workgroup, int8 scan of the early stages (first 10 %, then -- k >= 16
+        # or a shard of >= 128 tiles per workgroup -- the next 20 %: info.first_stage_rows counts both), exact re-scoring of their
         # pairs, int8 scan of the rest, exact re-scoring of its pairs (one stored row of d x esize bytes per pair; the query rows come
         # from L2), selections (the candidate keys: 8 bytes per pair, written once and read twice)
         seed = min(2 * int(info.grid), int(info.first_stage_rows) // int(info.rows_per_tile)) * int(info.rows_per_tile) * d * esize
         pairs = int(stats["rescored_pairs"])
         parts = {"query_staging_and_sketch": qbytes + 256 * d, "exact_seed_rows": seed,
-                 "sketch_scan_first_stage": int(info.first_stage_rows) * d, "sketch_scan_main": int(info.rows_per_launch) * d,
+                 "sketch_scan_early_stages": int(info.first_stage_rows) * d, "sketch_scan_main": int(info.rows_per_launch) * d,
                  "rescored_rows": pairs * d * esize, "candidate_pairs_and_keys": pairs * (8 + 8 + 3 * 8)}
     total = sum(parts.values())
     out = {"step_bytes_moved": total, "step_bytes_by_launch": parts,

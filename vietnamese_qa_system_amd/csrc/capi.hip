@@ -98,6 +98,7 @@ struct vqa_index {
     bool rotate = true;                     // the sketch is cut from rotated rows (convert.hip: sketch_rotate); VQA_SKETCH_ROTATE=0: from the rows as they are
     bool sketch_sx5 = true;                 // the sketch scan's X ring: five stages; VQA_SKETCH_SX=6: six (dev / A-B switch: measured equal)
     int mid_k = 16, mid_pct = 200;          // a second cascade stage of mid_pct % of the first one's tiles for k >= mid_k (VQA_SKETCH_MID_K, 0: never; VQA_SKETCH_MID_PCT)
+    int mid_min_tiles = 128;                // ... and for any k on shards of that many tiles per workgroup (VQA_SKETCH_MID_MIN, 0: by k only)
     bool cascade = true;                    // VQA_SKETCH_CASCADE=0: the exact first stage of the narrow sketch form (dev / A-B switch)
     int* sketch_flag_dev_mirror = nullptr;  // device address of the pinned mirror below (mapped host memory: the cascade's last merge writes it)
     int* sketch_flag_host = nullptr;        // pinned mirror of sketch_flag [3], copied once behind the last query tile of a call (read by LATER calls)
@@ -438,6 +439,7 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
             if (const char* cs = getenv("VQA_SKETCH_CASCADE")) ix->cascade = cs[0] != '0';
             if (const char* mk = getenv("VQA_SKETCH_MID_K")) ix->mid_k = atoi(mk);
             if (const char* mp = getenv("VQA_SKETCH_MID_PCT")) ix->mid_pct = atoi(mp) > 0 ? atoi(mp) : 200;
+            if (const char* mm = getenv("VQA_SKETCH_MID_MIN")) ix->mid_min_tiles = atoi(mm);
             if (const char* sx = getenv("VQA_SKETCH_SX")) ix->sketch_sx5 = sx[0] != '6';
             if (const char* ro = getenv("VQA_SKETCH_ROTATE")) ix->rotate = ro[0] != '0';
             if (const char* ce = getenv("VQA_SKETCH_CENTER")) ix->center = ce[0] != '0';
@@ -648,7 +650,10 @@ static LaunchPlan plan_launch(const vqa_index* ix, int k = 0) {
             // Sketch cascade, a third level for large k: most candidates of the main scan are admitted by the weakness of theta1 (the
             // k-th best of only 10 % of the rows), not by the bound's slack -- against the k-th best of 30 % of the rows the same bound
             // leaves 2.7x fewer (scripts/probes/decomp_probe.py) -- and their number grows with k.  [first | 2 x first | rest].
-            if (ix->sketch && ix->cascade && ix->mid_k > 0 && k >= ix->mid_k && k <= kSketchMaxK) {
+            // Small k: the level pays for its ~45 us (a launch ramp, a re-scoring, a selection) only on shards of >= 128 tiles per workgroup
+            // (10M x 768, k = 10, interleaved A/B: 1.936 -> 1.888 ms; 3M rows: +4 %).
+            if (ix->sketch && ix->cascade && ix->mid_k > 0 && k <= kSketchMaxK &&
+                (k >= ix->mid_k || (ix->mid_min_tiles > 0 && p.tiles >= (long long)ix->mid_min_tiles * p.grid1))) {
                 const int mid = (int)((long long)p.stage_tiles * ix->mid_pct / 100 / p.grid1) * p.grid1;
                 if (mid > 0 && p.stage_tiles + mid + p.grid1 <= p.tiles) p.mid_tiles = mid;
             }
