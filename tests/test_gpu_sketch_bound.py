@@ -530,3 +530,44 @@ def test_per_row_form_needs_six_k_steps(native_lib, monkeypatch):
     _same_rows_outside_near_ties(s1, p1, ref, q.astype(np.float32), k)
     ref.close()
 
+
+def test_a_search_that_scores_too_many_pairs_pauses_the_sketch_without_overflowing(native_lib, monkeypatch):
+    """100 tight clusters in a shard of natural sketch size (1.1M rows: no VQA_STAGE_MIN): every query has 11 000 near-duplicates.  No
+    candidate buffer fills up -- the search stands, exact -- but it scores 2.8M pairs exactly where the exact scan would have been
+    cheaper: the handle reports the pause an overflow would have started (VQA_SKETCH_PROFIT=0: stays on the sketch)."""
+    from vietnamese_qa_system_amd.index import DeviceIndex
+    n, d, b, k = 1_100_000, 64, 256, 10
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    centres = torch.randn((100, d), generator=g, device="cuda")
+    centres /= centres.norm(dim=1, keepdim=True)
+
+    def draw(m):
+        v = centres[torch.randint(0, 100, (m,), generator=g, device="cuda")] + 0.02 * torch.randn((m, d), generator=g, device="cuda") / d ** 0.5
+        return (v / v.norm(dim=1, keepdim=True)).half()
+
+    x, q = draw(n), draw(b)
+    monkeypatch.delenv("VQA_STAGE_MIN", raising=False)
+    ref = DeviceIndex(x, dtype="fp16", device=0, sketch=False)
+    s0, _, p0 = ref.search(q, k, return_positions=True)
+    ref.close()
+    for profit, want_pause in (("", True), ("0", False)):
+        if profit:
+            monkeypatch.setenv("VQA_SKETCH_PROFIT", profit)
+        ske = DeviceIndex(x, dtype="fp16", device=0, sketch=True)
+        assert ske.launch_info(b, k).sketch_scan == 1
+        s1, _, p1 = ske.search(q, k, return_positions=True)
+        torch.cuda.synchronize()
+        st = ske.sketch_stats()
+        assert st["overflow"] == 0 and st["rescored_pairs"] > 0.4 * n, st
+        assert (ske.sketch_state() > 0) == want_pause, (profit, ske.sketch_state())
+        assert (s1 - s0).abs().max().item() < 1e-6
+        s2, _, p2 = ske.search(q, k, return_positions=True)  # inside the pause: the exact scan
+        torch.cuda.synchronize()
+        if want_pause:
+            assert torch.equal(s2, s0) and torch.equal(p2, p0)
+        else:
+            assert torch.equal(s2, s1) and torch.equal(p2, p1)
+        ske.close()
+        monkeypatch.delenv("VQA_SKETCH_PROFIT", raising=False)
+

@@ -80,16 +80,20 @@ struct vqa_index {
     unsigned* region_cnt = nullptr;         // [max_grid]
     vqa_key* cand_keys = nullptr;           // [256][kSketchCap] exact (score, position) keys per query
     unsigned* cand_cnt = nullptr;           // [256][kSketchSubLists] x kSketchCntStride: keys in every sub-list of a query's list (a line per counter)
-    int* sketch_flag = nullptr;             // [3]: [0] 1 = a candidate buffer filled up in this query tile: its exact fallback scan runs;
-                                            // [1] = OR of [0] over the EARLIER query tiles of the call, [2] = the call's number (sketch_qconst_kernel)
+    int* sketch_flag = nullptr;             // [4]: [0] 1 = a candidate buffer filled up in this query tile: its exact fallback scan runs;
+                                            // [1] = OR of [0] over the EARLIER query tiles of the call, [2] = the call's number (sketch_qconst_kernel),
+                                            // [3] = pairs scored exactly for this query tile (rescore_kernel adds its regions' counts)
+    double profit_ratio = 0.4;              // a search that scores more than profit_ratio x n pairs exactly (per 256 queries) costs more than the exact scan
+                                            // it replaces (0.5 ns a pair against 0.16 ns a row saved at fp16; the f32 MFMA scan is 16x slower: 4.0): the
+                                            // handle pauses the sketch as after an overflow.  VQA_SKETCH_PROFIT, 0: never
     long long* stage_pos = nullptr;         // [256][max_k] row positions of the first stage's top-k
     float* mu = nullptr;                    // [d_pad8] centre of the shard (mean of the rows of its first fill), subtracted before the sketch
     float* wdir = nullptr;                  // [d_pad8] (behind mu, same allocation) w = T mu / ||T mu||: the slack term |z . x_lo| of the bound is split
                                             // along it (convert.hip sketch_rows_kernel); VQA_SKETCH_SPLIT=0: not (dev / A-B switch)
     bool split = true;
     float* beta = nullptr;                  // [tiles * 256] per-row form: beta = w . y of every row (the scan adds alpha beta per (query, row))
-    bool per_row = false;                   // decided with the centre, at the first fill: ||mu|| >= 0.85 (rows collapsed onto one direction;
-                                            // unit rows: the mean cosine to the centroid) and rows of >= 6 K-steps; VQA_SKETCH_PER_ROW=0 / 1 forces it
+    bool per_row = false;                   // decided with the centre, at the first fill: ||mu||^2 >= 0.85^2 x the sample's mean ||x||^2 (rows collapsed onto one
+                                            // direction; unit rows: the mean cosine to the centroid >= 0.85) and rows of >= 6 K-steps; VQA_SKETCH_PER_ROW=0 / 1 forces it
     int per_row_env = -1;
     float* qoff = nullptr;                  // [256] q . mu of the query tile
     float mu_norm = 0.f;
@@ -279,19 +283,21 @@ extern "C" int vqa_index_set_rows(vqa_index* ix, int64_t first, int64_t count, c
             // that a corpus stored sorted by topic still gets its overall mean --, fixed from then on: every tile's sketch must be
             // cut against the same centre; any centre is valid (q . x = q . mu + q . (x - mu)), a good one shortens the rows
             const int64_t samples = std::min<int64_t>(count, 65536);
-            int rcm = vqa_launch_row_mean(ix->rows, ix->dtype, first, samples, count / samples, ix->d_pad, ix->d_pad8, ix->mu, nullptr);
+            // (the mean of the squares lands where w goes afterwards: mu and w share an allocation)
+            int rcm = vqa_launch_row_mean(ix->rows, ix->dtype, first, samples, count / samples, ix->d_pad, ix->d_pad8, ix->mu, nullptr, ix->wdir);
             if (rcm != VQA_OK) return rcm;
-            std::vector<float> h((size_t)ix->d_pad8);
+            std::vector<float> h((size_t)ix->d_pad8 * (ix->wdir ? 2 : 1));
             VQA_HIP_CHECK(hipMemcpy(h.data(), ix->mu, h.size() * 4, hipMemcpyDeviceToHost));
-            double n2 = 0.0;
-            for (float v : h) n2 += (double)v * v;
+            double n2 = 0.0, row2 = 0.0;  // ||mu||^2 and the sample's mean ||x||^2
+            for (size_t j = 0; j < (size_t)ix->d_pad8; ++j) n2 += (double)h[j] * h[j];
+            for (size_t j = (size_t)ix->d_pad8; j < h.size(); ++j) row2 += (double)h[j];
             ix->mu_norm = (float)(std::sqrt(n2) * (1.0 + 1e-6));
             ix->mu_set = true;
             if (ix->wdir) {
                 rcm = vqa_launch_center_dir(ix->mu, ix->d_pad8, ix->rotate, ix->wdir, nullptr);
                 if (rcm != VQA_OK) return rcm;
                 // rows collapsed onto the centre direction (an untrained / anisotropic encoder): the per-row form (convert.hip sketch_rows_kernel)
-                ix->per_row = ix->beta && (ix->per_row_env == 1 || (ix->per_row_env < 0 && n2 >= 0.85 * 0.85));
+                ix->per_row = ix->beta && (ix->per_row_env == 1 || (ix->per_row_env < 0 && row2 > 0.0 && n2 >= 0.85 * 0.85 * row2));
             }
         }
         int rc = vqa_launch_tile_scales(ix->rows, ix->dtype, t0, t1 - t0 + 1, ix->d_pad, ix->d_pad8, ix->tile_info, ix->rotate, ix->center ? ix->mu : nullptr, nullptr,
@@ -427,15 +433,19 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
                 hipMalloc((void**)&ix->regions, (size_t)ix->max_grid * kSketchCap * 8) != hipSuccess ||
                 hipMalloc((void**)&ix->region_cnt, (size_t)ix->max_grid * 4) != hipSuccess ||
                 hipMalloc((void**)&ix->cand_keys, (size_t)VQA_QUERY_TILE * kSketchCap * sizeof(vqa_key)) != hipSuccess ||
-                hipMalloc((void**)&ix->cand_cnt, (size_t)VQA_QUERY_TILE * kSketchSubLists * kSketchCntStride * 4) != hipSuccess || hipMalloc((void**)&ix->sketch_flag, 3 * sizeof(int)) != hipSuccess ||
+                hipMalloc((void**)&ix->cand_cnt, (size_t)VQA_QUERY_TILE * kSketchSubLists * kSketchCntStride * 4) != hipSuccess || hipMalloc((void**)&ix->sketch_flag, 4 * sizeof(int)) != hipSuccess ||
                 hipMalloc((void**)&ix->stage_pos, (size_t)VQA_QUERY_TILE * max_k * 8) != hipSuccess ||
-                hipHostMalloc((void**)&ix->sketch_flag_host, 3 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+                hipHostMalloc((void**)&ix->sketch_flag_host, 4 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
                 hipHostGetDevicePointer((void**)&ix->sketch_flag_dev_mirror, ix->sketch_flag_host, 0) != hipSuccess) {
                 vqa_set_error("vqa_index_create: allocating the int8 sketch (%zu bytes) failed", ix->rows8_bytes);
                 rc = VQA_ENOMEM;
                 break;
             }
-            ix->sketch_flag_host[0] = ix->sketch_flag_host[1] = ix->sketch_flag_host[2] = 0;
+            ix->sketch_flag_host[0] = ix->sketch_flag_host[1] = ix->sketch_flag_host[2] = ix->sketch_flag_host[3] = 0;
+            // (a shard whose size rule was lowered by VQA_STAGE_MIN -- tests, A/B runs -- is below the size at which the sketch pays at all:
+            // the profitability rule is off there unless asked for)
+            if (const char* pf = getenv("VQA_SKETCH_PROFIT")) ix->profit_ratio = atof(pf);
+            else ix->profit_ratio = getenv("VQA_STAGE_MIN") ? 0.0 : dtype == VQA_F32 ? 4.0 : 0.4;
             if (const char* cs = getenv("VQA_SKETCH_CASCADE")) ix->cascade = cs[0] != '0';
             if (const char* mk = getenv("VQA_SKETCH_MID_K")) ix->mid_k = atoi(mk);
             if (const char* mp = getenv("VQA_SKETCH_MID_PCT")) ix->mid_pct = atoi(mp) > 0 ? atoi(mp) : 200;
@@ -465,7 +475,7 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
             if (const char* cd = getenv("VQA_SKETCH_COOLDOWN")) ix->sketch_cooldown_len = atoi(cd) > 0 ? atoi(cd) : 0;
             ix->sketch_cooldown_cur = ix->sketch_cooldown_len;
             if (hipMemset(ix->rows8, 0, ix->rows8_bytes) != hipSuccess || hipMemset(ix->tile_info, 0, (size_t)tiles * 20) != hipSuccess ||
-                hipMemset(ix->sketch_flag, 0, 3 * sizeof(int)) != hipSuccess ||
+                hipMemset(ix->sketch_flag, 0, 4 * sizeof(int)) != hipSuccess ||
                 hipMemset(ix->q8_stage, 0, (size_t)VQA_QUERY_TILE * ix->d_pad8) != hipSuccess) {
                 vqa_set_error("vqa_index_create: clearing the int8 sketch failed");
                 rc = VQA_EHIP;
@@ -580,7 +590,8 @@ extern "C" int32_t vqa_index_sketch_state(const vqa_index* ix) {
     // (the flag of the last sketch search arrives in the pinned mirror when that search has completed)
     // a completed call's report the host has not looked at yet: what the next search will do with it
     if (__atomic_load_n(ix->sketch_flag_host + 2, __ATOMIC_RELAXED) != ix->sketch_seq_seen &&
-        (__atomic_load_n(ix->sketch_flag_host, __ATOMIC_RELAXED) | __atomic_load_n(ix->sketch_flag_host + 1, __ATOMIC_RELAXED)) != 0)
+        ((__atomic_load_n(ix->sketch_flag_host, __ATOMIC_RELAXED) | __atomic_load_n(ix->sketch_flag_host + 1, __ATOMIC_RELAXED)) != 0 ||
+         (ix->profit_ratio > 0.0 && (double)__atomic_load_n(ix->sketch_flag_host + 3, __ATOMIC_RELAXED) > ix->profit_ratio * (double)ix->n)))
         return ix->sketch_cooldown_cur > 0 ? ix->sketch_cooldown_cur : 1;
     return ix->sketch_cooldown;
 }
@@ -863,7 +874,10 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             // (the three words arrive by one 12-byte DMA; the number is read first, so a report caught half-way is at worst taken
             // for the previous call's and looked at again next time)
             const int seq = __atomic_load_n(ix->sketch_flag_host + 2, __ATOMIC_ACQUIRE);
-            const bool over = (__atomic_load_n(ix->sketch_flag_host, __ATOMIC_RELAXED) | __atomic_load_n(ix->sketch_flag_host + 1, __ATOMIC_RELAXED)) != 0;
+            // "over": a candidate buffer overflowed (the call's exact fallback ran), or the call scored so many pairs exactly that the exact
+            // scan would have been cheaper (its result stands: this only decides what the NEXT searches run)
+            const bool over = (__atomic_load_n(ix->sketch_flag_host, __ATOMIC_RELAXED) | __atomic_load_n(ix->sketch_flag_host + 1, __ATOMIC_RELAXED)) != 0 ||
+                              (ix->profit_ratio > 0.0 && (double)__atomic_load_n(ix->sketch_flag_host + 3, __ATOMIC_RELAXED) > ix->profit_ratio * (double)ix->n);
             if (seq != ix->sketch_seq_seen) {  // a sketch search completed since the last look
                 ix->sketch_seq_seen = seq;
                 // (reports of calls that were already queued when the current pause began say nothing new)
@@ -1058,7 +1072,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
     // the overflow flags of this call (its last tile's, the OR over the earlier ones, the call's number) -> the pinned mirror a later
     // call's cool-down bookkeeping reads
     if (sketch_call && !mirror_by_kernel)
-        VQA_HIP_CHECK(hipMemcpyAsync(ix->sketch_flag_host, ix->sketch_flag, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        VQA_HIP_CHECK(hipMemcpyAsync(ix->sketch_flag_host, ix->sketch_flag, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
     return VQA_OK;
 }
 

@@ -571,17 +571,20 @@ __global__ __launch_bounds__(64) void center_dir_kernel(const float* __restrict_
 // one workgroup per 16-element unit, 256 threads over the rows
 template <typename SRC>
 __global__ __launch_bounds__(256) void row_mean_kernel(const SRC* __restrict__ tiled, long long first, long long count, long long stride,
-                                                       int KTS, float* __restrict__ mu) {
+                                                       int KTS, float* __restrict__ mu, float* __restrict__ msq) {
     __shared__ float red[256][17];
     const int u = blockIdx.x;
-    float acc[16];
+    float acc[16], acc2[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    for (int e = 0; e < 16; ++e) acc[e] = acc2[e] = 0.f;
     for (long long r = threadIdx.x; r < count; r += 256) {
         float x[16];
         load_sketch_unit<SRC>(tiled, first + r * stride, u, KTS, x);
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] += x[e];
+        for (int e = 0; e < 16; ++e) {
+            acc[e] += x[e];
+            acc2[e] = __builtin_fmaf(x[e], x[e], acc2[e]);
+        }
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) red[threadIdx.x][e] = acc[e];
@@ -592,19 +595,31 @@ __global__ __launch_bounds__(256) void row_mean_kernel(const SRC* __restrict__ t
         const float m = sum / (float)count;
         mu[16 * u + threadIdx.x] = m == m && fabsf(m) < INFINITY ? m : 0.f;  // NaN / Inf rows: no centre in that dimension
     }
+    if (msq) {  // mean of the squares, element by element: their sum over the row is the sample's mean ||x||^2 (how collapsed the rows are: ||mu||^2 against it)
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) red[threadIdx.x][e] = acc2[e];
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            float sum = 0.f;
+            for (int t = 0; t < 256; ++t) sum += red[t][threadIdx.x];
+            const float m = sum / (float)count;
+            msq[16 * u + threadIdx.x] = m == m && fabsf(m) < INFINITY ? m : 0.f;
+        }
+    }
 }
 
 }  // namespace
 
 int vqa_launch_row_mean(const void* tiled, int32_t src_dtype, int64_t first, int64_t count, int64_t stride, int32_t d_pad_src, int32_t d_pad8,
-                        float* mu, hipStream_t stream) {
+                        float* mu, hipStream_t stream, float* msq) {
     VQA_REQUIRE(count > 0 && stride >= 1 && (src_dtype == VQA_F16 || src_dtype == VQA_F32), "row_mean: bad arguments");
     if (src_dtype == VQA_F16)
         hipLaunchKernelGGL(row_mean_kernel<_Float16>, dim3(d_pad8 / 16), dim3(256), 0, stream, reinterpret_cast<const _Float16*>(tiled),
-                           (long long)first, (long long)count, (long long)stride, d_pad_src / 32, mu);
+                           (long long)first, (long long)count, (long long)stride, d_pad_src / 32, mu, msq);
     else
         hipLaunchKernelGGL(row_mean_kernel<float>, dim3(d_pad8 / 16), dim3(256), 0, stream, reinterpret_cast<const float*>(tiled),
-                           (long long)first, (long long)count, (long long)stride, d_pad_src / 16, mu);
+                           (long long)first, (long long)count, (long long)stride, d_pad_src / 16, mu, msq);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

@@ -54,6 +54,8 @@ __global__ __launch_bounds__(256) void rescore_kernel(const unsigned long long* 
     const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), nwaves = gridDim.x * 4;
     const int y = blockIdx.y;
     const int total = y < nregions ? (int)counts[y] : nq * k;
+    // (the host's profitability check: pairs this query tile scores exactly, one atomic per region and launch)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && y < nregions && total > 0) atomicAdd(overflow + 3, total < cap ? total : cap);
     const int units = KT * 4;
     const int sub_cap = capq / kSketchSubLists;
     auto pair_of = [&](int i, int& q, long long& pos) {
@@ -173,6 +175,7 @@ __global__ void sketch_qconst_kernel(const float* __restrict__ thr, const float*
             overflow[1] = clear == 2 ? 0 : (overflow[1] | overflow[0]);
             overflow[0] = 0;
             overflow[2] = seq;  // which call of the handle these flags belong to (the host's cool-down bookkeeping, capi.hip)
+            overflow[3] = 0;    // pairs scored exactly for this query tile (rescore_kernel adds)
         }
     }
 }

@@ -209,14 +209,14 @@ int vqa_launch_sketch_rows(const void* tiled, int32_t src_dtype, int64_t first, 
 int vqa_launch_center_dir(const float* mu, int32_t d_pad8, bool rotate, float* wdir, hipStream_t stream);
 // mean of the `count` rows first, first + stride, first + 2 stride, ... of a TILED array -> mu [d_pad8]
 int vqa_launch_row_mean(const void* tiled, int32_t src_dtype, int64_t first, int64_t count, int64_t stride, int32_t d_pad_src, int32_t d_pad8,
-                        float* mu, hipStream_t stream);
+                        float* mu, hipStream_t stream, float* msq = nullptr /* [d_pad8] mean of the squares, element by element */);
 // scale (= max |x| / 127) of tiles [tile0, tile0 + ntiles) of a TILED fp16 / fp32 array into tile_info; clears their two maxima
 int vqa_launch_tile_scales(const void* tiled, int32_t src_dtype, int64_t tile0, int64_t ntiles, int32_t d_pad_src, int32_t d_pad8,
                            float* tile_info, bool rotate, const float* mu, hipStream_t stream, float* tile_c = nullptr /* cleared too */,
                            const float* proj_w = nullptr /* per-row form: the scale of y - (w . y) w */);
 // sketch search: per-query constants of the scan + reset of the candidate counters; exact scores of the candidate pairs
 int vqa_launch_sketch_qconst(const float* thr, const float* qscale, const float* qlo, const float* qnorm, int32_t d, float* qconst,
-                             unsigned* cand_cnt, int* overflow /* [3]: this tile's flag, OR over the call's earlier tiles, seq */,
+                             unsigned* cand_cnt, int* overflow /* [4]: this tile's flag, OR over the call's earlier tiles, seq, pairs scored exactly */,
                              int clear /* 0: keep; 1: reset the candidate counters and the tile's overflow flag (OR-ed into overflow[1]
                                           first); 2: the same for the first query tile of a call (overflow[1] = 0) */,
                              int seq /* written to overflow[2] when clearing: the call these flags belong to */,
