@@ -17,7 +17,7 @@ for dtype, sizes in (("fp16", (1_200_000, 3_000_000, 10_000_000)), ("fp32", (600
             x[c0:c0 + r.shape[0]] = (r / r.norm(dim=1, keepdim=True)).to(x.dtype)
         ix = DeviceIndex(x, dtype=dtype)
         del x
-        for b, k in itertools.product((1, 7, 256, 257), (1, 10, 12, 13, 32, 64)):
+        for b, k in itertools.product((1, 7, 256, 257), (1, 10, 12, 13, 32, 64, 100, 128)):
             if ix.launch_info(b, k).sketch_scan != 1:
                 continue
             q = torch.randn((b, d), generator=g, device=dev)

@@ -80,12 +80,15 @@ struct vqa_index {
     unsigned* region_cnt = nullptr;         // [max_grid]
     vqa_key* cand_keys = nullptr;           // [256][kSketchCap] exact (score, position) keys per query
     unsigned* cand_cnt = nullptr;           // [256][kSketchSubLists] x kSketchCntStride: keys in every sub-list of a query's list (a line per counter)
-    int* sketch_flag = nullptr;             // [4]: [0] 1 = a candidate buffer filled up in this query tile: its exact fallback scan runs;
+    int* sketch_flag = nullptr;             // [5]: [0] 1 = a candidate buffer filled up in this query tile: its exact fallback scan runs;
                                             // [1] = OR of [0] over the EARLIER query tiles of the call, [2] = the call's number (sketch_qconst_kernel),
-                                            // [3] = pairs scored exactly for this query tile (rescore_kernel adds its regions' counts)
-    double profit_ratio = 0.4;              // a search that scores more than profit_ratio x n pairs exactly (per 256 queries) costs more than the exact scan
-                                            // it replaces (0.5 ns a pair against 0.16 ns a row saved at fp16; the f32 MFMA scan is 16x slower: 4.0): the
-                                            // handle pauses the sketch as after an overflow.  VQA_SKETCH_PROFIT, 0: never
+                                            // [3] = pairs scored exactly for this query tile (rescore_kernel adds its regions' counts), [4] = the
+                                            // most any earlier tile of the call scored
+    double profit_ratio = 0.5;              // A query tile that scores more pairs exactly than profit_pairs() costs more than the exact scan the sketch
+                                            // search replaces: the handle pauses the sketch as after an overflow.  Fitted to 10 shard shapes x 6 k
+                                            // (profiles/r04_profit_probe.txt): the sketch search loses where pairs > 0.5 n - 1.2e8 / d (a pair costs
+                                            // ~0.45 ns at d = 768, a row saved 0.2 ns, the cascade's extra launches ~70 us); the f32 MFMA scan of
+                                            // fp32 shards is 16x slower: 4 n.  VQA_SKETCH_PROFIT sets the factor, 0: never
     long long* stage_pos = nullptr;         // [256][max_k] row positions of the first stage's top-k
     float* mu = nullptr;                    // [d_pad8] centre of the shard (mean of the rows of its first fill), subtracted before the sketch
     float* wdir = nullptr;                  // [d_pad8] (behind mu, same allocation) w = T mu / ||T mu||: the slack term |z . x_lo| of the bound is split
@@ -433,19 +436,19 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
                 hipMalloc((void**)&ix->regions, (size_t)ix->max_grid * kSketchCap * 8) != hipSuccess ||
                 hipMalloc((void**)&ix->region_cnt, (size_t)ix->max_grid * 4) != hipSuccess ||
                 hipMalloc((void**)&ix->cand_keys, (size_t)VQA_QUERY_TILE * kSketchCap * sizeof(vqa_key)) != hipSuccess ||
-                hipMalloc((void**)&ix->cand_cnt, (size_t)VQA_QUERY_TILE * kSketchSubLists * kSketchCntStride * 4) != hipSuccess || hipMalloc((void**)&ix->sketch_flag, 4 * sizeof(int)) != hipSuccess ||
+                hipMalloc((void**)&ix->cand_cnt, (size_t)VQA_QUERY_TILE * kSketchSubLists * kSketchCntStride * 4) != hipSuccess || hipMalloc((void**)&ix->sketch_flag, 5 * sizeof(int)) != hipSuccess ||
                 hipMalloc((void**)&ix->stage_pos, (size_t)VQA_QUERY_TILE * max_k * 8) != hipSuccess ||
-                hipHostMalloc((void**)&ix->sketch_flag_host, 4 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
+                hipHostMalloc((void**)&ix->sketch_flag_host, 5 * sizeof(int), hipHostMallocMapped) != hipSuccess ||
                 hipHostGetDevicePointer((void**)&ix->sketch_flag_dev_mirror, ix->sketch_flag_host, 0) != hipSuccess) {
                 vqa_set_error("vqa_index_create: allocating the int8 sketch (%zu bytes) failed", ix->rows8_bytes);
                 rc = VQA_ENOMEM;
                 break;
             }
-            ix->sketch_flag_host[0] = ix->sketch_flag_host[1] = ix->sketch_flag_host[2] = ix->sketch_flag_host[3] = 0;
+            ix->sketch_flag_host[0] = ix->sketch_flag_host[1] = ix->sketch_flag_host[2] = ix->sketch_flag_host[3] = ix->sketch_flag_host[4] = 0;
             // (a shard whose size rule was lowered by VQA_STAGE_MIN -- tests, A/B runs -- is below the size at which the sketch pays at all:
             // the profitability rule is off there unless asked for)
             if (const char* pf = getenv("VQA_SKETCH_PROFIT")) ix->profit_ratio = atof(pf);
-            else ix->profit_ratio = getenv("VQA_STAGE_MIN") ? 0.0 : dtype == VQA_F32 ? 4.0 : 0.4;
+            else ix->profit_ratio = getenv("VQA_STAGE_MIN") ? 0.0 : dtype == VQA_F32 ? 4.0 : 0.5;
             if (const char* cs = getenv("VQA_SKETCH_CASCADE")) ix->cascade = cs[0] != '0';
             if (const char* mk = getenv("VQA_SKETCH_MID_K")) ix->mid_k = atoi(mk);
             if (const char* mp = getenv("VQA_SKETCH_MID_PCT")) ix->mid_pct = atoi(mp) > 0 ? atoi(mp) : 200;
@@ -475,7 +478,7 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
             if (const char* cd = getenv("VQA_SKETCH_COOLDOWN")) ix->sketch_cooldown_len = atoi(cd) > 0 ? atoi(cd) : 0;
             ix->sketch_cooldown_cur = ix->sketch_cooldown_len;
             if (hipMemset(ix->rows8, 0, ix->rows8_bytes) != hipSuccess || hipMemset(ix->tile_info, 0, (size_t)tiles * 20) != hipSuccess ||
-                hipMemset(ix->sketch_flag, 0, 4 * sizeof(int)) != hipSuccess ||
+                hipMemset(ix->sketch_flag, 0, 5 * sizeof(int)) != hipSuccess ||
                 hipMemset(ix->q8_stage, 0, (size_t)VQA_QUERY_TILE * ix->d_pad8) != hipSuccess) {
                 vqa_set_error("vqa_index_create: clearing the int8 sketch failed");
                 rc = VQA_EHIP;
@@ -585,13 +588,24 @@ extern "C" int vqa_index_get_rows(vqa_index* ix, int64_t first, int64_t count, v
 extern "C" int64_t vqa_index_size(const vqa_index* ix) { return ix ? ix->n : -1; }
 extern "C" int32_t vqa_index_dim(const vqa_index* ix) { return ix ? ix->d : -1; }
 extern "C" int32_t vqa_index_dtype(const vqa_index* ix) { return ix ? ix->dtype : -1; }
+// the profitability rule of the sketch search (vqa_index::profit_ratio)
+static double profit_pairs(const vqa_index* ix) {
+    const double n = (double)ix->n, d = (double)(ix->d_pad < 256 ? 256 : ix->d_pad);
+    const double lim = ix->profit_ratio * n - (ix->dtype == VQA_F32 ? 0.0 : 1.2e8 / d);
+    return lim > 0.1 * n ? lim : 0.1 * n;
+}
+static int pairs_reported(const vqa_index* ix) {  // the most pairs a query tile of the last reported call scored exactly
+    const int a = __atomic_load_n(ix->sketch_flag_host + 3, __ATOMIC_RELAXED), b = __atomic_load_n(ix->sketch_flag_host + 4, __ATOMIC_RELAXED);
+    return a > b ? a : b;  // (the kernel-written mirror holds the maximum in [3]; the copied flags hold [3] and [4])
+}
+
 extern "C" int32_t vqa_index_sketch_state(const vqa_index* ix) {
     if (!ix || !ix->sketch) return -1;
     // (the flag of the last sketch search arrives in the pinned mirror when that search has completed)
     // a completed call's report the host has not looked at yet: what the next search will do with it
     if (__atomic_load_n(ix->sketch_flag_host + 2, __ATOMIC_RELAXED) != ix->sketch_seq_seen &&
         ((__atomic_load_n(ix->sketch_flag_host, __ATOMIC_RELAXED) | __atomic_load_n(ix->sketch_flag_host + 1, __ATOMIC_RELAXED)) != 0 ||
-         (ix->profit_ratio > 0.0 && (double)__atomic_load_n(ix->sketch_flag_host + 3, __ATOMIC_RELAXED) > ix->profit_ratio * (double)ix->n)))
+         (ix->profit_ratio > 0.0 && (double)pairs_reported(ix) > profit_pairs(ix))))
         return ix->sketch_cooldown_cur > 0 ? ix->sketch_cooldown_cur : 1;
     return ix->sketch_cooldown;
 }
@@ -877,7 +891,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             // "over": a candidate buffer overflowed (the call's exact fallback ran), or the call scored so many pairs exactly that the exact
             // scan would have been cheaper (its result stands: this only decides what the NEXT searches run)
             const bool over = (__atomic_load_n(ix->sketch_flag_host, __ATOMIC_RELAXED) | __atomic_load_n(ix->sketch_flag_host + 1, __ATOMIC_RELAXED)) != 0 ||
-                              (ix->profit_ratio > 0.0 && (double)__atomic_load_n(ix->sketch_flag_host + 3, __ATOMIC_RELAXED) > ix->profit_ratio * (double)ix->n);
+                              (ix->profit_ratio > 0.0 && (double)pairs_reported(ix) > profit_pairs(ix));
             if (seq != ix->sketch_seq_seen) {  // a sketch search completed since the last look
                 ix->sketch_seq_seen = seq;
                 // (reports of calls that were already queued when the current pause began say nothing new)
@@ -1072,7 +1086,7 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
     // the overflow flags of this call (its last tile's, the OR over the earlier ones, the call's number) -> the pinned mirror a later
     // call's cool-down bookkeeping reads
     if (sketch_call && !mirror_by_kernel)
-        VQA_HIP_CHECK(hipMemcpyAsync(ix->sketch_flag_host, ix->sketch_flag, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        VQA_HIP_CHECK(hipMemcpyAsync(ix->sketch_flag_host, ix->sketch_flag, 5 * sizeof(int), hipMemcpyDeviceToHost, stream));
     return VQA_OK;
 }
 

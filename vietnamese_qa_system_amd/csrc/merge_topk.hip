@@ -177,16 +177,18 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
                 tail.overflow[1] = tail.clear == 2 ? 0 : (tail.overflow[1] | tail.overflow[0]);
                 tail.overflow[0] = 0;
                 tail.overflow[2] = tail.seq;
-                tail.overflow[3] = 0;  // pairs scored exactly for this query tile (rescore_kernel counts)
+                // [3]: pairs scored exactly for this query tile (rescore_kernel counts), [4]: the most any EARLIER tile of the call scored
+                tail.overflow[4] = tail.clear == 2 ? 0 : (tail.overflow[4] > tail.overflow[3] ? tail.overflow[4] : tail.overflow[3]);
+                tail.overflow[3] = 0;
             }
         }
     }
     if (tail.flag_mirror && q == 0 && threadIdx.x == 0) {
         __hip_atomic_store(tail.flag_mirror, tail.overflow[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(tail.flag_mirror + 1, tail.overflow[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        // pairs scored exactly for this (the call's last) query tile, scaled to a full tile of 256 queries: the host's profitability check
-        const long long pairs = (long long)tail.overflow[3] * VQA_QUERY_TILE / (long long)gridDim.x;
-        __hip_atomic_store(tail.flag_mirror + 3, (int)(pairs > 0x7FFFFFFFll ? 0x7FFFFFFFll : pairs), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // the most pairs any query tile of the call scored exactly: the host's profitability check
+        __hip_atomic_store(tail.flag_mirror + 3, tail.overflow[4] > tail.overflow[3] ? tail.overflow[4] : tail.overflow[3], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(tail.flag_mirror + 2, tail.overflow[2], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }

@@ -175,6 +175,7 @@ __global__ void sketch_qconst_kernel(const float* __restrict__ thr, const float*
             overflow[1] = clear == 2 ? 0 : (overflow[1] | overflow[0]);
             overflow[0] = 0;
             overflow[2] = seq;  // which call of the handle these flags belong to (the host's cool-down bookkeeping, capi.hip)
+            overflow[4] = clear == 2 ? 0 : (overflow[4] > overflow[3] ? overflow[4] : overflow[3]);  // the most an earlier tile of the call scored
             overflow[3] = 0;    // pairs scored exactly for this query tile (rescore_kernel adds)
         }
     }
