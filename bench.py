@@ -675,7 +675,8 @@ def non_isotropic_legs(torch, np, device, dev_index, b, k):
     """The sketch search OFF the benchmark's isotropic Gaussian corpus (its best case), driver-visible and bounded (~15 s):
     (1) rows produced by this build's own PhoBERT-base-shaped encoder (random-init weights, mean pooling, L2 norm) from 1.57M synthetic
     token sequences -- the one anisotropic embedding source available offline --, queries encoded the same way;
-    (2) 3M rows in 1000 clusters (within-cluster sigma 0.3 of the centre norm), queries drawn like the rows.
+    (2) 3M rows in 1000 clusters (within-cluster sigma 0.3 of the centre norm), queries drawn like the rows;
+    (3) 10M rows that share one common component (mean cosine 0.9): collapsed embeddings at the size the metric is quoted on.
     Per leg: candidate pairs, whether the search stayed on the sketch (sketch_state 0), sketch search vs exact scan of the same shard
     (queries/s), same rows as the exact scan."""
     from vietnamese_qa_system_amd.index import DeviceIndex
@@ -755,6 +756,27 @@ def non_isotropic_legs(torch, np, device, dev_index, b, k):
     q = draw(b)
     legs["clusters_1000"] = compare(x, q, {"source": "1000 cluster centres on the unit sphere + 0.3 / sqrt(d) N(0, 1) noise per component, L2-normalised; "
                                                      "queries drawn like the rows", "generate_s": round(time.perf_counter() - t0, 1)})
+    del x
+    torch.cuda.empty_cache()
+    # ---- (3) collapsed embeddings at the headline size: one common component of mean cosine 0.9 (what the encoder leg shows at 1.57M rows,
+    # synthetic here so that 10M rows take seconds): the per-row form of the bound at the size the metric is quoted on
+    t0 = time.perf_counter()
+    n_cc = 10_000_000
+    common = torch.randn((1, d), generator=gen, device=device)
+    common /= common.norm()
+
+    def draw_cc(m):
+        v = torch.randn((m, d), generator=gen, device=device)
+        v = 3.0 * common + v / v.norm(dim=1, keepdim=True)
+        return (v / v.norm(dim=1, keepdim=True)).to(torch.float16)
+
+    x = torch.empty((n_cc, d), dtype=torch.float16, device=device)
+    for c0 in range(0, n_cc, 1 << 19):
+        c1 = min(n_cc, c0 + (1 << 19))
+        x[c0:c1] = draw_cc(c1 - c0)
+    q = draw_cc(b)
+    legs["common_component_cos0p9_10M"] = compare(x, q, {"source": "3 x one fixed unit direction + a uniform unit vector, L2-normalised (mean cosine 0.9 between any two rows); "
+                                                                   "queries drawn like the rows", "generate_s": round(time.perf_counter() - t0, 1)})
     return legs
 
 
