@@ -704,7 +704,7 @@ def non_isotropic_legs(torch, np, device, dev_index, b, k):
         xs = x[:: max(1, n // 4096)].float()
         cen = xs.mean(0)
         return {"rows": n, "sketch_scan": bool(li.sketch_scan),
-                # "per-row": rows collapsed onto their centre direction (||centroid|| >= 0.85) -- rows and queries are projected off it before
+                # "per-row": rows collapsed onto their centre direction (||centroid||^2 >= 0.6 of the mean ||x||^2) -- rows and queries are projected off it before
                 # they are sketched and the scan adds the rank-one term per (query, row); "centre-split": every other centred shard
                 "bound_form": "per-row" if per_row else "centre-split",
                 "candidate_pairs_main_scan": stats["last_scan_pairs"],

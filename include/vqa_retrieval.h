@@ -48,7 +48,7 @@ extern "C" {
                              * accumulation) only the pairs the bound cannot exclude: the results are those of the exact scan.
                              * The sketch is cut from T (x - mu): mu the mean of the shard's first fill, T random signs + a block
                              * Walsh-Hadamard transform -- anisotropic embeddings (outlier dimensions, a common component) keep pruning; shards whose rows
-                             * collapse onto one direction (||mu|| >= 0.85) take a per-row form of the bound (vqa_index_get_sketch_split).
+                             * collapse onto one direction (||mu||^2 >= 0.6 of the mean ||x||^2: a mean cosine of 0.6 between two rows) take a per-row form of the bound (vqa_index_get_sketch_split).
                              * Ignored for fp8 storage. */
 #define VQA_INDEX_RESCORE_ROWS 4 /* with VQA_INDEX_SKETCH, where the sketch is kept: a second, ROW-MAJOR copy of the stored rows (+100 %
                              * of the rows' memory).  The sketch search scores its surviving (query, row) pairs exactly from the

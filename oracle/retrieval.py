@@ -423,7 +423,7 @@ def sketch_upper_bounds_centre_split(q: np.ndarray, x: np.ndarray, tile: int = 2
     * split form (``per_row=False``; every centred shard): the sketches are those of y and z as before, only the slack term
       |z . x_lo| <= ||z|| ||x_lo|| becomes |alpha| max_tile |w . x_lo| + ||z_r|| max_tile ||x_lo|| (x_lo is a quantisation residue:
       nearly orthogonal to any fixed direction);
-    * per-row form (shards with ||mu|| >= 0.85): beta = w . y per row, y_r = y - beta w; the sketches are cut from y_r and z_r and
+    * per-row form (shards whose rows have a mean cosine >= 0.6): beta = w . y per row, y_r = y - beta w; the sketches are cut from y_r and z_r and
       z . y = alpha beta + beta (z_r . w) + z_r . y_r: the scan adds alpha beta per (query, row), the middle term is rounding-sized."""
     x64, q64 = np.asarray(x, dtype=np.float64), np.asarray(q, dtype=np.float64)
     mu = x64[: min(len(x64), 65536)].mean(axis=0) if mu is None else np.asarray(mu, dtype=np.float64)

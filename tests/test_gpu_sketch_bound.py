@@ -470,7 +470,7 @@ def _collapsed(n, b, d, weight, seed):
 
 @pytest.mark.parametrize("pattern", ["", "0xCB"])
 def test_per_row_form_on_collapsed_embeddings(native_lib, monkeypatch, pattern):
-    """Rows collapsed onto their centre direction (mean cosine 0.9 >= 0.85) switch the shard to the per-row form at its first fill: rows
+    """Rows collapsed onto their centre direction (mean cosine 0.9 >= 0.6) switch the shard to the per-row form at its first fill: rows
     and queries are projected off w before they are sketched, the scan adds alpha beta per (query, row).  (a) what the device keeps
     for a tile, against float64: beta = w . y, the codes / maxima are those of y - beta w, the tile's c >= max |beta| -- with these the
     bound follows for every query by z . y = alpha (w . y) + z_r . y, z_r . y = beta (z_r . w) + z_r . y_r; (b) the search returns the

@@ -95,8 +95,9 @@ struct vqa_index {
                                             // along it (convert.hip sketch_rows_kernel); VQA_SKETCH_SPLIT=0: not (dev / A-B switch)
     bool split = true;
     float* beta = nullptr;                  // [tiles * 256] per-row form: beta = w . y of every row (the scan adds alpha beta per (query, row))
-    bool per_row = false;                   // decided with the centre, at the first fill: ||mu||^2 >= 0.85^2 x the sample's mean ||x||^2 (rows collapsed onto one
-                                            // direction; unit rows: the mean cosine to the centroid >= 0.85) and rows of >= 6 K-steps; VQA_SKETCH_PER_ROW=0 / 1 forces it
+    bool per_row = false;                   // decided with the centre, at the first fill: ||mu||^2 >= 0.6 x the sample's mean ||x||^2 (rows collapsed onto one
+                                            // direction; unit rows: a mean cosine of 0.6 between two rows; measured: the per-row form is level with the centre split at 0.5 and ahead from 0.7 on,
+                                            // profiles/r04_per_row_threshold.txt) and rows of >= 6 K-steps; VQA_SKETCH_PER_ROW=0 / 1 forces it
     int per_row_env = -1;
     float* qoff = nullptr;                  // [256] q . mu of the query tile
     float mu_norm = 0.f;
@@ -300,7 +301,7 @@ extern "C" int vqa_index_set_rows(vqa_index* ix, int64_t first, int64_t count, c
                 rcm = vqa_launch_center_dir(ix->mu, ix->d_pad8, ix->rotate, ix->wdir, nullptr);
                 if (rcm != VQA_OK) return rcm;
                 // rows collapsed onto the centre direction (an untrained / anisotropic encoder): the per-row form (convert.hip sketch_rows_kernel)
-                ix->per_row = ix->beta && (ix->per_row_env == 1 || (ix->per_row_env < 0 && row2 > 0.0 && n2 >= 0.85 * 0.85 * row2));
+                ix->per_row = ix->beta && (ix->per_row_env == 1 || (ix->per_row_env < 0 && row2 > 0.0 && n2 >= 0.6 * row2));
             }
         }
         int rc = vqa_launch_tile_scales(ix->rows, ix->dtype, t0, t1 - t0 + 1, ix->d_pad, ix->d_pad8, ix->tile_info, ix->rotate, ix->center ? ix->mu : nullptr, nullptr,

@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void sketch_rows_kernel(const SRC* __restrict_
     // ANY vector w and ANY number alpha as long as z_r is z - alpha w: nothing here has to be exact except that subtraction (its
     // rounding, <= 2^-23 ||z|| ||x_lo||, rides in the margin).  Query rows report |alpha| and ||z_r||, index rows raise their tile's
     // max |w . x_lo| (below, with the codes).
-    // Per-row form (sp.per_row; shards whose embeddings collapse onto the centre direction, mean cosine >= 0.85): the rank-one part leaves
+    // Per-row form (sp.per_row; shards whose embeddings collapse onto the centre direction, mean cosine between two rows >= 0.6): the rank-one part leaves
     // the sketch altogether.  With y = beta w + y_r per row (beta = w . y) and z = alpha w + z_r per query,
     //     z . y = alpha (w . y) + beta (z_r . w) + z_r . y_r,
     // the sketch is cut from y_r and z_r -- a quarter of the norm, a quarter of the quantisation step --, the scan adds alpha beta per
