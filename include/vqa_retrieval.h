@@ -106,8 +106,8 @@ int64_t vqa_index_device_bytes(const vqa_index* index);
  * further overflow doubles the pause (up to 64 x), a sketch search that stands resets it.  A search that does not overflow but
  * scores more pairs exactly in one query tile than the scan saves -- more than 0.5 n - 1.2e8 / d pairs (fp32 shards: 4 n;
  * VQA_SKETCH_PROFIT sets the factor) -- is treated the same way (dense clusters; a large k on a shard of a million rows): its
- * result stands, the following searches take the exact scan (the pause belongs to the handle, whatever k and batch size started
- * it: a handle that serves k = 100 and k = 10 searches alternately on a 1M-row shard runs both on the exact scan).  The host may run many searches ahead
+ * result stands, the following searches of at least HALF its k take the exact scan (a handle that serves k = 100 and k = 10
+ * searches alternately on a 1M-row shard keeps the k = 10 ones on the sketch; a pause started by an overflow applies to every k).  The host may run many searches ahead
  * of the device: reports of calls queued before a pause began are ignored, so the reaction lags by the queue depth and never
  * compounds.  Nothing but SPEED depends on this state: every path returns the exact top-k of the stored values.  Scores are
  * bit-stable within one path; between the sketch path (fp32 fma chain of the re-scoring kernel) and the exact scan (MFMA

@@ -119,6 +119,9 @@ struct vqa_index {
     int sketch_seq = 0;                     // calls of this handle that ran the sketch search; the device writes the call's number beside its
     int sketch_seq_seen = 0;                // flags (sketch_flag[2]), so the host reacts ONCE to every completed call, however far it runs ahead
     int sketch_seq_ignore = 0;              // calls up to this number were queued before the current pause began
+    int k_of_seq[64] = {0};                 // k of the sketch call with number seq (seq & 63): what a report is about
+    int pause_min_k = 0;                    // the current pause applies to searches with k >= this (0: to all -- an overflow; a pause started by the
+                                            // profitability rule at k leaves searches of less than half that k on the sketch)
     // opt-in kernel timing (bench.py): event pairs around the main scoring kernel
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
@@ -898,6 +901,9 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
                 // (reports of calls that were already queued when the current pause began say nothing new)
                 const bool fresh = (int)((unsigned)seq - (unsigned)ix->sketch_seq_ignore) > 0;
                 if (over && fresh) {
+                    const bool overflowed = (__atomic_load_n(ix->sketch_flag_host, __ATOMIC_RELAXED) | __atomic_load_n(ix->sketch_flag_host + 1, __ATOMIC_RELAXED)) != 0;
+                    const int min_k = overflowed ? 0 : (ix->k_of_seq[seq & 63] + 1) / 2;
+                    ix->pause_min_k = ix->sketch_cooldown > 0 ? std::min(ix->pause_min_k, min_k) : min_k;
                     ix->sketch_cooldown = ix->sketch_cooldown_cur;
                     // overflow, pause, overflow again: the pause doubles (64, 128, ... 4096 searches)
                     ix->sketch_cooldown_cur = std::min(2 * ix->sketch_cooldown_cur, 64 * ix->sketch_cooldown_len);
@@ -905,13 +911,14 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
                 } else if (!over && fresh && ix->sketch_cooldown == 0) {
                     ix->sketch_cooldown_cur = ix->sketch_cooldown_len;  // a sketch search stood: back to the base pause
                 }
-            } else if (ix->sketch_cooldown > 0) {
-                --ix->sketch_cooldown;
+            } else if (ix->sketch_cooldown > 0 && k >= ix->pause_min_k) {
+                --ix->sketch_cooldown;  // (the pause counts the searches it applies to)
             }
         }
-        const bool any_sketch = sketch_active(ix, p, k) && ix->sketch_cooldown == 0;
+        const bool any_sketch = sketch_active(ix, p, k) && (ix->sketch_cooldown == 0 || k < ix->pause_min_k);
         if (any_sketch && q0 == 0) {
             ++ix->sketch_seq;
+            ix->k_of_seq[ix->sketch_seq & 63] = k;
             sketch_call = true;
         }
         const int sk_clear = q0 == 0 ? 2 : 1;  // the call's first query tile also clears the OR over the tiles
