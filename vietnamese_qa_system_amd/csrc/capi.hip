@@ -1038,8 +1038,12 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             ScoreTopkArgs a = exact_launch_args(ix, nq, kk);
             a.upper = upper;
             a.gate = gate;
-            if (p.grid0 > 0 && (rc = seed_pass(ix, p, a, kk, gate, stream)) != VQA_OK) return rc;
-            a.thr_init = p.grid0 > 0 ? ix->thr0 : nullptr;
+            // The gated exact passes behind a cascade (k > 12: ceil(k / 12) of them, each "returns at once" -- but an empty launch still costs
+            // its ~5 us of dispatch: four launches per pass were 200 us of a 3 ms search at k = 100) need no seed pass of their own: theta0,
+            // the k-th largest exact seed of the cascade, bounds the k-th best score from below and with it every pass's 12 j-th.
+            const bool cascade_fallback = any_sketch && ix->cascade && gate == ix->sketch_flag;
+            if (!cascade_fallback && p.grid0 > 0 && (rc = seed_pass(ix, p, a, kk, gate, stream)) != VQA_OK) return rc;
+            a.thr_init = cascade_fallback ? ix->thr_seed : p.grid0 > 0 ? ix->thr0 : nullptr;
             a.tile_begin = 0;
             a.tile_end = p.tiles;
             a.grid = p.grid1;
