@@ -1041,8 +1041,11 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             // The gated exact passes behind a cascade (k > 12: ceil(k / 12) of them, each "returns at once" -- but an empty launch still costs
             // its ~5 us of dispatch: four launches per pass were 200 us of a 3 ms search at k = 100) need no seed pass of their own: theta0,
             // the k-th largest exact seed of the cascade, bounds the k-th best score from below and with it every pass's 12 j-th.
+            // The same holds behind the one-pass attempt of a shard without a sketch (gate = wide_flag): its seed pass left the k-th
+            // largest seed in thr0, and nothing overwrites it when the continuation passes do not seed themselves.
             const bool cascade_fallback = any_sketch && ix->cascade && gate == ix->sketch_flag;
-            if (!cascade_fallback && p.grid0 > 0 && (rc = seed_pass(ix, p, a, kk, gate, stream)) != VQA_OK) return rc;
+            const bool wide_fallback = gate != nullptr && gate == ix->wide_flag && p.grid0 > 0;
+            if (!cascade_fallback && !wide_fallback && p.grid0 > 0 && (rc = seed_pass(ix, p, a, kk, gate, stream)) != VQA_OK) return rc;
             a.thr_init = cascade_fallback ? ix->thr_seed : p.grid0 > 0 ? ix->thr0 : nullptr;
             a.tile_begin = 0;
             a.tile_end = p.tiles;
