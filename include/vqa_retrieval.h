@@ -104,7 +104,7 @@ int64_t vqa_index_device_bytes(const vqa_index* index);
  * last launch; a LATER vqa_index_search on the handle that finds the report of a call it has not seen yet, with a flag up, starts
  * a pause: the next VQA_SKETCH_COOLDOWN (default 64) searches run the exact scan only, then the sketch is tried again; every
  * further overflow doubles the pause (up to 64 x), a sketch search that stands resets it.  A search that does not overflow but
- * scores more pairs exactly in one query tile than the scan saves -- more than 0.5 n - 1.2e8 / d pairs (fp32 shards: 4 n;
+ * scores more pairs exactly in one query tile than the scan saves -- more than 0.75 n - 4e5 pairs (fp32 shards: 4 n;
  * VQA_SKETCH_PROFIT sets the factor) -- is treated the same way (dense clusters; a large k on a shard of a million rows): its
  * result stands, the following searches of at least HALF its k take the exact scan (a handle that serves k = 100 and k = 10
  * searches alternately on a 1M-row shard keeps the k = 10 ones on the sketch; a pause started by an overflow applies to every k).  The host may run many searches ahead

@@ -28,8 +28,8 @@ for dtype, sizes in (("fp16", (1_200_000, 3_000_000, 10_000_000)), ("fp32", (600
             st = ix.sketch_state()
             if st != 0:
                 bad.append((dtype, n, d, b, k, st))
-                for _ in range(st + 1):  # run the cool-down out so that the next cell starts on the sketch
-                    ix.search(q[:1], 1)
+                for _ in range(st + 1):  # run the pause out (it counts the searches it applies to: those of at least half this k)
+                    ix.search(q[:1], k)
                 torch.cuda.synchronize()
         ix.close()
         print(f"{dtype} n={n} d={d}: done ({cells} searches so far, {len(bad)} fell back)", flush=True)

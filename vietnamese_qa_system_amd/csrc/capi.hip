@@ -84,10 +84,10 @@ struct vqa_index {
                                             // [1] = OR of [0] over the EARLIER query tiles of the call, [2] = the call's number (sketch_qconst_kernel),
                                             // [3] = pairs scored exactly for this query tile (rescore_kernel adds its regions' counts), [4] = the
                                             // most any earlier tile of the call scored
-    double profit_ratio = 0.5;              // A query tile that scores more pairs exactly than profit_pairs() costs more than the exact scan the sketch
-                                            // search replaces: the handle pauses the sketch as after an overflow.  Fitted to 10 shard shapes x 6 k
-                                            // (profiles/r04_profit_probe.txt): the sketch search loses where pairs > 0.5 n - 1.2e8 / d (a pair costs
-                                            // ~0.45 ns at d = 768, a row saved 0.2 ns, the cascade's extra launches ~70 us); the f32 MFMA scan of
+    double profit_ratio = 0.75;             // A query tile that scores more pairs exactly than profit_pairs() costs more than the exact scan the sketch
+                                            // search replaces: the handle pauses the sketch as after an overflow.  Fitted to 5 shard shapes x 6 k
+                                            // (profiles/r04_profit_probe.txt, the set measured with the radix selections): the sketch search is level
+                                            // with the exact forms over a wide band and loses clearly where pairs > 0.75 n - 4e5; the f32 MFMA scan of
                                             // fp32 shards is 16x slower: 4 n.  VQA_SKETCH_PROFIT sets the factor, 0: never
     long long* stage_pos = nullptr;         // [256][max_k] row positions of the first stage's top-k
     float* mu = nullptr;                    // [d_pad8] centre of the shard (mean of the rows of its first fill), subtracted before the sketch
@@ -452,7 +452,7 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
             // (a shard whose size rule was lowered by VQA_STAGE_MIN -- tests, A/B runs -- is below the size at which the sketch pays at all:
             // the profitability rule is off there unless asked for)
             if (const char* pf = getenv("VQA_SKETCH_PROFIT")) ix->profit_ratio = atof(pf);
-            else ix->profit_ratio = getenv("VQA_STAGE_MIN") ? 0.0 : dtype == VQA_F32 ? 4.0 : 0.5;
+            else ix->profit_ratio = getenv("VQA_STAGE_MIN") ? 0.0 : dtype == VQA_F32 ? 4.0 : 0.75;
             if (const char* cs = getenv("VQA_SKETCH_CASCADE")) ix->cascade = cs[0] != '0';
             if (const char* mk = getenv("VQA_SKETCH_MID_K")) ix->mid_k = atoi(mk);
             if (const char* mp = getenv("VQA_SKETCH_MID_PCT")) ix->mid_pct = atoi(mp) > 0 ? atoi(mp) : 200;
@@ -594,8 +594,8 @@ extern "C" int32_t vqa_index_dim(const vqa_index* ix) { return ix ? ix->d : -1; 
 extern "C" int32_t vqa_index_dtype(const vqa_index* ix) { return ix ? ix->dtype : -1; }
 // the profitability rule of the sketch search (vqa_index::profit_ratio)
 static double profit_pairs(const vqa_index* ix) {
-    const double n = (double)ix->n, d = (double)(ix->d_pad < 256 ? 256 : ix->d_pad);
-    const double lim = ix->profit_ratio * n - (ix->dtype == VQA_F32 ? 0.0 : 1.2e8 / d);
+    const double n = (double)ix->n;
+    const double lim = ix->profit_ratio * n - (ix->dtype == VQA_F32 ? 0.0 : 4e5);
     return lim > 0.1 * n ? lim : 0.1 * n;
 }
 static int pairs_reported(const vqa_index* ix) {  // the most pairs a query tile of the last reported call scored exactly
