@@ -105,10 +105,14 @@ def test_full_size_properties(native_lib, shard):
     # or a wide k overflowed into the exact fallback (which would silently switch the sketch off for the next searches)
     assert full.launch_info(q.shape[0], K).sketch_scan == 1
     ragged = torch.cat([q, q[:1]])  # one query in the last tile
-    for qs, kk, rows in ((q[:1], K, [0]), (ragged, K, list(range(q.shape[0])) + [0]), (q[:64], 30, list(range(64)))):
+    # (k = 30: three cascade levels by k; k = 100: four -- the first stage's leading quarter as a stage of its own -- and the radix
+    # selection of the merges; the full batch at k = 10 takes three levels by the shard's size)
+    for qs, kk, rows in ((q[:1], K, [0]), (ragged, K, list(range(q.shape[0])) + [0]), (q[:64], 30, list(range(64))),
+                         (q[:48], 100, list(range(48)))):
         sq, iq, _ = full.search(qs, kk)
         torch.cuda.synchronize()
         assert torch.equal(sq[:, :K], s[rows]) and torch.equal(iq[:, :K], i[rows])
+        assert bool((sq[:, 1:] <= sq[:, :-1]).all()) and all(len(set(r)) == kk for r in iq.tolist())
     assert full.sketch_state() == 0
 
     # ---- planted needles: self-score = sum of squares of the stored fp16 values; the copy further down ties with it

@@ -106,6 +106,7 @@ struct vqa_index {
     bool rotate = true;                     // the sketch is cut from rotated rows (convert.hip: sketch_rotate); VQA_SKETCH_ROTATE=0: from the rows as they are
     bool sketch_sx5 = true;                 // the sketch scan's X ring: five stages; VQA_SKETCH_SX=6: six (dev / A-B switch: measured equal)
     int mid_k = 16, mid_pct = 200;          // a second cascade stage of mid_pct % of the first one's tiles for k >= mid_k (VQA_SKETCH_MID_K, 0: never; VQA_SKETCH_MID_PCT)
+    int pre_k = 48;                         // a leading quarter of the first stage as a stage of its own for k >= pre_k (VQA_SKETCH_PRE_K, 0: never)
     int mid_min_tiles = 128;                // ... and for any k on shards of that many tiles per workgroup (VQA_SKETCH_MID_MIN, 0: by k only)
     bool cascade = true;                    // VQA_SKETCH_CASCADE=0: the exact first stage of the narrow sketch form (dev / A-B switch)
     int* sketch_flag_dev_mirror = nullptr;  // device address of the pinned mirror below (mapped host memory: the cascade's last merge writes it)
@@ -457,6 +458,7 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
             if (const char* mk = getenv("VQA_SKETCH_MID_K")) ix->mid_k = atoi(mk);
             if (const char* mp = getenv("VQA_SKETCH_MID_PCT")) ix->mid_pct = atoi(mp) > 0 ? atoi(mp) : 200;
             if (const char* mm = getenv("VQA_SKETCH_MID_MIN")) ix->mid_min_tiles = atoi(mm);
+            if (const char* pk = getenv("VQA_SKETCH_PRE_K")) ix->pre_k = atoi(pk);
             if (const char* sx = getenv("VQA_SKETCH_SX")) ix->sketch_sx5 = sx[0] != '6';
             if (const char* ro = getenv("VQA_SKETCH_ROTATE")) ix->rotate = ro[0] != '0';
             if (const char* ce = getenv("VQA_SKETCH_CENTER")) ix->center = ce[0] != '0';
@@ -629,6 +631,7 @@ struct LaunchPlan {
     int grid1 = 0;  // workgroups of the main pass
     int stage_tiles = 0;  // two-stage search (k <= 12, large shards): tiles of the FIRST stage, 0 = one stage
     int mid_tiles = 0;    // sketch cascade, large k: tiles of a SECOND stage behind the first (0 = two levels)
+    int pre_tiles = 0;    // sketch cascade, larger k still: the first stage's leading tiles as a stage of their own (0 = none)
     int seeds_per_tile = 2;  // 8 for shards of fewer than 24 tiles (a 1000-row shard has 4: 8 seeds per query would leave the
                              // thresholds at -inf and every list flooding: 0.43 ms per search instead of 0.08)
 };
@@ -685,6 +688,12 @@ static LaunchPlan plan_launch(const vqa_index* ix, int k = 0) {
                 (k >= ix->mid_k || (ix->mid_min_tiles > 0 && p.tiles >= (long long)ix->mid_min_tiles * p.grid1))) {
                 const int mid = (int)((long long)p.stage_tiles * ix->mid_pct / 100 / p.grid1) * p.grid1;
                 if (mid > 0 && p.stage_tiles + mid + p.grid1 <= p.tiles) p.mid_tiles = mid;
+                // k >= pre_k: the first stage runs against the seeds' threshold -- the k-th best of only 131 072 rows -- and leaves most of a
+                // large-k search's pairs; its leading quarter as a stage of its own gives the other three quarters a threshold 4x as many rows deep
+                if (p.mid_tiles > 0 && ix->pre_k > 0 && k >= ix->pre_k) {
+                    const int pre = p.stage_tiles / 4 / p.grid1 * p.grid1;
+                    if (pre >= 2 * p.grid1) p.pre_tiles = pre;  // (the exact seeds' tiles -- 2 per workgroup -- lie inside it: their k rows make its lists k deep)
+                }
             }
         }
     }
@@ -972,30 +981,31 @@ extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, i
             ScoreTopkArgs a = exact_launch_args(ix, nq, k <= max_k ? k : max_k);
             // (every merge also does what sits between it and the next scan: the scan's per-query constants from the threshold it
             // has just selected, the reset of the candidate counters; the call's last one reports the overflow flags to the host)
-            MergeSketchTail t0 = qconst_tail(ix, sk_clear), t1 = qconst_tail(ix, 0), t2;
+            MergeSketchTail t0 = qconst_tail(ix, sk_clear), t2;
             t2.overflow = ix->sketch_flag;
             t2.min_score = ix->thr0;  // theta1: what the first selection left there
             t2.flag_mirror = q0 + VQA_QUERY_TILE >= B ? ix->sketch_flag_dev_mirror : nullptr;
             rc = seed_pass(ix, pc, a, k, nullptr, stream, ix->thr_seed, &t0);  // theta0 -> thr_seed
             if (rc != VQA_OK) return rc;
-            rc = sketch_scan_rescore(ix, p, nullptr, 0, p.stage_tiles, nq, 0, sk_clear, false, stream);
-            if (rc != VQA_OK) return rc;
-            rc = sketch_select(ix, nq, k, nullptr, nullptr, nullptr, stream, &t1);  // theta1 -> thr0
-            if (rc != VQA_OK) return rc;
-            int main_begin = p.stage_tiles;
-            if (p.mid_tiles > 0) {  // large k: a second stage against theta1 -> theta2 = the exact k-th best of the first two stages' rows
-                main_begin += p.mid_tiles;
-                rc = sketch_scan_rescore(ix, p, nullptr, p.stage_tiles, main_begin, nq, 0, 0, false, stream);
+            // the stages: [leading quarter of the first (k >= pre_k) |] first | [second (k >= mid_k or a large shard) |] the rest
+            int bounds[4], nb = 0;
+            if (p.pre_tiles > 0) bounds[nb++] = p.pre_tiles;
+            bounds[nb++] = p.stage_tiles;
+            if (p.mid_tiles > 0) bounds[nb++] = p.stage_tiles + p.mid_tiles;
+            bounds[nb++] = p.tiles;
+            for (int l = 0, begin = 0; l < nb; begin = bounds[l], ++l) {
+                const bool last = l == nb - 1;
+                rc = sketch_scan_rescore(ix, p, nullptr, begin, bounds[l], nq, 0, l == 0 ? sk_clear : 0, last, stream);
                 if (rc != VQA_OK) return rc;
-                MergeSketchTail tm = qconst_tail(ix, 0);
-                tm.min_score = ix->thr0;  // keys below theta1 cannot matter any more (read while the lists are gathered, before theta2 is written)
-                rc = sketch_select(ix, nq, k, nullptr, nullptr, nullptr, stream, &tm);  // theta2 -> thr0
+                if (last) {
+                    rc = sketch_select(ix, nq, k, os, oi, op, stream, &t2);
+                } else {  // theta_l = the exact k-th best of the rows scanned so far -> thr0 (and the next scan's constants)
+                    MergeSketchTail tl = qconst_tail(ix, 0);
+                    if (l > 0) tl.min_score = ix->thr0;  // keys below the previous level's threshold cannot matter any more (read while the lists are gathered, before the new threshold is written)
+                    rc = sketch_select(ix, nq, k, nullptr, nullptr, nullptr, stream, &tl);
+                }
                 if (rc != VQA_OK) return rc;
             }
-            rc = sketch_scan_rescore(ix, p, nullptr, main_begin, p.tiles, nq, 0, 0, true, stream);
-            if (rc != VQA_OK) return rc;
-            rc = sketch_select(ix, nq, k, os, oi, op, stream, &t2);
-            if (rc != VQA_OK) return rc;
             mirror_by_kernel = true;
             if (k <= max_k) {
                 a.thr_init = ix->thr_seed;
