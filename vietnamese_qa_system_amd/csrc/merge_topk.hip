@@ -65,6 +65,98 @@ __device__ __forceinline__ vqa_key block_max_key(vqa_key v, vqa_key* red, int ro
     return m;
 }
 
+// The k largest of the m keys in LDS `keys` (distinct but for empty = 0 slots), best first, into win[0, k) (0 = none); every thread of the
+// block calls it.  The k-th largest key by an 8-bit radix descent from the top byte -- 8 passes: a histogram of the current byte over the
+// keys that match the bytes chosen so far, then the bin in which the count from the top reaches the rank wanted -- then the keys at or
+// above it gathered and ordered by counting ranks: ~30 us whatever k, where k rounds of "largest key below the previous winner" cost
+// k x (a pass over the keys + a block reduction) -- 64-173 us per selection of a k = 100 cascade.  `keys` is overwritten (scratch for
+// the ordered winners); hist: [256 + 4] ints of LDS.
+__device__ __forceinline__ void select_topk_radix(vqa_key* keys, int m, int k, vqa_key* win, int* hist) {
+    int* sel = hist + 256;
+    const int kk = k < m ? k : m;
+    vqa_key prefix = 0ull;
+    int need = kk;
+    for (int pass = 0; pass < 8 && kk > 0; ++pass) {
+        const int shift = 56 - 8 * pass;
+        const vqa_key hi_mask = pass == 0 ? 0ull : (~0ull << (shift + 8));
+        for (int i = threadIdx.x; i < 256; i += kMergeThreads) hist[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < m; i += kMergeThreads) {
+            const vqa_key v = keys[i];
+            if ((v & hi_mask) == prefix) atomicAdd(&hist[(int)((v >> shift) & 255ull)], 1);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {  // one wave: lane l owns bins 255 - 4 l .. 252 - 4 l (from the top); inclusive scan over the lanes
+            const int l = threadIdx.x;
+            const int h0 = hist[255 - 4 * l], h1 = hist[254 - 4 * l], h2 = hist[253 - 4 * l], h3 = hist[252 - 4 * l];
+            const int mine = h0 + h1 + h2 + h3;
+            int inc = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(inc, off, 64);
+                if (l >= off) inc += up;
+            }
+            const int before = inc - mine;  // keys in bins above this lane's
+            if (before < need && inc >= need) {  // the wanted rank falls into this lane's four bins: exactly one lane
+                int b = 255 - 4 * l, above = before;
+                if (above + h0 < need) {
+                    above += h0;
+                    --b;
+                    if (above + h1 < need) {
+                        above += h1;
+                        --b;
+                        if (above + h2 < need) {
+                            above += h2;
+                            --b;
+                        }
+                    }
+                }
+                sel[0] = b;
+                sel[1] = need - above;
+            }
+        }
+        __syncthreads();
+        prefix |= (vqa_key)(unsigned)sel[0] << shift;
+        need = sel[1];
+    }
+    if (threadIdx.x == 0) sel[2] = 0;
+    __syncthreads();
+    // prefix IS the kk-th largest key.  The keys above it first (fewer than kk), then those equal to it up to kk in all: exactly one
+    // when the keys are distinct; the dense seed lists may hold empty (zero) slots, which tie
+    if (kk > 0) {
+        for (int i = threadIdx.x; i < m; i += kMergeThreads) {
+            const vqa_key v = keys[i];
+            if (v > prefix) win[atomicAdd(&sel[2], 1)] = v;
+        }
+    }
+    __syncthreads();
+    if (kk > 0) {
+        for (int i = threadIdx.x; i < m; i += kMergeThreads) {
+            const vqa_key v = keys[i];
+            if (v == prefix) {
+                const int sl = atomicAdd(&sel[2], 1);
+                if (sl < kk) win[sl] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // order the kk winners (best first) by rank counting; the slots behind them are empty
+    for (int t0 = 0; t0 < k; t0 += kMergeThreads) {
+        const int t = t0 + threadIdx.x;
+        vqa_key mine = 0ull;
+        int rank = t;
+        if (t < kk) {
+            mine = win[t];
+            rank = 0;
+            for (int j = 0; j < kk; ++j) rank += (win[j] > mine || (win[j] == mine && j < t)) ? 1 : 0;
+        }
+        // (every chunk reads the unsorted array: the sorted one goes to `keys`, which nobody needs any more, and is copied back)
+        if (t < k) keys[rank] = mine;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < k; t += kMergeThreads) win[t] = keys[t];
+}
+
 __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa_key* __restrict__ partial, int parts,
                                                                        int list_len, int k,
                                                                        const long long* __restrict__ ids,
@@ -134,95 +226,8 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
     // operation of the wave, so a global store per round made each round pay a store round trip (~2 us against ~0.6 us of work).
     vqa_key* win = reinterpret_cast<vqa_key*>(fill + 2);  // [k]
     if (k >= kRadixSelectK && cap_keys >= k) {
-        // Large k: k rounds of "largest key below the previous winner" cost k x (a pass over the m keys + a block reduction): 64-173 us per
-        // selection of a k = 100 cascade (4 700 keys per query behind the first stage).  Instead: the k-th largest key by an 8-bit
-        // radix descent from the top byte (8 passes: a histogram of the current byte over the keys that match the bytes chosen so far,
-        // the bin in which the count from the top reaches the rank wanted), then the keys at or above it -- exactly k, the keys are
-        // distinct -- gathered and ordered by counting ranks.  ~30 us whatever k.
-        int* hist = reinterpret_cast<int*>(win + k);  // [256] + [4]
-        int* sel = hist + 256;
-        const int kk = k < m ? k : m;
-        vqa_key prefix = 0ull;
-        int need = kk;
-        for (int pass = 0; pass < 8 && kk > 0; ++pass) {
-            const int shift = 56 - 8 * pass;
-            const vqa_key hi_mask = pass == 0 ? 0ull : (~0ull << (shift + 8));
-            for (int i = threadIdx.x; i < 256; i += kMergeThreads) hist[i] = 0;
-            __syncthreads();
-            for (int i = threadIdx.x; i < m; i += kMergeThreads) {
-                const vqa_key v = keys[i];
-                if ((v & hi_mask) == prefix) atomicAdd(&hist[(int)((v >> shift) & 255ull)], 1);
-            }
-            __syncthreads();
-            if (threadIdx.x < 64) {  // one wave: lane l owns bins 255 - 4 l .. 252 - 4 l (from the top); inclusive scan over the lanes
-                const int l = threadIdx.x;
-                const int h0 = hist[255 - 4 * l], h1 = hist[254 - 4 * l], h2 = hist[253 - 4 * l], h3 = hist[252 - 4 * l];
-                const int mine = h0 + h1 + h2 + h3;
-                int inc = mine;
-#pragma unroll
-                for (int off = 1; off < 64; off <<= 1) {
-                    const int up = __shfl_up(inc, off, 64);
-                    if (l >= off) inc += up;
-                }
-                const int before = inc - mine;  // keys in bins above this lane's
-                if (before < need && inc >= need) {  // the wanted rank falls into this lane's four bins: exactly one lane
-                    int b = 255 - 4 * l, above = before;
-                    if (above + h0 < need) {
-                        above += h0;
-                        --b;
-                        if (above + h1 < need) {
-                            above += h1;
-                            --b;
-                            if (above + h2 < need) {
-                                above += h2;
-                                --b;
-                            }
-                        }
-                    }
-                    sel[0] = b;
-                    sel[1] = need - above;
-                }
-            }
-            __syncthreads();
-            prefix |= (vqa_key)(unsigned)sel[0] << shift;
-            need = sel[1];
-        }
-        if (threadIdx.x == 0) sel[2] = 0;
-        __syncthreads();
-        // prefix IS the kk-th largest key.  The keys above it first (fewer than kk), then those equal to it up to kk in all: exactly one
-        // when the keys are distinct; the dense seed lists may hold empty (zero) slots, which tie
-        if (kk > 0) {
-            for (int i = threadIdx.x; i < m; i += kMergeThreads) {
-                const vqa_key v = keys[i];
-                if (v > prefix) win[atomicAdd(&sel[2], 1)] = v;
-            }
-        }
-        __syncthreads();
-        if (kk > 0) {
-            for (int i = threadIdx.x; i < m; i += kMergeThreads) {
-                const vqa_key v = keys[i];
-                if (v == prefix) {
-                    const int sl = atomicAdd(&sel[2], 1);
-                    if (sl < kk) win[sl] = v;
-                }
-            }
-        }
-        __syncthreads();
-        // order the kk winners (best first) by rank counting; the slots behind them are empty
-        for (int t0 = 0; t0 < k; t0 += kMergeThreads) {
-            const int t = t0 + threadIdx.x;
-            vqa_key mine = 0ull;
-            int rank = t;
-            if (t < kk) {
-                mine = win[t];
-                rank = 0;
-                for (int j = 0; j < kk; ++j) rank += (win[j] > mine || (win[j] == mine && j < t)) ? 1 : 0;
-            }
-            // (every chunk reads the unsorted array: the sorted one goes to `keys`, which nobody needs any more, and is copied back)
-            if (t < k) keys[rank] = mine;
-        }
-        __syncthreads();
-        for (int t = threadIdx.x; t < k; t += kMergeThreads) win[t] = keys[t];
+        // large k: radix descent to the k-th key instead of k selection rounds (select_topk_radix)
+        select_topk_radix(keys, m, k, win, reinterpret_cast<int*>(win + k));
     } else {
     vqa_key prev = ~0ull;
     for (int r = 0; r < k; ++r) {
@@ -364,6 +369,9 @@ __global__ __launch_bounds__(kMergeThreads) void merge_shards_kernel(const float
                                                              : vqa_make_key(scores[(size_t)r * score_rank_stride + src], (uint32_t)i);
     }
     __syncthreads();
+    if (k_out >= kRadixSelectK && m >= k_out) {
+        select_topk_radix(keys, m, k_out, win, reinterpret_cast<int*>(win + k_out));
+    } else {
     vqa_key prev = ~0ull;
     for (int r = 0; r < k_out; ++r) {
         vqa_key best = 0ull;
@@ -374,6 +382,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_shards_kernel(const float
         best = block_max_key(best, red, r);
         if (threadIdx.x == 0) win[r] = best;  // written out after the last round (no global round trip inside a round: see merge_partials)
         prev = best;
+    }
     }
     __syncthreads();
     for (int r = threadIdx.x; r < k_out; r += kMergeThreads) {
@@ -475,7 +484,8 @@ extern "C" int vqa_merge_topk(const float* scores, const int64_t* ids, int64_t s
     VQA_REQUIRE(score_rank_stride >= (int64_t)B * k && id_rank_stride >= (int64_t)B * k,
                 "vqa_merge_topk: rank strides %lld / %lld are smaller than one [B, k] block", (long long)score_rank_stride,
                 (long long)id_rank_stride);
-    const size_t lds = ((size_t)R * k + 8 + (size_t)k_out) * sizeof(vqa_key);  // keys, 4 reduction slots, k_out winners: above the 64 KiB default near the R * k = 8192 limit
+    // keys, 2 x 4 reduction slots, k_out winners, the radix selection's histogram: above the 64 KiB default near the R * k = 8192 limit
+    const size_t lds = ((size_t)R * k + 8 + (size_t)k_out) * sizeof(vqa_key) + (256 + 4) * sizeof(int);
     if (lds > 64 * 1024) {
         static VqaPerDeviceOnce once;
         int rc = once.run([&](int) -> int {
