@@ -33,32 +33,49 @@ def test_bench_prints_one_json_line_with_the_contract_keys(native_lib):
     assert rf["step_bytes_moved"] >= 300000 * 768 * 2 and 0 < rf["step_frac_physical"] < 1 and "qps_over_hbm_roofline_qps" in rf
     oc = r["other_configs"]
     assert {"own_encoder_outputs", "clusters_1000"} <= set(oc["non_isotropic"]) and {"minilm_l12_h384_dh32", "xlmr_base_h768_dh64"} <= set(oc["reference_model_shapes"])
+    # the other BASELINE configs are oracle-checked on the index that is timed, over all of its rows
+    f8, f32 = oc["fp8_e4m3"], oc["fp32_1M_plus_encoder"]
+    assert f8["recall_check"]["ok"] and f8["recall_check"]["stored_codes_equal_oracle_codes"] and f8["rows"] == 300000
+    assert f8["recall_check"]["sampled_rows"] >= 1024 and f8["recall_check"]["queries"] == 256
+    assert f32["recall_at_10"] == 1.0 and f32["recall_check"]["rows"] == f32["rows"] == 300000 and f32["recall_check"]["max_abs_score_err"] < 1e-5
     sm = r["step_ms"]
     assert sm["p10"] <= sm["median"] <= sm["p90"]
     e2e = r["end_to_end"]
     assert e2e["value"] > 0 and e2e["encoder_roofline"]["bound"] == "mfma" and 0 < e2e["encoder_roofline"]["frac"] < 1
 
 
-def test_bench_two_ranks_sharing_the_device(native_lib):
-    """bench.py's N > 1 path as the driver launches it (torch.distributed.run, one JSON line from rank 0), on the 1-GPU box:
+def test_bench_two_ranks_started_by_bench_itself(native_lib):
+    """`python bench.py --gpus 2` with NO launcher (how the driver starts the 1-GPU run, with N = 2): bench.py spawns its own
+    torch.distributed.run child before touching the GPU, relays rank 0's one JSON line and the exit code.  On the 1-GPU box
     VQA_BENCH_SHARE_GPU=1 puts both ranks on cuda:0 over gloo.  The row-sharded searcher, the all-gather, the merge, the
-    max-over-ranks timing and the end-to-end leg on every rank all run."""
-    import socket
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    env = dict(os.environ, VQA_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--docs-per-gpu",
+    max-over-ranks timing, the per-phase event times and the end-to-end leg on every rank all run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(VQA_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--docs-per-gpu",
                           "200000", "--steps", "4", "--warmup", "2", "--verify-queries", "4", "--e2e-steps", "3"],
                          capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    assert len(lines) == 1 and len(out.stdout.splitlines()) == 1  # stdout carries the JSON line and nothing else
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["config"]["docs_total"] == 400000 and r["scaling"] == "weak"
     assert r["recall_at_10"] == 1.0 and "cpu_baseline" not in r  # the CPU baseline is an N = 1 leg
     assert r["roofline"]["launches"] == 1 and r["end_to_end"]["value"] > 0
+    mg = r["multi_gpu"]
+    assert mg["world_size"] == 2 and mg["backend"].startswith("gloo") and mg["device_count"] >= 1 and mg["collectives_per_step"] == 1
+    pr = mg["per_rank_ms_per_step"]
+    assert len(pr["by_rank"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - r["ms_per_step"]) < 1e-3
+    for phase in ("local_search_ms", "gather_wait_ms", "merge_ms"):
+        assert 0 <= mg["phase_ms"][phase]["min"] <= mg["phase_ms"][phase]["max"]
+    assert mg["phase_ms"]["local_search_ms"]["rank0"] > 0
+
+
+def test_bench_more_gpus_than_the_node_has_is_a_clear_error(native_lib):
+    """A bare `--gpus 64` on a box with fewer devices (and no share flag) ends with a message and exit code 2 before any rank starts."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "VQA_BENCH_SHARE_GPU")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert out.returncode == 2 and "GPU(s)" in out.stderr and out.stdout.strip() == ""
 
 
 def test_bench_eight_ranks_sharing_the_device(native_lib):
@@ -81,3 +98,5 @@ def test_bench_eight_ranks_sharing_the_device(native_lib):
     assert r["config"]["parallelism"] == "row-shard x8" and r["recall_at_10"] == 1.0 and "cpu_baseline" not in r
     assert r["roofline"]["launches"] == 1 and r["end_to_end"]["value"] > 0
     assert r["pipelined"]["value"] > 0 and r["pipelined"]["batches"] >= 2
+    mg = r["multi_gpu"]
+    assert mg["world_size"] == 8 and len(mg["per_rank_ms_per_step"]["by_rank"]) == 8 and mg["collectives_per_step"] == 1

@@ -77,15 +77,31 @@ class ShardedSearcher:
         recv_s = recv[:, 8 * n:12 * n].view(torch.float32).unflatten(1, (b, k))
         return send, recv, (send_s, send_i, recv_s, recv_i)
 
-    def search(self, queries: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    def search(self, queries: torch.Tensor, k: int, stamps=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """One batch: shard search -> all-gather -> merge.  ``stamps`` (bench / profiling only): four ``torch.cuda.Event``s
+        recorded on the current stream before the shard search, after it, after the all-gather (the current stream has
+        waited for RCCL's stream by then) and after the merge -- the three phases of a step as the device saw them."""
         b = int(queries.shape[0])
         send, recv, (send_s, send_i, recv_s, recv_i) = self._buffers(b, k, self._device(queries))
+        if stamps is not None:
+            stamps[0].record()
         self.local_search(queries, k, send_s, send_i)
+        if stamps is not None:
+            stamps[1].record()
         if not self.collective:
-            return send_s.clone(), send_i.clone()
+            out = send_s.clone(), send_i.clone()
+            if stamps is not None:
+                stamps[2].record()
+                stamps[3].record()
+            return out
         self.collectives += 1
         dist.all_gather_into_tensor(recv.view(-1), send, group=self.group)  # the one exchange step
-        return self.merge(recv_s, recv_i, k)
+        if stamps is not None:
+            stamps[2].record()
+        out = self.merge(recv_s, recv_i, k)
+        if stamps is not None:
+            stamps[3].record()
+        return out
 
     def search_pipelined(self, batches, k: int):
         """Several query batches back to back with the exchange of batch i hidden under the scan of batch i + 1 (SURVEY.md
