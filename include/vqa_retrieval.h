@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VQA_VERSION 107 /* 0.1.7: vqa_index_get_sketch_split; 0.1.6: vqa_index_sketch_stats, vqa_index_get_sketch_tile; 0.1.5: vqa_index_sketch_state; 0.1.4: VQA_INDEX_RESCORE_ROWS, vqa_index_device_bytes; 0.1.3: VQA_INDEX_SKETCH */
+#define VQA_VERSION 108 /* 0.1.8: vqa_encoder_forward_hidden; 0.1.7: vqa_index_get_sketch_split; 0.1.6: vqa_index_sketch_stats, vqa_index_get_sketch_tile; 0.1.5: vqa_index_sketch_state; 0.1.4: VQA_INDEX_RESCORE_ROWS, vqa_index_device_bytes; 0.1.3: VQA_INDEX_SKETCH */
 
 /* error codes */
 #define VQA_OK 0
@@ -235,6 +235,15 @@ void vqa_encoder_destroy(vqa_encoder* enc);
  * report it without a synchronisation). */
 int vqa_encoder_forward(vqa_encoder* enc, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L,
                         int32_t real_tokens, int32_t pooling, int32_t normalize, float* out, void* hip_stream);
+
+/* Hidden states of the same forward (HF `output_hidden_states`: transformers BaseModelOutput.hidden_states[n_layers], what
+ * `q_model(input_ids)` of src/test.py:84-86 carries beside .pooler_output): the embedding output (n_layers = 0) or the output of layer
+ * n_layers (1 .. layers; n_layers = layers: last_hidden_state), every position, LayerNorm applied, as fp32 [B, L, hidden] on the device.
+ * Runs the kernels, tile shapes and folded LayerNorms a vqa_encoder_forward of this (B, L, real_tokens) runs, eagerly (no graph).
+ * real_tokens as in vqa_encoder_forward; in the packed form padding positions are not computed and come back as zeros.  This is how the
+ * parity tests hold the HIP layers -- not only the pooled vector -- to the HF goldens (tests/test_gpu_encoder.py). */
+int vqa_encoder_forward_hidden(vqa_encoder* enc, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L,
+                               int32_t real_tokens, int32_t n_layers, float* out_hidden, void* hip_stream);
 
 /* ---- helpers used by the host side when it builds an index from fp32 embeddings ------------------------------
  * rows fp32 [n, d] device -> L2-normalised (optional) -> element type dtype, written to out (device). */

@@ -15,7 +15,10 @@ to the GPU box; only these inputs/outputs and this script are committed).
 * ``enc_minilm_layer.npz`` (round 4): ONE MiniLM-L12-shaped layer (hidden 384, 12 heads of 32, FFN 1536) of HF ``BertModel``:
   ``hidden_in`` / ``attention_mask`` / ``hidden_out``; weights from ``oracle.encoder.synthetic_weights`` (seed 4321), not stored.
 
-    python tests/golden/make_golden_encoder.py
+* ``enc_phobert_hidden.npz`` / ``enc_minilm_hidden.npz`` (round 5): 2-layer models of the two shapes from TOKEN IDS (12 x 32 ragged
+  tokens), HF ``output_hidden_states`` of the first sequences -- the per-layer golden of the HIP encoder (``hidden_states``).
+
+    python tests/golden/make_golden_encoder.py [--hidden-only]
 """
 import os
 import sys
@@ -136,11 +139,47 @@ def minilm_layer():
     np.savez(os.path.join(HERE, "enc_minilm_layer.npz"), hidden_in=hidden_in, attention_mask=mask, hidden_out=out.numpy())
 
 
+def hidden_states(name, cfg, seed, token_seed, b, l, keep, hf_model, hf_cfg):
+    """Round 5: a 2-layer model of a reference shape FROM TOKEN IDS, HF ``output_hidden_states`` -- what the HIP encoder's
+    ``vqa_encoder_forward_hidden`` is held to (the layer goldens above start from arbitrary hidden_in rows, which no sequence of
+    token ids produces).  b x l tokens (384: the HIP side runs its LDS-DMA tile GEMMs with the folded LayerNorms); the hidden
+    states of the first ``keep`` sequences are stored (fp32), weights come from the seeded recipe and are not stored."""
+    w = E.synthetic_weights(cfg, seed=seed, layers=2)
+    model = hf_model(hf_cfg, add_pooling_layer=False).eval()
+    missing, unexpected = model.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=False)
+    assert not unexpected and all("position_ids" in m or "token_type_ids" in m for m in missing), (missing, unexpected)
+    ids, mask = E.synthetic_tokens(cfg, b, l, seed=token_seed)
+    with torch.no_grad():
+        out = model(input_ids=torch.from_numpy(ids).long(), attention_mask=torch.from_numpy(mask).long(), output_hidden_states=True)
+    hs = [h.numpy()[:keep] for h in out.hidden_states]
+    assert len(hs) == 3 and np.array_equal(hs[2], out.last_hidden_state.numpy()[:keep])
+    np.savez(os.path.join(HERE, name), input_ids=ids, attention_mask=mask, hidden_0=hs[0], hidden_1=hs[1], hidden_2=hs[2])
+
+
+def phobert_hidden():
+    cfg = dict(E.PHOBERT_BASE, layers=2, vocab_size=2000)
+    hidden_states("enc_phobert_hidden.npz", cfg, 2024, 5, 12, 32, 3, RobertaModel,
+                  RobertaConfig(vocab_size=2000, hidden_size=768, num_hidden_layers=2, num_attention_heads=12, intermediate_size=3072,
+                                max_position_embeddings=258, type_vocab_size=1, pad_token_id=1, layer_norm_eps=1e-5,
+                                hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))
+
+
+def minilm_hidden():
+    cfg = dict(E.MINILM_L12, layers=2, vocab_size=2000)
+    hidden_states("enc_minilm_hidden.npz", cfg, 2025, 6, 12, 32, 4, BertModel,
+                  BertConfig(vocab_size=2000, hidden_size=384, num_hidden_layers=2, num_attention_heads=12, intermediate_size=1536,
+                             max_position_embeddings=512, type_vocab_size=2, pad_token_id=0, layer_norm_eps=1e-12,
+                             hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0))
+
+
 if __name__ == "__main__":
-    tiny()
-    phobert_layer()
-    bert_tiny()
-    minilm_layer()
+    if "--hidden-only" not in sys.argv:
+        tiny()
+        phobert_layer()
+        bert_tiny()
+        minilm_layer()
+    phobert_hidden()
+    minilm_hidden()
     for f in sorted(os.listdir(HERE)):
         if f.startswith("enc_"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

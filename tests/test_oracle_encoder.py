@@ -79,3 +79,20 @@ def test_minilm_shaped_layer(golden_dir):
     out = E.layer_forward(w, cfg, 0, p["hidden_in"].astype(np.float64), p["attention_mask"])
     real = p["attention_mask"].astype(bool)
     assert np.abs(out - p["hidden_out"])[real].max() < 5e-6
+
+
+def test_two_layer_models_from_token_ids_every_hidden_state(golden_dir):
+    """HF output_hidden_states of 2-layer PhoBERT-base- and MiniLM-L12-shaped models run from token ids (12 x 32 ragged tokens; the
+    first sequences stored): the oracle's embedding output and both layers, real positions."""
+    for name, base, seed in (("enc_phobert_hidden.npz", E.PHOBERT_BASE, 2024), ("enc_minilm_hidden.npz", E.MINILM_L12, 2025)):
+        g = np.load(f"{golden_dir}/{name}")
+        cfg = dict(base, layers=2, vocab_size=2000)
+        w = {k: v.astype(np.float64) for k, v in E.synthetic_weights(cfg, seed=seed, layers=2).items()}
+        keep = g["hidden_0"].shape[0]
+        ids, mask = g["input_ids"][:keep], g["attention_mask"][:keep]
+        real = mask.astype(bool)
+        x = E.embed(w, cfg, ids)
+        assert np.abs(x - g["hidden_0"])[real].max() < 5e-6
+        for i in (0, 1):
+            x = E.layer_forward(w, cfg, i, x, mask)
+            assert np.abs(x - g[f"hidden_{i + 1}"])[real].max() < 2e-5, (name, i)

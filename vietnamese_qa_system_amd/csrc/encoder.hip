@@ -1430,6 +1430,31 @@ __global__ __launch_bounds__(256) void pool_normalize_kernel(const _Float16* __r
     }
 }
 
+// hidden states for a caller (vqa_encoder_forward_hidden = HF `output_hidden_states`): row t of the activation array (packed or padded)
+// -> fp32 row (seq, l) of out [B, L, H]; stats != nullptr: x holds raw rows whose LayerNorm is folded into the GEMMs, applied here.
+// One wave per row.
+__global__ __launch_bounds__(256) void export_hidden_kernel(const _Float16* __restrict__ x, int T, int L, int H, const int* __restrict__ cu,
+                                                            const int* __restrict__ row_seq, int B, const float2* __restrict__ stats,
+                                                            int st_stride, int p, const float* __restrict__ g, const float* __restrict__ b,
+                                                            float eps, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= T) return;
+    size_t dst = (size_t)t;
+    if (cu) {
+        if (t >= cu[B]) return;
+        const int seq = row_seq[t];
+        dst = (size_t)seq * L + (t - cu[seq]);
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (stats) row_stats(stats, (size_t)st_stride, (size_t)t, p, lane, 1.0f / H, eps, mean, rstd);
+    for (int j = lane; j < H; j += 64) {
+        float v = (float)x[(size_t)t * H + j];
+        if (stats) v = (v - mean) * rstd * g[j] + b[j];
+        out[dst * H + j] = v;
+    }
+}
+
 }  // namespace
 
 struct vqa_encoder {
@@ -1923,8 +1948,11 @@ static void launch_ln(const _Float16* a, int T, int H, const float* g, const flo
 }
 
 // the launch sequence of one forward pass (no validation, no allocation, no synchronisation: capturable)
+// hidden_out != nullptr (vqa_encoder_forward_hidden): run `stop_layers` layers only, write the hidden state of every position as
+// fp32 [B, L, H] and return without pooling.
 static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L,
-                          int32_t real_tokens, int32_t pooling, int32_t normalize, float* out, hipStream_t s) {
+                          int32_t real_tokens, int32_t pooling, int32_t normalize, float* out, hipStream_t s,
+                          int stop_layers = -1, float* hidden_out = nullptr) {
     const int H = e->cfg.hidden, F = e->cfg.ffn, heads = e->cfg.heads, dh = H / heads;
     // real_tokens > 0: the caller states how many mask entries are set (right-padded masks): only those rows are computed
     const bool packed = real_tokens > 0 && real_tokens < B * L && att_mfma_head_size(dh) && L <= 32 * kAttMaxBlocks;
@@ -1934,7 +1962,7 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
     const int row_blocks = (T + 3) / 4;
     // CLS pooling of a large batch: the last layer's out-projection / FFN / LayerNorms only on the first-token rows (below);
     // small calls are launch-bound and keep the plain sequence (VQA_ENC_FIRST_ROWS=0 at create: dev / test switch)
-    const bool first_rows_only = e->first_rows_on && pooling == VQA_POOL_CLS && T >= kTileMinM && T >= 2 * B && H % 8 == 0 && !e->layers.empty() &&
+    const bool first_rows_only = hidden_out == nullptr && e->first_rows_on && pooling == VQA_POOL_CLS && T >= kTileMinM && T >= 2 * B && H % 8 == 0 && !e->layers.empty() &&
                                  (size_t)B * (3 * H + F) <= (size_t)e->max_tokens * F;  // the scratch fits the FFN array
     if (packed) {
         hipLaunchKernelGGL(pack_kernel, dim3(1), dim3(256), 0, s, attn_mask, B, L, real_tokens, e->cu, e->row_seq, e->bad_ids_dev);
@@ -1959,7 +1987,9 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
     if (attn_lds > 64 * 1024)
         VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_lds));
+    int layers_done = 0;
     for (const vqa_encoder::Layer& Ly : e->layers) {
+        if (hidden_out && layers_done++ == stop_layers) break;
         int rc;
         if (fold) rc = launch_gemm_fold<0>(e->x, Ly.wqkv_f, Ly.bqkv_f, nullptr, e->qkv, T, 3 * H, H,
                                            FoldArgs{e->st_x, p_x, st_stride, inv_h, eps, Ly.cqkv, nullptr, nullptr, nullptr}, s);
@@ -2053,10 +2083,48 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
         launch_ln(e->tmp, T, H, Ly.ln2_g, Ly.ln2_b, eps, e->x, s);
         VQA_HIP_CHECK(hipGetLastError());
     }
+    if (hidden_out) {
+        if (packed) VQA_HIP_CHECK(hipMemsetAsync(hidden_out, 0, (size_t)B * L * H * sizeof(float), s));  // padding positions: not computed
+        hipLaunchKernelGGL(export_hidden_kernel, dim3(row_blocks), dim3(256), 0, s, e->x, T, L, H, cu, e->row_seq, B,
+                           fold ? e->st_x : (const float2*)nullptr, st_stride, p_x, pg, pb, eps, hidden_out);
+        VQA_HIP_CHECK(hipGetLastError());
+        return VQA_OK;
+    }
     hipLaunchKernelGGL(pool_normalize_kernel, dim3((B + 3) / 4), dim3(256), 0, s, e->x, attn_mask, B, L, H, pooling, normalize, cu, out,
                        fold ? e->st_x : (const float2*)nullptr, st_stride, p_x, pg, pb, eps);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
+}
+
+namespace {
+struct EncBusy {  // the handle's staging buffers, activations and graphs are shared: a second concurrent call is refused
+    std::atomic_flag& f;
+    bool ok;
+    explicit EncBusy(std::atomic_flag& flag) : f(flag), ok(!flag.test_and_set(std::memory_order_acquire)) {}
+    ~EncBusy() {
+        if (ok) f.clear(std::memory_order_release);
+    }
+};
+}  // namespace
+
+extern "C" int vqa_encoder_forward_hidden(vqa_encoder* e, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L,
+                                          int32_t real_tokens, int32_t n_layers, float* out_hidden, void* hip_stream) {
+    VQA_REQUIRE(e, "vqa_encoder_forward_hidden: encoder is null");
+    VQA_REQUIRE(input_ids && attn_mask && out_hidden, "vqa_encoder_forward_hidden: null pointer");
+    VQA_REQUIRE(B >= 1 && L >= 1, "vqa_encoder_forward_hidden: B=%d L=%d", B, L);
+    VQA_REQUIRE((long long)B * L <= e->max_tokens, "vqa_encoder_forward_hidden: B*L=%lld exceeds the workspace of %d tokens",
+                (long long)B * L, e->max_tokens);
+    const int last_pos = e->cfg.position_ids == VQA_POS_ABSOLUTE ? L - 1 : L + e->cfg.pad_id;
+    VQA_REQUIRE(last_pos < e->cfg.max_pos, "vqa_encoder_forward_hidden: L=%d needs position %d, the table has %d rows", L, last_pos,
+                e->cfg.max_pos);
+    VQA_REQUIRE(n_layers >= 0 && n_layers <= e->cfg.layers, "vqa_encoder_forward_hidden: n_layers=%d outside [0, %d]", n_layers, e->cfg.layers);
+    VQA_REQUIRE(real_tokens >= 0 && (long long)real_tokens <= (long long)B * L,
+                "vqa_encoder_forward_hidden: real_tokens=%d outside [0, B*L=%lld]", real_tokens, (long long)B * L);
+    EncBusy busy(e->busy);
+    VQA_REQUIRE(busy.ok, "vqa_encoder_forward_hidden: this encoder handle is in use by another host thread");
+    DevGuard guard(e->device);
+    // always the eager launch sequence (the same kernels, tile shapes and folded LayerNorms a forward of this shape runs; no graph)
+    return encoder_launch(e, input_ids, attn_mask, B, L, real_tokens, VQA_POOL_MEAN, 0, nullptr, (hipStream_t)hip_stream, n_layers, out_hidden);
 }
 
 extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L,
@@ -2072,14 +2140,7 @@ extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, con
     VQA_REQUIRE(real_tokens >= 0 && (long long)real_tokens <= (long long)B * L, "vqa_encoder_forward: real_tokens=%d outside [0, B*L=%lld]",
                 real_tokens, (long long)B * L);
     hipStream_t s = (hipStream_t)hip_stream;
-    struct Busy {  // the handle's staging buffers, activations and graphs are shared: a second concurrent call is refused
-        std::atomic_flag& f;
-        bool ok;
-        explicit Busy(std::atomic_flag& flag) : f(flag), ok(!flag.test_and_set(std::memory_order_acquire)) {}
-        ~Busy() {
-            if (ok) f.clear(std::memory_order_release);
-        }
-    } busy(e->busy);
+    EncBusy busy(e->busy);
     VQA_REQUIRE(busy.ok, "vqa_encoder_forward: this encoder handle is in use by another host thread (one forward at a time per handle)");
     if (__atomic_load_n(e->bad_ids_host, __ATOMIC_RELAXED)) {
         __atomic_store_n(e->bad_ids_host, 0, __ATOMIC_RELAXED);

@@ -155,6 +155,35 @@ class QuestionEncoder:
 
     __call__ = forward
 
+    def hidden_states(self, input_ids, attention_mask, n_layers: Optional[int] = None, *,
+                      real_tokens: Optional[int] = None) -> torch.Tensor:
+        """Hidden state of every position after ``n_layers`` layers (``None``: all = HF ``last_hidden_state``; 0: the embedding
+        output) as a [B, L, hidden] fp32 cuda tensor -- HF ``output_hidden_states[n_layers]``.  Same kernels as :meth:`forward`
+        of this shape; with a right-padded host mask (or ``real_tokens``) the packed form runs and padding positions are zeros."""
+        if not self._handle.value:
+            raise RuntimeError("encoder is closed")
+        dev = torch.device("cuda", self.device)
+        ids = torch.as_tensor(np.asarray(input_ids) if not isinstance(input_ids, torch.Tensor) else input_ids)
+        mask = torch.as_tensor(np.asarray(attention_mask) if not isinstance(attention_mask, torch.Tensor) else attention_mask)
+        if ids.dim() != 2 or mask.shape != ids.shape:
+            raise ValueError("input_ids and attention_mask must both be [B, L]")
+        if real_tokens is None:
+            real_tokens = 0
+            if not mask.is_cuda and mask.numel():
+                m = mask != 0
+                right_padded = bool(m[:, 0].all()) and bool((m[:, :-1] >= m[:, 1:]).all())
+                real_tokens = int(m.sum()) if right_padded else 0
+        n_layers = int(self.config["layers"]) if n_layers is None else int(n_layers)
+        ids = ids.to(dev, dtype=torch.int32).contiguous()
+        mask = mask.to(dev, dtype=torch.int32).contiguous()
+        b, l = int(ids.shape[0]), int(ids.shape[1])
+        with torch.cuda.device(dev):
+            out = torch.empty((b, l, int(self.config["hidden"])), dtype=torch.float32, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            N.check(self._lib.vqa_encoder_forward_hidden(self._handle, ids.data_ptr(), mask.data_ptr(), b, l, int(real_tokens),
+                                                         n_layers, out.data_ptr(), stream), "vqa_encoder_forward_hidden")
+        return out
+
 
 class TextEncoder:
     """``list[str] -> [B, hidden]`` hook for ``Embeddings(encoder=...)``: a host tokenizer + the HIP encoder.
