@@ -1,0 +1,128 @@
+"""``Embeddings(path=<local model directory>)`` (heavy_ranker.py:78-83): the loader of Hugging Face / sentence-transformers
+directories -- host logic here (safetensors container, prefix stripping, config mapping, pooling from modules.json); the
+``-m gpu`` half runs the loaded model on the device and holds it to the HF outputs stored beside the same weights."""
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from vietnamese_qa_system_amd import pretrained as P
+
+TINY = dict(vocab_size=100, hidden=64, layers=2, heads=4, ffn=128, max_pos=40, type_vocab=1, pad_id=1, ln_eps=1e-5, position_ids="roberta")
+BERT_TINY = dict(vocab_size=120, hidden=64, layers=2, heads=2, ffn=128, max_pos=48, type_vocab=2, pad_id=0, ln_eps=1e-12,
+                 position_ids="absolute")
+
+
+def _npz_weights(golden_dir, name):
+    g = np.load(f"{golden_dir}/{name}")
+    return g, {k[2:]: g[k] for k in g.files if k.startswith("w.")}
+
+
+def test_sentence_transformers_directory_with_safetensors(golden_dir):
+    w, cfg, pooling, normalize = P.load_pretrained(f"{golden_dir}/hf_tiny_roberta_st")
+    _, ref = _npz_weights(golden_dir, "enc_tiny.npz")
+    assert cfg == TINY and pooling == "mean" and normalize is True
+    assert set(w) == set(ref) and all(np.array_equal(w[k], ref[k]) and w[k].dtype == np.float32 for k in ref)
+
+
+def test_plain_hf_directory_with_prefixed_pytorch_bin(golden_dir):
+    w, cfg, pooling, normalize = P.load_pretrained(f"{golden_dir}/hf_tiny_bert_bin")
+    _, ref = _npz_weights(golden_dir, "enc_bert_tiny.npz")
+    assert cfg == BERT_TINY and pooling is None and normalize is None
+    assert set(w) == set(ref) and all(np.array_equal(w[k], ref[k]) for k in ref)  # pooler / head / position_ids tensors skipped
+
+
+def test_safetensors_reader_dtypes_and_errors(tmp_path):
+    a32 = np.arange(6, dtype=np.float32).reshape(2, 3)
+    a16 = np.array([1.5, -2.0], dtype=np.float16)
+    bf = (np.array([1.0, -0.5, 3.140625], np.float32).view(np.uint32) >> 16).astype("<u2")  # exactly representable in bf16
+    blobs = [("x", "F32", a32.shape, a32.tobytes()), ("y", "F16", a16.shape, a16.tobytes()), ("z", "BF16", (3,), bf.tobytes())]
+    header, off = {"__metadata__": {"format": "pt"}}, 0
+    for name, dt, shape, raw in blobs:
+        header[name] = {"dtype": dt, "shape": list(shape), "data_offsets": [off, off + len(raw)]}
+        off += len(raw)
+    hj = json.dumps(header).encode()
+    path = tmp_path / "m.safetensors"
+    path.write_bytes(struct.pack("<Q", len(hj)) + hj + b"".join(b[3] for b in blobs))
+    t = P.read_safetensors(str(path))
+    assert np.array_equal(t["x"], a32) and np.array_equal(t["y"], a16) and t["z"].dtype == np.float32
+    assert t["z"].tolist() == [1.0, -0.5, 3.140625]
+    path.write_bytes(struct.pack("<Q", len(hj)) + hj + b"\x00" * 5)  # truncated data
+    with pytest.raises(ValueError, match="past the end"):
+        P.read_safetensors(str(path))
+    path.write_bytes(b"\x01\x02")
+    with pytest.raises(ValueError, match="not a safetensors"):
+        P.read_safetensors(str(path))
+
+
+def test_config_mapping_and_refusals(tmp_path):
+    base = {"model_type": "xlm-roberta", "vocab_size": 250002, "hidden_size": 768, "num_hidden_layers": 12, "num_attention_heads": 12,
+            "intermediate_size": 3072, "max_position_embeddings": 514, "type_vocab_size": 1, "pad_token_id": 1, "layer_norm_eps": 1e-5}
+    from vietnamese_qa_system_amd.encoder import MINILM_L12, XLMR_BASE
+    assert P.encoder_config_from_hf(base) == dict(XLMR_BASE, position_ids="roberta")
+    minilm = {"model_type": "bert", "vocab_size": 250037, "hidden_size": 384, "num_hidden_layers": 12, "num_attention_heads": 12,
+              "intermediate_size": 1536, "max_position_embeddings": 512, "type_vocab_size": 2, "pad_token_id": 0, "layer_norm_eps": 1e-12}
+    assert P.encoder_config_from_hf(minilm) == MINILM_L12  # paraphrase-multilingual-MiniLM-L12-v2, heavy_ranker.py:80
+    with pytest.raises(ValueError, match="model_type"):
+        P.encoder_config_from_hf(dict(base, model_type="t5"))
+    with pytest.raises(ValueError, match="GELU"):
+        P.encoder_config_from_hf(dict(base, hidden_act="relu"))
+    with pytest.raises(ValueError, match="relative"):
+        P.encoder_config_from_hf(dict(base, position_embedding_type="relative_key"))
+    with pytest.raises(FileNotFoundError, match="not a directory"):
+        P.load_pretrained("sentence-transformers/paraphrase-multilingual-MiniLM-L12-v2")  # a hub name: nothing to fetch it with
+    (tmp_path / "config.json").write_text(json.dumps(base))
+    with pytest.raises(FileNotFoundError, match="safetensors"):
+        P.load_pretrained(str(tmp_path))
+    # a pooling mix the encoder does not implement is refused, not approximated
+    os.makedirs(tmp_path / "1_Pooling")
+    (tmp_path / "modules.json").write_text(json.dumps([{"path": "", "type": "sentence_transformers.models.Transformer"},
+                                                       {"path": "1_Pooling", "type": "sentence_transformers.models.Pooling"}]))
+    (tmp_path / "1_Pooling" / "config.json").write_text(json.dumps({"pooling_mode_cls_token": True, "pooling_mode_max_tokens": True}))
+    with pytest.raises(ValueError, match="pooling modes"):
+        P.load_pretrained(str(tmp_path))
+
+
+@pytest.mark.gpu
+def test_embeddings_loads_the_model_named_by_path(native_lib, golden_dir):
+    """heavy_ranker.py:78-83 in miniature: Embeddings(content=True, path=<directory>) -> index(texts) -> search(text).  The HIP
+    encoder built from the directory reproduces HF's last_hidden_state of the same weights (enc_tiny.npz) and its mean-pooled,
+    L2-normalised vectors drive the search."""
+    import torch
+    from oracle import encoder as E
+    from vietnamese_qa_system_amd import Embeddings
+    from vietnamese_qa_system_amd.encoder import QuestionEncoder
+    g, w = _npz_weights(golden_dir, "enc_tiny.npz")
+    ids, mask = g["input_ids"], g["attention_mask"]
+    enc = QuestionEncoder.from_pretrained(f"{golden_dir}/hf_tiny_roberta_st", max_tokens=64)
+    assert enc.pooling == "mean" and enc.normalize is True and enc.config == TINY
+    real = mask.astype(bool)
+    hs = enc.hidden_states(ids, mask).cpu().numpy()
+    assert np.abs(hs[real] - g["last_hidden_state"][real]).max() < 2.4e-2  # tests/test_gpu_encoder.py BOUNDS["tiny_hidden"]
+    enc.close()
+    table = {f"text {i}": (ids[i], mask[i]) for i in range(ids.shape[0])}
+
+    def tokenizer(texts):
+        return np.stack([table[t][0] for t in texts]), np.stack([table[t][1] for t in texts])
+
+    emb = Embeddings(content=True, path=f"{golden_dir}/hf_tiny_roberta_st", tokenizer=tokenizer, max_tokens=64, min_score=None)
+    emb.index([{"id": 10 + i, "text": f"text {i}", "source": "s"} for i in range(4)])
+    assert emb.pooling == "mean"
+    ref = E.encode({k: np.asarray(v, np.float64) for k, v in w.items()}, TINY, ids, mask, pooling="mean")
+    for i in range(4):
+        hit = emb.search(f"text {i}", 1)[0]
+        assert hit["id"] == 10 + i and hit["text"] == f"text {i}" and abs(hit["score"] - 1.0) < 2e-3
+    res = emb.search("text 2", 4)
+    want = np.argsort(-(ref @ ref[2]))
+    assert [r["id"] for r in res] == [10 + int(j) for j in want]
+    # the BERT directory (prefixed pytorch_model.bin, no modules.json): pooling stays what the caller asked for
+    gb, _ = _npz_weights(golden_dir, "enc_bert_tiny.npz")
+    encb = QuestionEncoder.from_pretrained(f"{golden_dir}/hf_tiny_bert_bin", max_tokens=64)
+    assert encb.pooling is None and encb.config == BERT_TINY
+    got = encb.forward(gb["input_ids"], gb["attention_mask"], pooling="mean", normalize=False).cpu().numpy()
+    assert np.abs(got - gb["mean_pooled"]).max() < 1.2e-2  # BOUNDS["tiny_raw"]
+    encb.close()
+    with pytest.raises(RuntimeError, match="hub names"):
+        Embeddings(path="sentence-transformers/paraphrase-multilingual-MiniLM-L12-v2").index([{"id": 1, "text": "q"}])

@@ -62,9 +62,16 @@ class Embeddings:
     def __init__(self, config: Optional[dict] = None, *, path: Optional[str] = None, content: bool = False,
                  hybrid: bool = False, dtype: str = "fp16", device: Optional[int] = None, pooling: str = "mean",
                  normalize: bool = True, encoder: Optional[Callable[[List[str]], torch.Tensor]] = None,
-                 min_score: Optional[float] = 0.0, group=None):
+                 min_score: Optional[float] = 0.0, group=None, tokenizer=None, max_tokens: int = 1024 * 32):
+        """``path`` (``heavy_ranker.py:78-83``): a LOCAL model directory (Hugging Face / sentence-transformers layout) is loaded
+        into the HIP question encoder (:meth:`QuestionEncoder.from_pretrained`) when the first text is encoded -- pooling and
+        normalisation as its ``modules.json`` says, else the ``pooling`` / ``normalize`` arguments.  ``tokenizer``:
+        ``texts -> (input_ids, attention_mask)``; default: ``transformers.AutoTokenizer`` of the same directory (host side).  A
+        path that is not a directory (a hub name) is only recorded: there is no network to resolve it."""
         cfg = dict(config or {})
         self.path = cfg.get("path", path)
+        self.tokenizer = tokenizer
+        self.max_tokens = int(max_tokens)
         self.content = bool(cfg.get("content", content))
         self.hybrid = bool(cfg.get("hybrid", hybrid))
         self.dtype = cfg.get("dtype", dtype)
@@ -113,9 +120,33 @@ class Embeddings:
             out.append(d)
         return out
 
+    def _encoder_from_path(self):
+        """``path=<local model directory>`` -> ``TextEncoder`` over the HIP encoder (built once, on first use)."""
+        from .encoder import QuestionEncoder, TextEncoder
+        enc = QuestionEncoder.from_pretrained(self.path, device=self.device, max_tokens=self.max_tokens)
+        tok = self.tokenizer
+        if tok is None:
+            try:
+                from transformers import AutoTokenizer  # host-side tokenisation only; the forward is ours
+            except ImportError as e:  # pragma: no cover
+                raise RuntimeError("no tokenizer= was given and transformers is not importable for AutoTokenizer") from e
+            hf_tok = AutoTokenizer.from_pretrained(self.path)
+            cap = max(8, min(128, int(enc.config["max_pos"]) - 2 - int(enc.config["pad_id"])))
+
+            def tok(texts):
+                e = hf_tok(list(texts), padding=True, truncation=True, max_length=cap, return_tensors="np")
+                return e["input_ids"], e["attention_mask"]
+        if enc.pooling is not None:
+            self.pooling = enc.pooling
+        # (txtai L2-normalises every embedding whatever the model's own modules say: cosine = inner product of unit rows)
+        return TextEncoder(tok, enc, pooling=self.pooling, normalize=self.normalize or bool(enc.normalize))
+
     def _encode(self, texts: List[str]) -> torch.Tensor:
+        if self.encoder is None and self.path and os.path.isdir(str(self.path)):
+            self.encoder = self._encoder_from_path()
         if self.encoder is None:
-            raise RuntimeError("this Embeddings object has no text encoder: pass encoder= (see encoder.TextEncoder) "
+            raise RuntimeError("this Embeddings object has no text encoder: pass encoder= (see encoder.TextEncoder), a path= that is "
+                               f"a local model directory (path={self.path!r} is not one: hub names cannot be fetched here), "
                                "or index/search with vectors")
         v = self.encoder(texts)
         if not isinstance(v, torch.Tensor) or v.dim() != 2 or v.shape[0] != len(texts):

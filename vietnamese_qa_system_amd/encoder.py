@@ -59,6 +59,9 @@ class QuestionEncoder:
         self.device = int(device)
         self.config = dict(config)
         self.max_tokens = int(max_tokens)
+        self.pooling: Optional[str] = None      # set by from_pretrained (sentence-transformers modules.json)
+        self.normalize: Optional[bool] = None
+        self.model_dir: Optional[str] = None
         keep = []  # host copies kept alive until vqa_encoder_create returns
 
         def ptr(name: str, shape: Tuple[int, ...]) -> int:
@@ -101,6 +104,19 @@ class QuestionEncoder:
             N.check(self._lib.vqa_encoder_create(ctypes.byref(self._handle), self.device, ctypes.byref(cfg), ctypes.byref(top),
                                                  self.max_tokens), "vqa_encoder_create")
         del keep
+
+    @classmethod
+    def from_pretrained(cls, model_dir: str, *, device: int = 0, max_tokens: int = 1024 * 32) -> "QuestionEncoder":
+        """The encoder of a LOCAL Hugging Face / sentence-transformers model directory (``config.json`` + ``model.safetensors`` or
+        ``pytorch_model.bin``; what the reference names by ``path=`` at ``heavy_ranker.py:80,83``).  The returned object carries
+        ``.pooling`` / ``.normalize`` as the directory's ``modules.json`` prescribes them (``None`` when it says nothing)."""
+        from .pretrained import load_pretrained
+        weights, cfg, pooling, normalize = load_pretrained(model_dir)
+        if int(cfg["max_pos"]) < 2:
+            raise ValueError("max_position_embeddings < 2")
+        enc = cls(weights, cfg, device=device, max_tokens=max_tokens)
+        enc.pooling, enc.normalize, enc.model_dir = pooling, normalize, model_dir
+        return enc
 
     def close(self) -> None:
         if getattr(self, "_handle", None) is not None and self._handle.value:
