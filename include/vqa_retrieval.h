@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VQA_VERSION 108 /* 0.1.8: vqa_encoder_forward_hidden; 0.1.7: vqa_index_get_sketch_split; 0.1.6: vqa_index_sketch_stats, vqa_index_get_sketch_tile; 0.1.5: vqa_index_sketch_state; 0.1.4: VQA_INDEX_RESCORE_ROWS, vqa_index_device_bytes; 0.1.3: VQA_INDEX_SKETCH */
+#define VQA_VERSION 109 /* 0.1.9: vqa_index_options / vqa_index_create_ex, vqa_encoder_options / vqa_encoder_create_ex (no environment variable is read any more), vqa_launch_info.levels; 0.1.8: vqa_encoder_forward_hidden; 0.1.7: vqa_index_get_sketch_split; 0.1.6: vqa_index_sketch_stats, vqa_index_get_sketch_tile; 0.1.5: vqa_index_sketch_state; 0.1.4: VQA_INDEX_RESCORE_ROWS, vqa_index_device_bytes; 0.1.3: VQA_INDEX_SKETCH */
 
 /* error codes */
 #define VQA_OK 0
@@ -83,6 +83,47 @@ const char* vqa_last_error(void);
  * a 15-123 GB shard never needs a second full copy; it synchronises before returning. */
 int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t d, int32_t dtype, const void* rows, int32_t rows_dtype,
                      const int64_t* ids_or_null, int64_t id_base, uint32_t flags);
+
+/* Every knob of an index handle, explicit and versioned.  The library reads NO environment variable (rounds 1-4 read 22 VQA_* at
+ * create time; a `-DVQA_DEV` build -- scripts/, never the product -- still overlays them on these defaults for A/B runs).
+ * vqa_index_options_init fills in the defaults [in brackets]; a caller changes what it wants and passes the struct to
+ * vqa_index_create_ex.  `struct_size` = sizeof of the struct the caller was compiled against: fields a newer library knows beyond
+ * it keep their defaults.  The production plan is what the defaults give (csrc/capi.hip kPlan: one table, every constant with the
+ * probe that fitted it); the other values exist for tests that must reach a plan at a small size and for A/B measurements.
+ * Nothing but speed depends on any of them: every plan returns the exact top-k of the stored values. */
+typedef struct vqa_index_options {
+    uint32_t struct_size;         /* sizeof(vqa_index_options) */
+    uint32_t flags;               /* VQA_INDEX_* [0] */
+    int32_t two_pass;             /* [1] seed pass (sub-maxima of the first tiles -> starting thresholds) in front of the main pass */
+    int32_t wide_k;               /* [1] k > VQA_MAX_K: one verified pass before the ceil(k / 12) exact passes */
+    int32_t seed_mult;            /* [2] seed pass covers seed_mult x CUs tiles (1..4) ... */
+    int32_t seed_div;             /* [16] ... but at most 1 / seed_div of the shard's tiles (0: no cap) */
+    int32_t stage_min_tiles;      /* [-1: by type -- 24 tiles per compute unit, 16 for an fp16 and 8 for an fp32 shard with a sketch] shard size
+                                   * from which the two-stage / sketch plan applies; 0: never.  Given explicitly (tests at small sizes), the
+                                   * profitability pause is off unless sketch_profit is given too */
+    int32_t stage_pct;            /* [10] share of the first stage, percent (1..50) */
+    int32_t f16_loop;             /* [0] fp16 K loop: 0 anti-phase slots, 1 K-step pairs, 2 pairs for the main launch of a two-stage search */
+    int32_t sketch_cascade;       /* [1] cascade of bounds; 0: round 3's form with an exact first stage (k <= 12) */
+    int32_t sketch_rotate;        /* [1] sketch cut from sign-flipped, block-Hadamard-rotated rows */
+    int32_t sketch_center;        /* [1] ... of centred rows (needs the rotation) */
+    int32_t sketch_split;         /* [1] slack term of the bound split along the centre direction */
+    int32_t sketch_per_row;       /* [-1: auto, ||mu||^2 >= 0.6 mean ||x||^2 at the first fill] 0 / 1 force the per-row form off / on */
+    int32_t sketch_ring_stages;   /* [5] X-ring stages of the int8 scan (6: measured equal) */
+    int32_t sketch_mid_k;         /* [16] a second cascade stage from this k on (0: never) ... */
+    int32_t sketch_mid_min_tiles; /* [128] ... or from this many tiles per workgroup on, whatever k (0: by k only) */
+    int32_t sketch_mid_pct;       /* [200] its size, percent of the first stage */
+    int32_t sketch_pre_k;         /* [48] the first stage's leading quarter as a stage of its own from this k on (0: never) */
+    int32_t sketch_cooldown;      /* [64] base length of the pause after an overflow, in searches (0: no pause) */
+    float sketch_profit;          /* [-1: by type -- 0.75 fp16, 4 fp32] factor f of the profitability rule (pause when a query tile scores
+                                   * more than f n - 4e5 pairs exactly); 0: never */
+    int32_t rescore_copy;         /* with VQA_INDEX_RESCORE_ROWS: [-1] take the copy only if an eighth of the device's memory stays free
+                                   * behind it, 1: whenever the allocation succeeds */
+    int32_t poison_workspace;     /* [-1: no] 0..255: fill every workspace with this byte at create (tests: nothing may read what no launch wrote) */
+} vqa_index_options;
+void vqa_index_options_init(vqa_index_options* opt);
+/* vqa_index_create with explicit options (`flags` travel inside them); opt == NULL: the defaults */
+int vqa_index_create_ex(vqa_index** out, int device, int64_t n, int32_t d, int32_t dtype, const void* rows, int32_t rows_dtype,
+                        const int64_t* ids_or_null, int64_t id_base, const vqa_index_options* opt);
 int vqa_index_set_rows(vqa_index* index, int64_t first, int64_t count, const void* rows, int32_t rows_dtype,
                        const int64_t* ids_or_null);
 /* export (Embeddings.save, heavy_ranker.py:87): rows [first, first + count) back as row-major [count, d] in the STORAGE
@@ -102,10 +143,10 @@ int64_t vqa_index_device_bytes(const vqa_index* index);
  * still returns the exact result -- its exact fallback runs behind it on the device, gated on a flag, no host round trip -- but
  * costs a sketch scan AND an exact scan.  The flags of a call (+ the call's number) are copied to a pinned mirror behind its
  * last launch; a LATER vqa_index_search on the handle that finds the report of a call it has not seen yet, with a flag up, starts
- * a pause: the next VQA_SKETCH_COOLDOWN (default 64) searches run the exact scan only, then the sketch is tried again; every
+ * a pause: the next `sketch_cooldown` (vqa_index_options, default 64) searches run the exact scan only, then the sketch is tried again; every
  * further overflow doubles the pause (up to 64 x), a sketch search that stands resets it.  A search that does not overflow but
  * scores more pairs exactly in one query tile than the scan saves -- more than 0.75 n - 4e5 pairs (fp32 shards: 4 n;
- * VQA_SKETCH_PROFIT sets the factor) -- is treated the same way (dense clusters; a large k on a shard of a million rows): its
+ * vqa_index_options.sketch_profit sets the factor) -- is treated the same way (dense clusters; a large k on a shard of a million rows): its
  * result stands, the following searches of at least HALF its k take the exact scan (a handle that serves k = 100 and k = 10
  * searches alternately on a 1M-row shard keeps the k = 10 ones on the sketch; a pause started by an overflow applies to every k).  The host may run many searches ahead
  * of the device: reports of calls queued before a pause began are ignored, so the reaction lags by the queue depth and never
@@ -180,7 +221,8 @@ typedef struct vqa_launch_info {
                                * k-th best scores seed the main launch's thresholds); 0 = the main launch covers every row */
     int32_t sketch_scan;      /* 1: the main launch scans the int8 sketch (VQA_INDEX_SKETCH): bytes_per_launch counts one byte per
                                * element, flops_per_launch the same multiply-adds (int8 x int8 -> int32) */
-    int32_t pad_;
+    int32_t levels;           /* scans of disjoint row ranges one pass consists of: 1 = one launch over every row; 2 = first stage + main
+                               * launch; sketch cascade: 2 .. 4 (leading quarter | first stage | second stage | the rest) */
 } vqa_launch_info;
 int vqa_index_launch_info(const vqa_index* index, int32_t B, int32_t k, vqa_launch_info* out);
 int vqa_index_set_timing(vqa_index* index, int32_t enabled); /* 0: off (recorded pairs are kept until get_timing), 1: on, from scratch,
@@ -222,6 +264,16 @@ typedef struct vqa_encoder_weights {
 
 int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encoder_config* cfg, const vqa_encoder_weights* w,
                        int32_t max_tokens /* B*L capacity of the activation workspace */);
+/* the encoder's switches, as vqa_index_options: explicit, versioned, defaults in brackets; no environment variable is read */
+typedef struct vqa_encoder_options {
+    uint32_t struct_size; /* sizeof(vqa_encoder_options) */
+    int32_t fold_layernorm; /* [1] calls of > 320 tokens carry raw rows + row statistics and apply the LayerNorms inside the GEMMs; 0: LayerNorm kernels */
+    int32_t first_rows;     /* [1] CLS pooling of a large batch: the last layer past its attention on the first-token rows only */
+    int32_t graphs;         /* [1] calls of <= 1024 positions replay a captured hipGraph */
+} vqa_encoder_options;
+void vqa_encoder_options_init(vqa_encoder_options* opt);
+int vqa_encoder_create_ex(vqa_encoder** out, int device, const vqa_encoder_config* cfg, const vqa_encoder_weights* w, int32_t max_tokens,
+                          const vqa_encoder_options* opt /* NULL: defaults */);
 void vqa_encoder_destroy(vqa_encoder* enc);
 /* input_ids, attn_mask: [B, L] int32 device.  out: [B, hidden] fp32 device.
  * real_tokens: 0 = unknown (every one of the B * L positions is computed), else the number of set mask entries of a

@@ -9,6 +9,7 @@ from vietnamese_qa_system_amd.index import DeviceIndex
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=80_000_000)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--exact", action="store_true", help="no int8 sketch: the exact fp16 scan")
 args = ap.parse_args()
 n, d, b, k = args.n, 768, 256, 10
 dev = torch.device("cuda", 0)
@@ -16,7 +17,7 @@ gen = torch.Generator(device=dev); gen.manual_seed(7)
 q = torch.randn((b, d), generator=gen, device=dev); q = (q / q.norm(dim=1, keepdim=True)).half()
 rng = np.random.default_rng(3)
 needles = np.sort(rng.choice(n, size=64, replace=False))  # query i is planted at row needles[i]
-ix = DeviceIndex.empty(n, d, id_base=1, dtype="fp16", device=0)  # VQA_SKETCH=0 in the environment: the exact scan
+ix = DeviceIndex.empty(n, d, id_base=1, dtype="fp16", device=0, sketch=not args.exact)
 chunk = 1 << 20
 t0 = time.perf_counter()
 for c0 in range(0, n, chunk):

@@ -31,6 +31,41 @@ int main() {
     EXPECT(vqa_index_create(&ix, 0, 10, 8, 7, nullptr, VQA_F16, nullptr, 0, 0) == VQA_EINVAL);
     EXPECT(vqa_index_create(&ix, 0, 10, 8, VQA_F16, nullptr, VQA_F16, nullptr, 0, 0xF0) == VQA_EINVAL);
     EXPECT(vqa_index_create(&ix, 0, (int64_t)1 << 33, 8, VQA_F16, nullptr, VQA_F16, nullptr, 0, 0) == VQA_EINVAL);
+    // explicit options (vqa_index_create_ex): defaults, versioning by struct_size, range checks -- all before any device work
+    {
+        vqa_index_options o;
+        memset(&o, 0xAB, sizeof(o));
+        vqa_index_options_init(&o);
+        EXPECT(o.struct_size == sizeof(o) && o.flags == 0 && o.stage_min_tiles == -1 && o.stage_pct == 10 && o.sketch_cooldown == 64 &&
+               o.sketch_profit < 0.f && o.poison_workspace == -1 && o.rescore_copy == -1 && o.sketch_per_row == -1 && o.seed_mult == 2);
+        vqa_index_options_init(nullptr);
+        vqa_index_options bad_o = o;
+        bad_o.struct_size = 0;
+        EXPECT(vqa_index_create_ex(&ix, 0, 10, 8, VQA_F16, nullptr, VQA_F16, nullptr, 0, &bad_o) == VQA_EINVAL && ix == nullptr);
+        EXPECT(strstr(vqa_last_error(), "struct_size") != nullptr);
+        bad_o = o;
+        bad_o.stage_pct = 99;
+        EXPECT(vqa_index_create_ex(&ix, 0, 10, 8, VQA_F16, nullptr, VQA_F16, nullptr, 0, &bad_o) == VQA_EINVAL);
+        bad_o = o;
+        bad_o.seed_mult = 0;
+        EXPECT(vqa_index_create_ex(&ix, 0, 10, 8, VQA_F16, nullptr, VQA_F16, nullptr, 0, &bad_o) == VQA_EINVAL);
+        bad_o = o;
+        bad_o.poison_workspace = 300;
+        EXPECT(vqa_index_create_ex(&ix, 0, 10, 8, VQA_F16, nullptr, VQA_F16, nullptr, 0, &bad_o) == VQA_EINVAL);
+        bad_o = o;
+        bad_o.flags = 0xF0;
+        EXPECT(vqa_index_create_ex(&ix, 0, 10, 8, VQA_F16, nullptr, VQA_F16, nullptr, 0, &bad_o) == VQA_EINVAL);
+        // an OLDER caller's shorter struct: the fields it does not know keep their defaults (only the prefix is read)
+        vqa_index_options shorter = o;
+        shorter.struct_size = 16;
+        shorter.poison_workspace = 300;  // beyond the prefix: must not be looked at
+        const int rc_short = vqa_index_create_ex(&ix, 0, 10, 8, VQA_F16, nullptr, VQA_F16, nullptr, 0, &shorter);
+        EXPECT(rc_short == VQA_OK || rc_short == VQA_ENODEV || rc_short == VQA_EHIP);
+        if (rc_short == VQA_OK) vqa_index_destroy(ix);
+        vqa_encoder_options eo;
+        vqa_encoder_options_init(&eo);
+        EXPECT(eo.struct_size == sizeof(eo) && eo.fold_layernorm == 1 && eo.first_rows == 1 && eo.graphs == 1);
+    }
     int rc = vqa_index_create(&ix, 0, 1000, 64, VQA_F16, nullptr, VQA_F16, nullptr, 1, 0);
     if (rc == VQA_OK) {  // a device is visible: create / use-after-bad-args / destroy cycles
         for (int i = 0; i < 3; ++i) {

@@ -210,7 +210,8 @@ def main():
     #     131 072 rows per shard): every rank's main launch scans its sketch and re-scores the survivors; the merged result
     #     equals the single-shard sketch search of the concatenated corpus bit for bit -- a row's exact score does not depend on
     #     the shard it sits in, and ties astride shard AND stage boundaries resolve by global row position
-    os.environ["VQA_STAGE_MIN"] = "2"
+    from vietnamese_qa_system_amd import index as index_mod
+    index_mod.DEFAULT_OPTIONS["stage_min_tiles"] = 2  # (vqa_index_options.stage_min_tiles; rounds 1-4: VQA_STAGE_MIN=2 in the environment)
     n3 = 140_000 * world + 3
     x3 = unit(rng, n3, 64)
     b3 = [shard_bounds(n3, world, r) for r in range(world)]
@@ -232,7 +233,7 @@ def main():
     assert i1[0, :min(k, len(tie))].cpu().numpy().tolist() == tie[:k], (i1[0].tolist(), tie)
     one.close()
     e10._index.close()
-    del os.environ["VQA_STAGE_MIN"]
+    del index_mod.DEFAULT_OPTIONS["stage_min_tiles"]
 
     dist.barrier()
     with open(os.path.join(args.out, f"rank{rank}.json"), "w") as f:

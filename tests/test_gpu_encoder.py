@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import set_option
+
 from oracle import encoder as E
 from oracle import retrieval as R
 
@@ -229,7 +231,7 @@ def test_cls_pooling_prunes_the_last_layer_to_first_rows(native_lib, monkeypatch
     ids_d, mask_d = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
     out = {}
     for on in ("1", "0"):
-        monkeypatch.setenv("VQA_ENC_FIRST_ROWS", on)
+        set_option(monkeypatch, "VQA_ENC_FIRST_ROWS", on)
         enc = QuestionEncoder(w, cfg, max_tokens=b * l)
         out[on] = {(p, r): enc.forward(ids_d, mask_d, pooling=p, real_tokens=int(mask.sum()) if r else 0).cpu().numpy()
                    for p in ("cls", "mean") for r in (False, True)}
@@ -261,8 +263,8 @@ def test_folded_layernorms_match_the_layernorm_kernels(native_lib, monkeypatch):
     ids_d, mask_d = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
     out = {}
     for fold, first in (("1", "1"), ("0", "1"), ("1", "0")):
-        monkeypatch.setenv("VQA_ENC_FOLD", fold)
-        monkeypatch.setenv("VQA_ENC_FIRST_ROWS", first)
+        set_option(monkeypatch, "VQA_ENC_FOLD", fold)
+        set_option(monkeypatch, "VQA_ENC_FIRST_ROWS", first)
         enc = QuestionEncoder(w, cfg, max_tokens=b * l)
         out[fold, first] = {(p, r): enc.forward(ids_d, mask_d, pooling=p, real_tokens=int(mask.sum()) if r else 0).cpu().numpy()
                             for p in ("cls", "mean") for r in (False, True)}
@@ -306,7 +308,7 @@ def test_folded_layernorms_with_outlier_dimensions_and_wide_gammas(native_lib, m
     ids_d, mask_d = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
     out = {}
     for fold in ("1", "0"):
-        monkeypatch.setenv("VQA_ENC_FOLD", fold)
+        set_option(monkeypatch, "VQA_ENC_FOLD", fold)
         enc = QuestionEncoder(w, cfg, max_tokens=b * l)
         out[fold] = {(p, r): enc.forward(ids_d, mask_d, pooling=p, real_tokens=int(mask.sum()) if r else 0).cpu().numpy()
                      for p in ("cls", "mean") for r in (False, True)}

@@ -59,13 +59,9 @@ def _check(s, p, exp_sc, exp_pos, tie_tol, score_tol, min_clear):
 
 def _search(x16, q16, dtype, env=None):
     from vietnamese_qa_system_amd.index import DeviceIndex
-    old = {k: os.environ.get(k) for k in (env or {})}
-    os.environ.update(env or {})
-    try:
-        ix = DeviceIndex(x16, id_base=0, dtype=dtype, device=0)  # VQA_STAGE_MIN is read when the index is created
-    finally:
-        for k, v in old.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    # (env: the round-4 vocabulary of these tests; VQA_STAGE_MIN is vqa_index_options.stage_min_tiles, read when the index is created)
+    options = {{"VQA_STAGE_MIN": "stage_min_tiles"}[k]: int(v) for k, v in (env or {}).items()}
+    ix = DeviceIndex(x16, id_base=0, dtype=dtype, device=0, options=options)
     s, _, p = ix.search(q16.cuda(), K, return_positions=True)
     torch.cuda.synchronize()
     info = ix.launch_info(q16.shape[0], K)

@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import set_option
+
 from oracle import retrieval as R
 
 pytestmark = pytest.mark.gpu
@@ -114,7 +116,7 @@ def test_two_stage_search_equals_one_stage(native_lib, monkeypatch, k):
     its thresholds; capi.hip plan_launch).  VQA_STAGE_MIN brings the switch-over down to a size the oracle handles: the
     result must be the oracle's and bit-identical to the one-stage search's (VQA_STAGE_MIN=0).  (Exact fp16 main launch:
     the int8 sketch pre-pass of large shards, tests/test_gpu_sketch.py, is switched off here.)"""
-    monkeypatch.setenv("VQA_SKETCH", "0")
+    set_option(monkeypatch, "VQA_SKETCH", "0")
     from vietnamese_qa_system_amd.index import DeviceIndex
     n, d, b = 300_001, 64, 41
     x, q = _mk(n, d, b, seed=11)
@@ -123,7 +125,7 @@ def test_two_stage_search_equals_one_stage(native_lib, monkeypatch, k):
     s_full = R.full_scores(q.astype(np.float32), x, R.DTYPE_F16)
     out = []
     for stage_min in ("2", "0"):
-        monkeypatch.setenv("VQA_STAGE_MIN", stage_min)
+        set_option(monkeypatch, "VQA_STAGE_MIN", stage_min)
         ix = DeviceIndex(x, id_base=1, dtype="fp16", device=0)
         info = ix.launch_info(b, k)
         assert (info.first_stage_rows > 0) == (stage_min == "2" and k <= 12)
@@ -229,7 +231,7 @@ def test_large_k_clustered_rows_take_the_gated_fallback(native_lib, monkeypatch)
     assert ((top >= 256) & (top < 316)).all()  # the whole top-40 of every query sits in one tile = one workgroup
     results = []
     for wide in ("1", "0"):
-        monkeypatch.setenv("VQA_WIDE_K", wide)
+        set_option(monkeypatch, "VQA_WIDE_K", wide)
         ix = DeviceIndex(x, id_base=1, dtype="fp16", device=0)
         s, i, p = ix.search(torch.from_numpy(q).cuda(), k, return_positions=True)
         torch.cuda.synchronize()

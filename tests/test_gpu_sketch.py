@@ -10,6 +10,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import set_option
+
 from oracle import retrieval as R
 
 pytestmark = pytest.mark.gpu
@@ -22,7 +24,7 @@ def _unit(rng, n, d):
 
 def _index(x, monkeypatch, sketch, stage_min="2", ids=None, id_base=0, dtype="fp16", rescore_copy=None):
     from vietnamese_qa_system_amd.index import DeviceIndex
-    monkeypatch.setenv("VQA_STAGE_MIN", stage_min)
+    set_option(monkeypatch, "VQA_STAGE_MIN", stage_min)
     return DeviceIndex(x, ids=ids, id_base=id_base, dtype=dtype, device=0, sketch=sketch, rescore_copy=rescore_copy)
 
 
@@ -108,7 +110,7 @@ def test_wide_sketch_overflow_takes_the_exact_passes(native_lib, monkeypatch):
     x = np.repeat(v, n, axis=0)
     x[5] = _unit(rng, 1, d)[0]
     q = np.repeat(v, b, axis=0)
-    monkeypatch.setenv("VQA_WIDE_K", "0")  # the reference handle: plain exact passes
+    set_option(monkeypatch, "VQA_WIDE_K", "0")  # the reference handle: plain exact passes
     ref = _index(x, monkeypatch, sketch=False)
     ske = _index(x, monkeypatch, sketch=True)
     s0, _, p0 = _search(ref, q, k)
@@ -171,7 +173,7 @@ def test_shard_filled_in_unaligned_chunks_has_a_consistent_sketch(native_lib, mo
     rng = np.random.default_rng(9)
     x, q = _unit(rng, n, d), _unit(rng, b, d)
     whole = _index(x, monkeypatch, sketch=True)
-    monkeypatch.setenv("VQA_STAGE_MIN", "2")
+    set_option(monkeypatch, "VQA_STAGE_MIN", "2")
     parts = DeviceIndex.empty(n, d, dtype="fp16", device=0, sketch=True)
     for lo, hi in ((100_000, 150_003), (0, 777), (777, 40_001), (40_001, 100_000)):
         parts.set_rows(lo, x[lo:hi])
@@ -282,12 +284,12 @@ def test_third_cascade_level_changes_no_bit(native_lib, monkeypatch):
     s3, _, p3 = _search(three, q, k)
     assert three.sketch_stats()["overflow"] == 0
     three.close()
-    monkeypatch.setenv("VQA_SKETCH_MID_K", "0")
+    set_option(monkeypatch, "VQA_SKETCH_MID_K", "0")
     two = _index(x, monkeypatch, sketch=True)
     assert two.launch_info(b, k).first_stage_rows == 65536
     s2, _, p2 = _search(two, q, k)
     two.close()
-    monkeypatch.delenv("VQA_SKETCH_MID_K")
+    set_option(monkeypatch, "VQA_SKETCH_MID_K", None)
     assert np.array_equal(p3, p2) and np.array_equal(s3, s2)
     assert p3[0, :5].tolist() == [5, 70_000, 196_607, 196_608, 300_000] and len(set(s3[0, :5].tolist())) == 1
 
@@ -307,7 +309,7 @@ def test_row_major_rescoring_copy_changes_no_bit(native_lib, monkeypatch, dtype,
     x[[5, 70_000, n - 1]] = x[5]
     q[0] = x[5]
     plain = _index(x, monkeypatch, sketch=True, dtype=dtype, rescore_copy=False)
-    monkeypatch.setenv("VQA_STAGE_MIN", "2")
+    set_option(monkeypatch, "VQA_STAGE_MIN", "2")
     copy = DeviceIndex.empty(n, d, dtype=dtype, device=0, sketch=True, rescore_copy=True)
     for lo, hi in ((90_001, n), (0, 513), (513, 90_001)):
         copy.set_rows(lo, x[lo:hi])
@@ -332,7 +334,7 @@ def test_first_form_with_an_exact_first_stage_still_agrees(native_lib, monkeypat
     x[[7, 65_536, n - 2]] = x[7]
     q[0] = x[7]
     cascade = _index(x, monkeypatch, sketch=True)
-    monkeypatch.setenv("VQA_SKETCH_CASCADE", "0")
+    set_option(monkeypatch, "VQA_SKETCH_CASCADE", "0")
     first = _index(x, monkeypatch, sketch=True)
     s0, _, p0 = _search(cascade, q, k)
     s1, _, p1 = _search(first, q, k)
@@ -392,7 +394,7 @@ def test_anisotropic_rows_stay_on_the_sketch_and_agree(native_lib, monkeypatch, 
     x[[11, 70_000, n - 3]] = x[11]
     q[0] = x[11]
     ref = _index(x, monkeypatch, sketch=False)
-    monkeypatch.setenv("VQA_STAGE_MIN", "2")
+    set_option(monkeypatch, "VQA_STAGE_MIN", "2")
     ske = DeviceIndex.empty(n, d, dtype="fp16", device=0, sketch=True)
     for lo, hi in ((0, 100_001), (100_001, n)):  # the centre comes from the first fill; the second chunk is cut against it too
         ske.set_rows(lo, x[lo:hi])

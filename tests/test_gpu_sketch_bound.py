@@ -28,6 +28,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import set_option
+
 pytestmark = pytest.mark.gpu
 
 S = 2.0 ** -10      # grid step of the planted tiles = their sketch scale
@@ -37,9 +39,9 @@ FRAC = 0.4375       # residue of every planted component, in steps, with the sig
 
 def _index(x, monkeypatch, sketch, env=None, dtype="fp16", **kw):
     from vietnamese_qa_system_amd.index import DeviceIndex
-    monkeypatch.setenv("VQA_STAGE_MIN", "2")
+    set_option(monkeypatch, "VQA_STAGE_MIN", "2")
     for key, v in (env or {}).items():
-        monkeypatch.setenv(key, v)
+        set_option(monkeypatch, key, v)
     return DeviceIndex(x, dtype=dtype, device=0, sketch=sketch, **kw)
 
 
@@ -267,7 +269,7 @@ def test_split_slack_term_prunes_collapsed_embeddings_and_changes_no_result(nati
         assert st["overflow"] == 0 and ske.sketch_state() == 0, (name, st)
         pairs[name] = st["rescored_pairs"]
         ske.close()
-        monkeypatch.delenv("VQA_SKETCH_SPLIT", raising=False)
+        set_option(monkeypatch, "VQA_SKETCH_SPLIT", None)
     assert np.array_equal(res["split"][0], res["plain"][0]) and np.array_equal(res["split"][1], res["plain"][1])
     ref = _index(x, monkeypatch, sketch=False)
     _same_rows_outside_near_ties(res["split"][0], res["split"][1], ref, q.astype(np.float32), k)  # re-scoring vs MFMA summation order
@@ -315,8 +317,8 @@ def test_unfilled_tiles_and_a_partly_filled_shard(native_lib, monkeypatch):
     x = (x / np.linalg.norm(x, axis=1, keepdims=True)).astype(np.float16)
     q = rng.standard_normal((b, d)).astype(np.float32)
     q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float16)
-    monkeypatch.setenv("VQA_STAGE_MIN", "2")
-    monkeypatch.setenv("VQA_SKETCH_COOLDOWN", "0")  # no pause after the overflow: the search behind the second fill is a sketch search
+    set_option(monkeypatch, "VQA_STAGE_MIN", "2")
+    set_option(monkeypatch, "VQA_SKETCH_COOLDOWN", "0")  # no pause after the overflow: the search behind the second fill is a sketch search
     filled = 200_100
     ske = DeviceIndex.empty(n, d, dtype="fp16", device=0, sketch=True)
     ske.set_rows(0, x[:filled])
@@ -478,7 +480,7 @@ def test_per_row_form_on_collapsed_embeddings(native_lib, monkeypatch, pattern):
     n, d, b, k = 300_000, 768, 300, 10
     x, q = _collapsed(n, b, d, 3.0, 91)
     if pattern:
-        monkeypatch.setenv("VQA_POISON_WORKSPACE", pattern)
+        set_option(monkeypatch, "VQA_POISON_WORKSPACE", pattern)
     ske = _index(x, monkeypatch, sketch=True)
     t = _rotation(d)
     for tile in (0, 500, (n - 1) // 256):
@@ -502,13 +504,13 @@ def test_per_row_form_on_collapsed_embeddings(native_lib, monkeypatch, pattern):
     assert st["overflow"] == 0 and st["overflow_earlier_tiles"] == 0 and ske.sketch_state() == 0, st
     pairs = st["rescored_pairs"]
     ske.close()
-    monkeypatch.delenv("VQA_POISON_WORKSPACE", raising=False)
+    set_option(monkeypatch, "VQA_POISON_WORKSPACE", None)
     split = _index(x, monkeypatch, sketch=True, env={"VQA_SKETCH_PER_ROW": "0"})
     assert not split.sketch_split(0)[3]
     s2, p2 = _search(split, q.astype(np.float32), k)
     pairs_split = split.sketch_stats()["rescored_pairs"]
     split.close()
-    monkeypatch.delenv("VQA_SKETCH_PER_ROW", raising=False)
+    set_option(monkeypatch, "VQA_SKETCH_PER_ROW", None)
     assert np.array_equal(s1, s2) and np.array_equal(p1, p2)  # both score the survivors with the same kernel
     assert pairs < 0.6 * pairs_split, (pairs, pairs_split)
     ref = _index(x, monkeypatch, sketch=False)
@@ -526,7 +528,7 @@ def test_per_row_form_needs_six_k_steps(native_lib, monkeypatch):
     s1, p1 = _search(ske, q.astype(np.float32), k)
     assert ske.sketch_stats()["overflow"] == 0
     ske.close()
-    monkeypatch.delenv("VQA_SKETCH_PER_ROW", raising=False)
+    set_option(monkeypatch, "VQA_SKETCH_PER_ROW", None)
     ref = _index(x, monkeypatch, sketch=False)
     _same_rows_outside_near_ties(s1, p1, ref, q.astype(np.float32), k)
     ref.close()
@@ -548,13 +550,13 @@ def test_a_search_that_scores_too_many_pairs_pauses_the_sketch_without_overflowi
         return (v / v.norm(dim=1, keepdim=True)).half()
 
     x, q = draw(n), draw(b)
-    monkeypatch.delenv("VQA_STAGE_MIN", raising=False)
+    set_option(monkeypatch, "VQA_STAGE_MIN", None)
     ref = DeviceIndex(x, dtype="fp16", device=0, sketch=False)
     s0, _, p0 = ref.search(q, k, return_positions=True)
     ref.close()
     for profit, want_pause in (("", True), ("0", False)):
         if profit:
-            monkeypatch.setenv("VQA_SKETCH_PROFIT", profit)
+            set_option(monkeypatch, "VQA_SKETCH_PROFIT", profit)
         ske = DeviceIndex(x, dtype="fp16", device=0, sketch=True)
         assert ske.launch_info(b, k).sketch_scan == 1
         s1, _, p1 = ske.search(q, k, return_positions=True)
@@ -570,7 +572,7 @@ def test_a_search_that_scores_too_many_pairs_pauses_the_sketch_without_overflowi
         else:
             assert torch.equal(s2, s1) and torch.equal(p2, p1)
         ske.close()
-        monkeypatch.delenv("VQA_SKETCH_PROFIT", raising=False)
+        set_option(monkeypatch, "VQA_SKETCH_PROFIT", None)
 
 
 def test_per_row_form_fp32_shard_filled_in_unaligned_chunks(native_lib, monkeypatch):
@@ -580,7 +582,7 @@ def test_per_row_form_fp32_shard_filled_in_unaligned_chunks(native_lib, monkeypa
     n, d, b, k = 150_003, 768, 32, 10
     x, q = _collapsed(n, b, d, 3.0, 93)
     x, q = x.astype(np.float32), q.astype(np.float32)
-    monkeypatch.setenv("VQA_STAGE_MIN", "2")
+    set_option(monkeypatch, "VQA_STAGE_MIN", "2")
     ske = DeviceIndex.empty(n, d, dtype="fp32", device=0, sketch=True)
     for lo, hi in ((100_000, 150_003), (0, 777), (777, 40_001), (40_001, 100_000)):
         ske.set_rows(lo, x[lo:hi])
@@ -619,7 +621,7 @@ def test_a_pause_started_by_a_large_k_leaves_small_k_on_the_sketch(native_lib, m
     x = (x / x.norm(dim=1, keepdim=True)).half()
     q = torch.randn((b, d), generator=g, device="cuda")
     q = (q / q.norm(dim=1, keepdim=True)).half()
-    monkeypatch.delenv("VQA_STAGE_MIN", raising=False)
+    set_option(monkeypatch, "VQA_STAGE_MIN", None)
     ske = DeviceIndex(x, dtype="fp16", device=0, sketch=True)
     ref = DeviceIndex(x, dtype="fp16", device=0, sketch=False)
     ske.search(q, 128)

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VQA_LIB") or os.path.join(_HERE, "lib", "libvqa_retrieval.so")  # VQA_LIB: dev override
 
-VQA_VERSION = 108  # include/vqa_retrieval.h: the ABI these bindings were written against
+VQA_VERSION = 109  # include/vqa_retrieval.h: the ABI these bindings were written against
 VQA_F32, VQA_F16, VQA_FP8_E4M3 = 0, 1, 2
 VQA_INDEX_HAS_IDS = 1
 VQA_INDEX_SKETCH = 2
@@ -27,9 +27,9 @@ DTYPE_BYTES = {VQA_F32: 4, VQA_F16: 2, VQA_FP8_E4M3: 1}
 
 # every symbol include/vqa_retrieval.h declares (tests/test_capi_symbols.py checks the two lists agree)
 EXPORTS = (
-    "vqa_version", "vqa_last_error", "vqa_index_create", "vqa_index_set_rows", "vqa_index_get_rows", "vqa_index_destroy", "vqa_index_size", "vqa_index_dim",
+    "vqa_version", "vqa_last_error", "vqa_index_create", "vqa_index_options_init", "vqa_index_create_ex", "vqa_index_set_rows", "vqa_index_get_rows", "vqa_index_destroy", "vqa_index_size", "vqa_index_dim",
     "vqa_index_dtype", "vqa_index_device_bytes", "vqa_index_sketch_state", "vqa_index_sketch_stats", "vqa_index_get_sketch_tile", "vqa_index_get_sketch_split", "vqa_index_search", "vqa_merge_topk", "vqa_index_launch_info", "vqa_index_set_timing",
-    "vqa_index_get_timing", "vqa_encoder_create",
+    "vqa_index_get_timing", "vqa_encoder_create", "vqa_encoder_options_init", "vqa_encoder_create_ex",
     "vqa_encoder_destroy", "vqa_encoder_forward", "vqa_encoder_forward_hidden", "vqa_normalize_convert",
 )
 
@@ -43,7 +43,22 @@ class LaunchInfo(ctypes.Structure):
                 ("rows_per_tile", ctypes.c_int32), ("rows_per_launch", ctypes.c_int64),
                 ("bytes_per_launch", ctypes.c_int64), ("flops_per_launch", ctypes.c_int64),
                 ("seed_grid", ctypes.c_int32), ("seed_tiles", ctypes.c_int32), ("first_stage_rows", ctypes.c_int64),
-                ("sketch_scan", ctypes.c_int32), ("pad_", ctypes.c_int32)]
+                ("sketch_scan", ctypes.c_int32), ("levels", ctypes.c_int32)]
+
+
+class IndexOptions(ctypes.Structure):
+    """``vqa_index_options`` (include/vqa_retrieval.h): every knob of an index handle; ``vqa_index_options_init`` fills the defaults."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("flags", ctypes.c_uint32)] + [(n, ctypes.c_int32) for n in (
+        "two_pass", "wide_k", "seed_mult", "seed_div", "stage_min_tiles", "stage_pct", "f16_loop", "sketch_cascade", "sketch_rotate",
+        "sketch_center", "sketch_split", "sketch_per_row", "sketch_ring_stages", "sketch_mid_k", "sketch_mid_min_tiles", "sketch_mid_pct",
+        "sketch_pre_k", "sketch_cooldown")] + [("sketch_profit", ctypes.c_float), ("rescore_copy", ctypes.c_int32),
+                                               ("poison_workspace", ctypes.c_int32)]
+
+
+class EncoderOptions(ctypes.Structure):
+    """``vqa_encoder_options``."""
+    _fields_ = [("struct_size", ctypes.c_uint32), ("fold_layernorm", ctypes.c_int32), ("first_rows", ctypes.c_int32),
+                ("graphs", ctypes.c_int32)]
 
 
 class EncoderConfig(ctypes.Structure):
@@ -88,6 +103,14 @@ def load() -> ctypes.CDLL:
     lib.vqa_last_error.restype = c.c_char_p
     lib.vqa_index_create.argtypes = [c.POINTER(c.c_void_p), c.c_int, c.c_int64, c.c_int32, c.c_int32, c.c_void_p,
                                      c.c_int32, c.c_void_p, c.c_int64, c.c_uint32]
+    lib.vqa_index_options_init.argtypes = [c.POINTER(IndexOptions)]
+    lib.vqa_index_options_init.restype = None
+    lib.vqa_index_create_ex.argtypes = [c.POINTER(c.c_void_p), c.c_int, c.c_int64, c.c_int32, c.c_int32, c.c_void_p,
+                                        c.c_int32, c.c_void_p, c.c_int64, c.POINTER(IndexOptions)]
+    lib.vqa_encoder_options_init.argtypes = [c.POINTER(EncoderOptions)]
+    lib.vqa_encoder_options_init.restype = None
+    lib.vqa_encoder_create_ex.argtypes = [c.POINTER(c.c_void_p), c.c_int, c.POINTER(EncoderConfig), c.POINTER(EncoderWeights), c.c_int32,
+                                          c.POINTER(EncoderOptions)]
     lib.vqa_index_set_rows.argtypes = [c.c_void_p, c.c_int64, c.c_int64, c.c_void_p, c.c_int32, c.c_void_p]
     lib.vqa_index_get_rows.argtypes = [c.c_void_p, c.c_int64, c.c_int64, c.c_void_p, c.c_void_p]
     lib.vqa_index_destroy.argtypes = [c.c_void_p]
@@ -123,7 +146,7 @@ def load() -> ctypes.CDLL:
     lib.vqa_normalize_convert.argtypes = [c.c_void_p, c.c_int64, c.c_int32, c.c_int32, c.c_int32, c.c_void_p, c.c_void_p]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if fn.restype is c.c_int and name not in ("vqa_version",):
+        if fn.restype is c.c_int and name not in ("vqa_version", "vqa_index_options_init", "vqa_encoder_options_init"):
             fn.restype = c.c_int
     _lib = lib
     return lib
@@ -139,3 +162,27 @@ def check(status: int, what: str) -> None:
     if status == -3:
         raise MemoryError(f"{what}: {msg}")
     raise VqaError(f"{what} failed ({status}): {msg}")
+
+
+def index_options(flags: int = 0, **kw) -> IndexOptions:
+    """The library's defaults with ``kw`` laid over them (unknown names raise)."""
+    o = IndexOptions()
+    load().vqa_index_options_init(ctypes.byref(o))
+    o.flags = int(flags)
+    known = {n for n, _ in IndexOptions._fields_} - {"struct_size", "flags"}
+    for k, v in kw.items():
+        if k not in known:
+            raise ValueError(f"unknown index option {k!r} (known: {sorted(known)})")
+        setattr(o, k, float(v) if k == "sketch_profit" else int(v))
+    return o
+
+
+def encoder_options(**kw) -> EncoderOptions:
+    o = EncoderOptions()
+    load().vqa_encoder_options_init(ctypes.byref(o))
+    known = {n for n, _ in EncoderOptions._fields_} - {"struct_size"}
+    for k, v in kw.items():
+        if k not in known:
+            raise ValueError(f"unknown encoder option {k!r} (known: {sorted(known)})")
+        setattr(o, k, int(v))
+    return o

@@ -27,6 +27,32 @@ extern "C" int vqa_version(void) { return VQA_VERSION; }
 
 static int elem_bytes(int dtype) { return dtype == VQA_F32 ? 4 : dtype == VQA_F16 ? 2 : 1; }
 
+// ---- THE PLAN RULES: every constant that decides which launches a search consists of, in one place, with the measurement that
+// fitted it (all on MI355X, i.i.d. unit rows unless said otherwise).  vqa_index_options_init copies them into the caller-visible
+// options; plan_launch / sketch_active / profit_pairs below apply them.  tests/test_gpu_plan.py pins what they give for the five
+// BASELINE per-GPU shard shapes.
+struct PlanRules {
+    int seed_mult = 2;             // seed pass = 2 x CUs tiles: 512 tiles halve the main pass's appends against 256 (round 1, net gain) ...
+    int seed_div = 16;             // ... capped at 1/16 of the shard (1M x 768 fp32: 13 % of the search in the seed pass without it, 3.37 -> 3.19 ms)
+    int seed_floor_tiles = 24;     // ... never fewer than 24 tiles (20 000-row shard with 4 seed tiles: thresholds stay -inf, 0.39 ms of flooding)
+    int stage_min_plain = 24;      // two stages from 24 tiles per CU on (1.6M rows; crossover between 1M rows +1 % and 2M rows -2 %: profiles/r02_sweeps.txt)
+    int stage_min_f16_sketch = 16; // fp16 + sketch: the cascade pays from 16 tiles per CU (1.05M rows; 1.5M rows 0.56 vs 0.65 ms, 1M level, 0.5M 0.30 vs 0.27)
+    int stage_min_f32_sketch = 8;  // fp32 + sketch: the exact scan runs at 1/16 of the fp16 matrix rate, the int8 scan does not: from 524k rows
+    int stage_pct = 10;            // first stage = 10 % of the tiles (6-14 % level at 10M rows: 2.00-2.03 ms; scripts/trace_steps_env.sh, r04_stage_size_trace.txt)
+    int mid_k = 16;                // a third cascade level from k = 16 on ...
+    int mid_min_tiles = 128;       // ... or from 128 tiles per workgroup on at any k (10M x 768, k = 10, interleaved A/B: 1.936 -> 1.888 ms; 3M rows: +4 %)
+    int mid_pct = 200;             // ... of twice the first stage's tiles (profiles/r04_cascade_levels_ab.txt)
+    int pre_k = 48;                // a fourth level (the first stage's leading quarter) from k = 48 on (r04_cascade_levels_ab.txt: k = 100: 3.9 -> 3.2 ms)
+    int sketch_max_k = 128;        // the sketch search serves k <= 128 (txtai's hybrid search asks for 10 x limit; r04_k_and_batch.txt)
+    double profit_f16 = 0.75;      // pause when a query tile scores more than 0.75 n - 4e5 pairs exactly (profiles/r04_profit_probe.txt: 5 shapes x 6 k)
+    double profit_f32 = 4.0;       // fp32 shards: 4 n (their exact scan is 16x slower)
+    double profit_offset_f16 = 4e5;
+    double per_row_ratio = 0.6;    // per-row form when ||mu||^2 >= 0.6 mean ||x||^2 (level with the centre split at 0.5, ahead from 0.7: r04_per_row_threshold.txt)
+    int per_row_min_ksteps = 6;    // ... and rows of >= 6 K-steps of 64 bytes
+    int cooldown = 64;             // searches without the sketch after an overflow, doubling up to 64 x (r04_fallback_scan.txt: none of 576 shapes overflow unclustered)
+};
+static const PlanRules kPlan;
+
 struct vqa_index {
     int device = 0;
     int64_t n = 0;
@@ -305,7 +331,7 @@ extern "C" int vqa_index_set_rows(vqa_index* ix, int64_t first, int64_t count, c
                 rcm = vqa_launch_center_dir(ix->mu, ix->d_pad8, ix->rotate, ix->wdir, nullptr);
                 if (rcm != VQA_OK) return rcm;
                 // rows collapsed onto the centre direction (an untrained / anisotropic encoder): the per-row form (convert.hip sketch_rows_kernel)
-                ix->per_row = ix->beta && (ix->per_row_env == 1 || (ix->per_row_env < 0 && row2 > 0.0 && n2 >= 0.6 * row2));
+                ix->per_row = ix->beta && (ix->per_row_env == 1 || (ix->per_row_env < 0 && row2 > 0.0 && n2 >= kPlan.per_row_ratio * row2));
             }
         }
         int rc = vqa_launch_tile_scales(ix->rows, ix->dtype, t0, t1 - t0 + 1, ix->d_pad, ix->d_pad8, ix->tile_info, ix->rotate, ix->center ? ix->mu : nullptr, nullptr,
@@ -330,10 +356,91 @@ extern "C" int vqa_index_set_rows(vqa_index* ix, int64_t first, int64_t count, c
     return VQA_OK;
 }
 
+extern "C" void vqa_index_options_init(vqa_index_options* o) {
+    if (!o) return;
+    o->struct_size = (uint32_t)sizeof(vqa_index_options);
+    o->flags = 0;
+    o->two_pass = 1;
+    o->wide_k = 1;
+    o->seed_mult = kPlan.seed_mult;
+    o->seed_div = kPlan.seed_div;
+    o->stage_min_tiles = -1;
+    o->stage_pct = kPlan.stage_pct;
+    o->f16_loop = 0;
+    o->sketch_cascade = o->sketch_rotate = o->sketch_center = o->sketch_split = 1;
+    o->sketch_per_row = -1;
+    o->sketch_ring_stages = 5;
+    o->sketch_mid_k = kPlan.mid_k;
+    o->sketch_mid_min_tiles = kPlan.mid_min_tiles;
+    o->sketch_mid_pct = kPlan.mid_pct;
+    o->sketch_pre_k = kPlan.pre_k;
+    o->sketch_cooldown = kPlan.cooldown;
+    o->sketch_profit = -1.0f;
+    o->rescore_copy = -1;
+    o->poison_workspace = -1;
+}
+
+// -DVQA_DEV variant libraries only (scripts/: ab_loops.py, probes): the rounds-1-4 environment switches laid over the options
+static void dev_env_overlay(vqa_index_options* o) {
+    auto geti = [](const char* name, int32_t* dst) {
+        if (const char* v = vqa_dev_env(name)) *dst = atoi(v);
+    };
+    geti("VQA_TWO_PASS", &o->two_pass);
+    geti("VQA_WIDE_K", &o->wide_k);
+    geti("VQA_SEED_MULT", &o->seed_mult);
+    geti("VQA_SEED_DIV", &o->seed_div);
+    geti("VQA_STAGE_MIN", &o->stage_min_tiles);
+    geti("VQA_STAGE_PCT", &o->stage_pct);
+    geti("VQA_F16_LOOP", &o->f16_loop);
+    geti("VQA_SKETCH_CASCADE", &o->sketch_cascade);
+    geti("VQA_SKETCH_ROTATE", &o->sketch_rotate);
+    geti("VQA_SKETCH_CENTER", &o->sketch_center);
+    geti("VQA_SKETCH_SPLIT", &o->sketch_split);
+    geti("VQA_SKETCH_PER_ROW", &o->sketch_per_row);
+    geti("VQA_SKETCH_SX", &o->sketch_ring_stages);
+    geti("VQA_SKETCH_MID_K", &o->sketch_mid_k);
+    geti("VQA_SKETCH_MID_MIN", &o->sketch_mid_min_tiles);
+    geti("VQA_SKETCH_MID_PCT", &o->sketch_mid_pct);
+    geti("VQA_SKETCH_PRE_K", &o->sketch_pre_k);
+    geti("VQA_SKETCH_COOLDOWN", &o->sketch_cooldown);
+    if (const char* v = vqa_dev_env("VQA_SKETCH_PROFIT")) o->sketch_profit = (float)atof(v);
+    geti("VQA_RESCORE_COPY", &o->rescore_copy);
+    if (const char* v = vqa_dev_env("VQA_POISON_WORKSPACE")) o->poison_workspace = (int)strtol(v, nullptr, 0) & 0xFF;
+    if (const char* v = vqa_dev_env("VQA_SKETCH")) {
+        if (v[0] == '0') o->flags &= ~(uint32_t)VQA_INDEX_SKETCH;
+    }
+}
+
 extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t d, int32_t dtype, const void* rows,
                                 int32_t rows_dtype, const int64_t* ids_or_null, int64_t id_base, uint32_t flags) {
+    vqa_index_options o;
+    vqa_index_options_init(&o);
+    o.flags = flags;
+    return vqa_index_create_ex(out, device, n, d, dtype, rows, rows_dtype, ids_or_null, id_base, &o);
+}
+
+extern "C" int vqa_index_create_ex(vqa_index** out, int device, int64_t n, int32_t d, int32_t dtype, const void* rows,
+                                   int32_t rows_dtype, const int64_t* ids_or_null, int64_t id_base, const vqa_index_options* opt) {
     VQA_REQUIRE(out, "vqa_index_create: out is null");
     *out = nullptr;
+    vqa_index_options o;
+    vqa_index_options_init(&o);
+    if (opt) {
+        VQA_REQUIRE(opt->struct_size >= 8 && opt->struct_size <= 4096, "vqa_index_create_ex: options.struct_size=%u (vqa_index_options_init sets it)",
+                    opt->struct_size);
+        memcpy(&o, opt, opt->struct_size < sizeof(o) ? opt->struct_size : sizeof(o));
+        o.struct_size = (uint32_t)sizeof(o);
+    }
+    dev_env_overlay(&o);
+    const uint32_t flags = o.flags;
+    VQA_REQUIRE(o.seed_mult >= 1 && o.seed_mult <= 4, "vqa_index_create_ex: seed_mult=%d outside [1, 4]", o.seed_mult);
+    VQA_REQUIRE(o.seed_div >= 0, "vqa_index_create_ex: seed_div=%d", o.seed_div);
+    VQA_REQUIRE(o.stage_pct >= 1 && o.stage_pct <= 50, "vqa_index_create_ex: stage_pct=%d outside [1, 50]", o.stage_pct);
+    VQA_REQUIRE(o.f16_loop >= 0 && o.f16_loop <= 2, "vqa_index_create_ex: f16_loop=%d", o.f16_loop);
+    VQA_REQUIRE(o.sketch_ring_stages == 5 || o.sketch_ring_stages == 6, "vqa_index_create_ex: sketch_ring_stages=%d (5 or 6)", o.sketch_ring_stages);
+    VQA_REQUIRE(o.sketch_mid_pct >= 1 && o.sketch_cooldown >= 0 && o.sketch_mid_k >= 0 && o.sketch_pre_k >= 0 && o.sketch_mid_min_tiles >= 0,
+                "vqa_index_create_ex: a sketch_* option is negative");
+    VQA_REQUIRE(o.poison_workspace >= -1 && o.poison_workspace <= 255, "vqa_index_create_ex: poison_workspace=%d", o.poison_workspace);
     VQA_REQUIRE(n >= 0 && n < 0xFFFFFFFFll, "vqa_index_create: n=%lld outside [0, 2^32-1) rows per shard", (long long)n);
     VQA_REQUIRE(d >= 1 && d <= 65536, "vqa_index_create: d=%d", d);
     VQA_REQUIRE(dtype == VQA_F32 || dtype == VQA_F16 || dtype == VQA_FP8_E4M3, "vqa_index_create: dtype %d", dtype);
@@ -366,20 +473,14 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
     ix->id_base = id_base;
     ix->num_cu = prop.multiProcessorCount;
     ix->max_grid = ix->num_cu;
-    const char* tp = getenv("VQA_TWO_PASS");
-    ix->two_pass = !(tp && tp[0] == '0');
-    const char* wk = getenv("VQA_WIDE_K");
-    ix->wide = !(wk && wk[0] == '0');
-    const char* sd = getenv("VQA_SEED_DIV");
-    if (sd) ix->seed_div = atoi(sd);
-    const char* sg = getenv("VQA_STAGE_MIN");
-    if (sg) ix->stage_min_tiles = atoi(sg);
-    const char* sp = getenv("VQA_STAGE_PCT");
-    if (sp && atoi(sp) >= 1 && atoi(sp) <= 50) ix->stage_pct = atoi(sp);
-    const char* fl = getenv("VQA_F16_LOOP");
-    if (fl && fl[0] >= '0' && fl[0] <= '2') ix->f16_loop = fl[0] - '0';  // 2: pairs for the main launch of a two-stage search only
-    const char* sm = getenv("VQA_SEED_MULT");
-    if (sm && sm[0] >= '1' && sm[0] <= '4') ix->seed_mult = sm[0] - '0';
+    ix->two_pass = o.two_pass != 0;
+    ix->wide = o.wide_k != 0;
+    ix->seed_div = o.seed_div;
+    ix->seed_mult = o.seed_mult;
+    const bool stage_given = o.stage_min_tiles >= 0;  // (tests, A/B runs: a plan forced at a size production would not pick it at)
+    ix->stage_min_tiles = stage_given ? o.stage_min_tiles : kPlan.stage_min_plain;
+    ix->stage_pct = o.stage_pct;
+    ix->f16_loop = o.f16_loop;
     const int eb = elem_bytes(dtype);
     int rc = VQA_OK;
     do {
@@ -424,10 +525,10 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
         // (and only for shards large enough for the two-stage search, whose main launch the sketch scan replaces)
         // fp32 shards: the exact scan runs at 1/16 of the fp16 matrix rate, the sketch scan at the same int8 rate: the
         // two-stage / sketch plan pays from 8 tiles per compute unit (524k rows) on
-        if ((flags & VQA_INDEX_SKETCH) && dtype == VQA_F32 && !sg && ix->stage_min_tiles > 8) ix->stage_min_tiles = 8;
+        if ((flags & VQA_INDEX_SKETCH) && dtype == VQA_F32 && !stage_given) ix->stage_min_tiles = kPlan.stage_min_f32_sketch;
         // fp16 shards: the cascade pays from 16 tiles per compute unit (1.05M rows) on -- 1.5M rows: 0.56 vs 0.65 ms, 1M: 0.48 either
         // way, 0.5M: 0.30 vs 0.27 (the exact two-stage plan of shards without a sketch keeps its 24)
-        if ((flags & VQA_INDEX_SKETCH) && dtype == VQA_F16 && !sg && ix->stage_min_tiles > 16) ix->stage_min_tiles = 16;
+        if ((flags & VQA_INDEX_SKETCH) && dtype == VQA_F16 && !stage_given) ix->stage_min_tiles = kPlan.stage_min_f16_sketch;
         ix->sketch = (flags & VQA_INDEX_SKETCH) && (dtype == VQA_F16 || dtype == VQA_F32) && n > 0 && ix->stage_min_tiles > 0 &&
                      tiles >= (int64_t)ix->stage_min_tiles * ix->max_grid &&
                      (tiles + ix->max_grid - 1) / ix->max_grid <= vqa_score_topk_sketch_max_tiles() && d <= 8192;
@@ -450,18 +551,18 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
                 break;
             }
             ix->sketch_flag_host[0] = ix->sketch_flag_host[1] = ix->sketch_flag_host[2] = ix->sketch_flag_host[3] = ix->sketch_flag_host[4] = 0;
-            // (a shard whose size rule was lowered by VQA_STAGE_MIN -- tests, A/B runs -- is below the size at which the sketch pays at all:
+            // (a shard whose size rule was given explicitly -- tests, A/B runs -- is below the size at which the sketch pays at all:
             // the profitability rule is off there unless asked for)
-            if (const char* pf = getenv("VQA_SKETCH_PROFIT")) ix->profit_ratio = atof(pf);
-            else ix->profit_ratio = getenv("VQA_STAGE_MIN") ? 0.0 : dtype == VQA_F32 ? 4.0 : 0.75;
-            if (const char* cs = getenv("VQA_SKETCH_CASCADE")) ix->cascade = cs[0] != '0';
-            if (const char* mk = getenv("VQA_SKETCH_MID_K")) ix->mid_k = atoi(mk);
-            if (const char* mp = getenv("VQA_SKETCH_MID_PCT")) ix->mid_pct = atoi(mp) > 0 ? atoi(mp) : 200;
-            if (const char* mm = getenv("VQA_SKETCH_MID_MIN")) ix->mid_min_tiles = atoi(mm);
-            if (const char* pk = getenv("VQA_SKETCH_PRE_K")) ix->pre_k = atoi(pk);
-            if (const char* sx = getenv("VQA_SKETCH_SX")) ix->sketch_sx5 = sx[0] != '6';
-            if (const char* ro = getenv("VQA_SKETCH_ROTATE")) ix->rotate = ro[0] != '0';
-            if (const char* ce = getenv("VQA_SKETCH_CENTER")) ix->center = ce[0] != '0';
+            if (o.sketch_profit >= 0.f) ix->profit_ratio = o.sketch_profit;
+            else ix->profit_ratio = stage_given ? 0.0 : dtype == VQA_F32 ? kPlan.profit_f32 : kPlan.profit_f16;
+            ix->cascade = o.sketch_cascade != 0;
+            ix->mid_k = o.sketch_mid_k;
+            ix->mid_pct = o.sketch_mid_pct;
+            ix->mid_min_tiles = o.sketch_mid_min_tiles;
+            ix->pre_k = o.sketch_pre_k;
+            ix->sketch_sx5 = o.sketch_ring_stages != 6;
+            ix->rotate = o.sketch_rotate != 0;
+            ix->center = o.sketch_center != 0;
             ix->center = ix->center && ix->rotate;
             ix->tile_c = ix->tile_info + (size_t)tiles * 4;
             if (ix->center && (hipMalloc((void**)&ix->mu, (size_t)ix->d_pad8 * 8) != hipSuccess ||
@@ -471,17 +572,16 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
                 rc = VQA_ENOMEM;
                 break;
             }
-            if (const char* sp = getenv("VQA_SKETCH_SPLIT")) ix->split = sp[0] != '0';
-            ix->split = ix->split && ix->center;
+            ix->split = o.sketch_split != 0 && ix->center;
             if (ix->split) ix->wdir = ix->mu + ix->d_pad8;
-            if (const char* pr = getenv("VQA_SKETCH_PER_ROW")) ix->per_row_env = pr[0] == '1' ? 1 : pr[0] == '0' ? 0 : -1;
-            if (ix->split && ix->d_pad8 / 64 >= 6 && ix->per_row_env != 0 &&
+            ix->per_row_env = o.sketch_per_row == 1 ? 1 : o.sketch_per_row == 0 ? 0 : -1;
+            if (ix->split && ix->d_pad8 / 64 >= kPlan.per_row_min_ksteps && ix->per_row_env != 0 &&
                 (hipMalloc((void**)&ix->beta, (size_t)tiles * 256 * 4) != hipSuccess || hipMemset(ix->beta, 0, (size_t)tiles * 256 * 4) != hipSuccess)) {
                 vqa_set_error("vqa_index_create: allocating the per-row betas failed");
                 rc = VQA_ENOMEM;
                 break;
             }
-            if (const char* cd = getenv("VQA_SKETCH_COOLDOWN")) ix->sketch_cooldown_len = atoi(cd) > 0 ? atoi(cd) : 0;
+            ix->sketch_cooldown_len = o.sketch_cooldown;
             ix->sketch_cooldown_cur = ix->sketch_cooldown_len;
             if (hipMemset(ix->rows8, 0, ix->rows8_bytes) != hipSuccess || hipMemset(ix->tile_info, 0, (size_t)tiles * 20) != hipSuccess ||
                 hipMemset(ix->sketch_flag, 0, 5 * sizeof(int)) != hipSuccess ||
@@ -499,8 +599,7 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
                     (void)hipGetLastError();
                     mem_free = mem_total = 0;
                 }
-                const char* force = getenv("VQA_RESCORE_COPY");
-                const bool room = (force && force[0] == '1') || mem_total == 0 || mem_free >= ix->rows_bytes + mem_total / 8;
+                const bool room = o.rescore_copy == 1 || mem_total == 0 || mem_free >= ix->rows_bytes + mem_total / 8;
                 if (!room || hipMalloc(&ix->rows_rm, ix->rows_bytes) != hipSuccess) {
                     (void)hipGetLastError();
                     ix->rows_rm = nullptr;
@@ -515,10 +614,10 @@ extern "C" int vqa_index_create(vqa_index** out, int device, int64_t n, int32_t 
                 }
             }
         }
-        if (const char* pz = getenv("VQA_POISON_WORKSPACE")) {
+        if (o.poison_workspace >= 0) {
             // test hook: every workspace a search is expected to WRITE before it reads starts as a byte pattern instead of whatever the
             // allocator hands out (a long-lived process gets recycled, dirty memory; 0xCB... reads as a large negative float)
-            const int byte = (int)strtol(pz, nullptr, 0) & 0xFF;
+            const int byte = o.poison_workspace;
             const int max_k2 = vqa_score_topk_max_k(dtype);
             (void)hipMemset(ix->q_stage, byte, (size_t)VQA_QUERY_TILE * ix->d_pad * eb);
             (void)hipMemset(ix->partial, byte, (size_t)4 * ix->max_grid * VQA_QUERY_TILE * max_k2 * sizeof(vqa_key));
@@ -597,7 +696,7 @@ extern "C" int32_t vqa_index_dtype(const vqa_index* ix) { return ix ? ix->dtype 
 // the profitability rule of the sketch search (vqa_index::profit_ratio)
 static double profit_pairs(const vqa_index* ix) {
     const double n = (double)ix->n;
-    const double lim = ix->profit_ratio * n - (ix->dtype == VQA_F32 ? 0.0 : 4e5);
+    const double lim = ix->profit_ratio * n - (ix->dtype == VQA_F32 ? 0.0 : kPlan.profit_offset_f16);
     return lim > 0.1 * n ? lim : 0.1 * n;
 }
 static int pairs_reported(const vqa_index* ix) {  // the most pairs a query tile of the last reported call scored exactly
@@ -640,7 +739,7 @@ struct LaunchPlan {
 // txtai's hybrid search asks the dense index for 10 x limit rows (30 at its default limit).  The candidates of a query grow with k
 // (theta sits at rank k: ~860 rows at k = 10, ~2300 at k = 30, ~13 000 at k = 100 of a 10M-row shard -- half of them from the first
 // stage, whose seed threshold is the weaker one) and the exact re-scoring with them; txtai's hybrid search at limit 10 asks for 100.
-constexpr int kSketchMaxK = 128;
+#define kSketchMaxK (kPlan.sketch_max_k)
 
 static LaunchPlan plan_launch(const vqa_index* ix, int k = 0) {
     LaunchPlan p;
@@ -660,7 +759,7 @@ static LaunchPlan plan_launch(const vqa_index* ix, int k = 0) {
         // ... but never fewer than 24 (or all there are): a tile gives 2 seeds per query, and with fewer than k of them the
         // threshold stays at -inf and every workgroup floods its lists on its first tile -- a 20 000-row shard (79 tiles,
         // 4 seed tiles by the 1/16 rule) spent 0.39 ms there, 4x what a 65 536-row shard takes
-        const int floor_tiles = 24;
+        const int floor_tiles = kPlan.seed_floor_tiles;
         if (want < floor_tiles) want = floor_tiles;
         // a large k on a small shard: the threshold is the k-th largest seed, so there must be k of them
         if (2 * want < k) want = (k + 1) / 2;
@@ -715,7 +814,7 @@ extern "C" int vqa_index_launch_info(const vqa_index* ix, int32_t B, int32_t k, 
     out->sketch_scan = sketch_active(ix, p, k) ? 1 : 0;
     out->first_stage_rows = (k <= vqa_score_topk_max_k(ix->dtype) || out->sketch_scan) ? (int64_t)(p.stage_tiles + (out->sketch_scan ? p.mid_tiles : 0)) * 256 : 0;
     out->rows_per_launch = ix->n - out->first_stage_rows;
-    out->pad_ = 0;
+    out->levels = out->sketch_scan ? 2 + (p.mid_tiles > 0) + (p.pre_tiles > 0) : (p.stage_tiles > 0 && k <= vqa_score_topk_max_k(ix->dtype) && p.grid0 > 0) ? 2 : 1;
     out->bytes_per_launch = out->rows_per_launch * (int64_t)ix->d * (out->sketch_scan ? 1 : elem_bytes(ix->dtype));
     out->flops_per_launch = 2 * (int64_t)VQA_QUERY_TILE * out->rows_per_launch * (int64_t)ix->d;
     out->seed_grid = p.grid0;

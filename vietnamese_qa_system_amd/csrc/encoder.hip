@@ -14,6 +14,8 @@
 //   attention       per (sequence, head): softmax(q k^T / sqrt(dh) + mask) v, K/V in LDS, wavefront-shuffle softmax
 //   ln              LayerNorm (the residual add is fused into the producing GEMM's epilogue) (one wave per token)
 //   pool_normalize  CLS row or masked mean -> fp32 -> x / ||x||                          (one wave per sequence)
+#include <string.h>
+
 #include <atomic>
 #include <new>
 #include <type_traits>
@@ -1597,7 +1599,7 @@ int launch_tile(const _Float16* A, const _Float16* W, const float* bias, const _
     const int grid = tiles < num_cu ? tiles : num_cu;
     // blocked tile order inside an XCD (see tile_of in the kernel): needs the XCD split itself (tiles, grid multiples of 8),
     // whole token-tile rows per XCD, and a block of per = grid / 8 tiles that divides them
-    static const int nb_force = getenv("VQA_GEMM_NB") ? atoi(getenv("VQA_GEMM_NB")) : -1;  // dev override; 0 = feature-fastest order
+    static const int nb_force = vqa_dev_env("VQA_GEMM_NB") ? atoi(vqa_dev_env("VQA_GEMM_NB")) : -1;  // dev override; 0 = feature-fastest order
     int nb = 0;
     if (tiles % 8 == 0 && grid % 8 == 0 && tiles_m % 8 == 0) {
         const int per = grid / 8, rows = tiles_m / 8;
@@ -1634,8 +1636,8 @@ static const int kTileShapes[7][4] = {{256, 288, 32, 2}, {256, 192, 32, 2}, {256
 // index into kTileShapes of the LDS-DMA tile kernel's shape for this problem; -1: the problem does not take that kernel
 // (fewer than 1024 rows, or no shape divides N / K); -2: HIP error (message set)
 static int tile_choice(int M, int N, int K, int* num_cu_out) {
-    static const int force_tile = getenv("VQA_GEMM_TILE") ? atoi(getenv("VQA_GEMM_TILE")) : -1;  // dev override: shape index 0..6
-    static const int tile_min_m = getenv("VQA_TILE_MIN_M") ? atoi(getenv("VQA_TILE_MIN_M")) : kTileMinM;  // dev override
+    static const int force_tile = vqa_dev_env("VQA_GEMM_TILE") ? atoi(vqa_dev_env("VQA_GEMM_TILE")) : -1;  // dev override: shape index 0..6
+    static const int tile_min_m = vqa_dev_env("VQA_TILE_MIN_M") ? atoi(vqa_dev_env("VQA_TILE_MIN_M")) : kTileMinM;  // dev override
     if (!(M >= tile_min_m && N % 64 == 0 && K % 32 == 0)) return -1;
     static VqaPerDeviceOnce once;
     static int num_cu[64] = {};  // written inside the once, read after it
@@ -1685,7 +1687,7 @@ int launch_gemm_fold(const _Float16* A, const _Float16* W, const float* bias, co
     const int best = tile_choice(M, N, K, &cu);
     // the 128 x 128 tile (64-deep K-steps: the packed N = 768 projections) runs the one-barrier K loop -- its two fragment sets fit
     // beside 64 accumulators and the folded epilogue without spilling (VQA_GEMM_ONEBAR=0: the slot loop, dev / A-B switch)
-    static const bool onebar6 = !(getenv("VQA_GEMM_ONEBAR") && atoi(getenv("VQA_GEMM_ONEBAR")) == 0);
+    static const bool onebar6 = !(vqa_dev_env("VQA_GEMM_ONEBAR") && atoi(vqa_dev_env("VQA_GEMM_ONEBAR")) == 0);
     switch (best) {
         case 0: return launch_tile<EPI, 256, 288, 4, 2, 32, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
         case 1: return launch_tile<EPI, 256, 192, 4, 2, 32, 1>(A, W, bias, R, C, M, N, K, cu, s, fa);
@@ -1705,8 +1707,8 @@ int launch_gemm_fold(const _Float16* A, const _Float16* W, const float* bias, co
 template <int EPI>
 int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, const _Float16* R, _Float16* C, int M, int N, int K,
                 hipStream_t s) {
-    static const bool force_small = getenv("VQA_GEMM_SMALL") != nullptr;  // dev override, read once
-    static const int skinny_max = getenv("VQA_SKINNY_MAX") ? atoi(getenv("VQA_SKINNY_MAX")) : kSkinnyMax;  // dev override
+    static const bool force_small = vqa_dev_env("VQA_GEMM_SMALL") != nullptr;  // dev override, read once
+    static const int skinny_max = vqa_dev_env("VQA_SKINNY_MAX") ? atoi(vqa_dev_env("VQA_SKINNY_MAX")) : kSkinnyMax;  // dev override
     if (M <= skinny_max && N % 16 == 0 && K % 256 == 0 && !force_small) {
         const int mt = M >= 64 ? 4 : (M + 15) / 16;
         const int chunks = (M + 16 * mt - 1) / (16 * mt);
@@ -1806,10 +1808,34 @@ extern "C" void vqa_encoder_destroy(vqa_encoder* e) {
     delete e;
 }
 
+extern "C" void vqa_encoder_options_init(vqa_encoder_options* o) {
+    if (!o) return;
+    o->struct_size = (uint32_t)sizeof(vqa_encoder_options);
+    o->fold_layernorm = 1;
+    o->first_rows = 1;
+    o->graphs = 1;
+}
+
 extern "C" int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encoder_config* cfg, const vqa_encoder_weights* w,
                                   int32_t max_tokens) {
+    return vqa_encoder_create_ex(out, device, cfg, w, max_tokens, nullptr);
+}
+
+extern "C" int vqa_encoder_create_ex(vqa_encoder** out, int device, const vqa_encoder_config* cfg, const vqa_encoder_weights* w,
+                                     int32_t max_tokens, const vqa_encoder_options* opt) {
     VQA_REQUIRE(out, "vqa_encoder_create: out is null");
     *out = nullptr;
+    vqa_encoder_options o;
+    vqa_encoder_options_init(&o);
+    if (opt) {
+        VQA_REQUIRE(opt->struct_size >= 8 && opt->struct_size <= 4096, "vqa_encoder_create_ex: options.struct_size=%u (vqa_encoder_options_init sets it)",
+                    opt->struct_size);
+        memcpy(&o, opt, opt->struct_size < sizeof(o) ? opt->struct_size : sizeof(o));
+        o.struct_size = (uint32_t)sizeof(o);
+    }
+    if (const char* v = vqa_dev_env("VQA_ENC_FIRST_ROWS")) o.first_rows = atoi(v) != 0;
+    if (const char* v = vqa_dev_env("VQA_ENC_FOLD")) o.fold_layernorm = atoi(v) != 0;
+    if (const char* v = vqa_dev_env("VQA_ENCODER_GRAPH")) o.graphs = v[0] != '0';
     VQA_REQUIRE(cfg && w && w->layer, "vqa_encoder_create: null config / weights");
     VQA_REQUIRE(cfg->hidden >= 32 && cfg->hidden <= 2048 && cfg->hidden % 32 == 0,
                 "vqa_encoder_create: hidden=%d must be a multiple of 32 in [32, 2048]", cfg->hidden);
@@ -1836,8 +1862,8 @@ extern "C" int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encod
     e->device = device;
     e->cfg = *cfg;
     e->max_tokens = max_tokens;
-    e->first_rows_on = !(getenv("VQA_ENC_FIRST_ROWS") && atoi(getenv("VQA_ENC_FIRST_ROWS")) == 0);
-    e->fold_on = !(getenv("VQA_ENC_FOLD") && atoi(getenv("VQA_ENC_FOLD")) == 0);
+    e->first_rows_on = o.first_rows != 0;
+    e->fold_on = o.fold_layernorm != 0;
     const size_t H = cfg->hidden, F = cfg->ffn;
     int rc = VQA_OK;
     do {
@@ -1918,8 +1944,7 @@ extern "C" int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encod
         }
         *e->bad_ids_host = 0;
         {
-            const char* gv = getenv("VQA_ENCODER_GRAPH");
-            e->use_graphs = !(gv && gv[0] == '0');
+            e->use_graphs = o.graphs != 0;
             if (e->use_graphs && hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) {
                 (void)hipGetLastError();
                 e->cap_stream = nullptr;

@@ -26,6 +26,19 @@ void vqa_set_error(const char* fmt, ...);
         }                            \
     } while (0)
 
+// ---- development overrides.  The product build reads NO environment variable: every knob is a field of vqa_index_options /
+// vqa_encoder_options.  A `-DVQA_DEV` variant library (scripts/: A/B runs, timing ablations) still overlays VQA_* variables on those
+// defaults and honours the GEMM launcher's dev switches; vqa_dev_env is the one place that decides.
+#include <stdlib.h>
+static inline const char* vqa_dev_env(const char* name) {
+#ifdef VQA_DEV
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
+
 // ---- one-time setup per device (hipFuncSetAttribute, device queries), callable from several host threads at once:
 // different handles may be used from different threads (include/vqa_retrieval.h), and every launch path comes through here.
 struct VqaPerDeviceOnce {

@@ -27,6 +27,9 @@ XLMR_BASE = dict(vocab_size=250002, hidden=768, layers=12, heads=12, ffn=3072, m
 MINILM_L12 = dict(vocab_size=250037, hidden=384, layers=12, heads=12, ffn=1536, max_pos=512, type_vocab=2, pad_id=0, ln_eps=1e-12,
                   position_ids="absolute")
 POSITION_IDS = {"roberta": N.VQA_POS_ROBERTA, "absolute": N.VQA_POS_ABSOLUTE}
+# process-wide defaults laid under QuestionEncoder(options=...): vqa_encoder_options by field name (fold_layernorm, first_rows, graphs);
+# empty in production (tests / A/B scripts set entries: explicit Python state, no environment variable is read)
+DEFAULT_OPTIONS: dict = {}
 
 _LAYER_FIELDS = (
     ("wq", "attention.self.query.weight"), ("bq", "attention.self.query.bias"),
@@ -51,7 +54,8 @@ class QuestionEncoder:
     pad-offset ids, the default; "absolute": BERT's 0 .. L - 1).  ``max_tokens`` bounds B * L of one call.
     """
 
-    def __init__(self, weights: Dict[str, object], config: dict, *, device: int = 0, max_tokens: int = 1024 * 32):
+    def __init__(self, weights: Dict[str, object], config: dict, *, device: int = 0, max_tokens: int = 1024 * 32,
+                 options: Optional[dict] = None):
         if not torch.cuda.is_available():
             raise RuntimeError("QuestionEncoder needs an MI355X (gfx950); there is no CPU fallback")
         self._lib = N.load()
@@ -101,8 +105,11 @@ class QuestionEncoder:
         top.layer = ctypes.cast(layers, ctypes.POINTER(N.EncoderLayerWeights))
         with torch.cuda.device(self.device):
             torch.cuda.synchronize()
-            N.check(self._lib.vqa_encoder_create(ctypes.byref(self._handle), self.device, ctypes.byref(cfg), ctypes.byref(top),
-                                                 self.max_tokens), "vqa_encoder_create")
+            opts = dict(DEFAULT_OPTIONS)
+            opts.update(options or {})
+            self.options = N.encoder_options(**opts)
+            N.check(self._lib.vqa_encoder_create_ex(ctypes.byref(self._handle), self.device, ctypes.byref(cfg), ctypes.byref(top),
+                                                    self.max_tokens, ctypes.byref(self.options)), "vqa_encoder_create_ex")
         del keep
 
     @classmethod

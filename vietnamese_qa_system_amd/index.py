@@ -20,6 +20,12 @@ _SRC_DTYPE = {torch.float32: N.VQA_F32, torch.float16: N.VQA_F16}
 _STORE_NP = {N.VQA_F32: np.float32, N.VQA_F16: np.float16, N.VQA_FP8_E4M3: np.uint8}
 FP8_SCALE = 16.0  # an fp8 index stores e4m3(16 * x) (and scores 16 * q the same way); scores come back divided by 256
 
+# Process-wide option defaults laid UNDER ``DeviceIndex(options=...)`` (vqa_index_options of include/vqa_retrieval.h by field name,
+# plus "sketch": keep an int8 sketch where the library's plan uses one).  Empty in production: the library's own defaults are the
+# production plan.  Tests and A/B scripts put entries here -- explicit Python state instead of the VQA_* environment variables the
+# library read up to round 4 (which could change a deployed process's behaviour from the caller's environment).
+DEFAULT_OPTIONS: dict = {}
+
 
 def _require_gpu(device: int) -> None:
     if not torch.cuda.is_available():
@@ -55,12 +61,13 @@ class DeviceIndex:
     ``float32`` or ``float16``); ``normalize=True`` L2-normalises float32 rows on the device first (txtai's behaviour
     at index time).  ``ids`` [n] int64 external ids or ``None`` (id = ``id_base`` + row position; sqlite
     AUTOINCREMENT rowids start at 1, ``setup_db.py:14``).  ``DeviceIndex.empty(n, d)`` + :meth:`set_rows` fills a
-    large shard chunk by chunk without a second full copy.
+    large shard chunk by chunk without a second full copy.  ``options``: fields of ``vqa_index_options`` by name (A/B runs and
+    tests; production passes none).
     """
 
     def __init__(self, vectors=None, ids=None, *, id_base: int = 0, dtype="fp16", device: int = 0, normalize: bool = False,
                  n: Optional[int] = None, d: Optional[int] = None, with_ids: Optional[bool] = None, sketch: Optional[bool] = None,
-                 rescore_copy: Optional[bool] = None):
+                 rescore_copy: Optional[bool] = None, options: Optional[dict] = None):
         self._handle = ctypes.c_void_p()
         self.device = int(device)
         _require_gpu(self.device)
@@ -76,31 +83,34 @@ class DeviceIndex:
         has_ids = bool(with_ids) if with_ids is not None else ids is not None
         # int8 sketch beside the fp16 rows of a large shard (include/vqa_retrieval.h VQA_INDEX_SKETCH): on by default, the
         # library keeps one only where its two-stage search applies; VQA_SKETCH=0 or sketch=False: exact fp16 scan everywhere
+        opts = dict(DEFAULT_OPTIONS)
+        opts.update(options or {})
         if sketch is None:
-            sketch = os.environ.get("VQA_SKETCH", "1") != "0"
+            sketch = bool(opts.pop("sketch", True))
+        opts.pop("sketch", None)
         flags = (N.VQA_INDEX_HAS_IDS if has_ids else 0) | (N.VQA_INDEX_SKETCH if sketch and self.dtype in (N.VQA_F16, N.VQA_F32) else 0)
         # row-major copy of the rows for the sketch search's exact re-scoring (VQA_INDEX_RESCORE_ROWS: +100 % of the rows' memory,
         # re-scoring 3x faster, bit-equal results; kept only where the library keeps a sketch).  Default: shards whose rows take
         # up to RESCORE_COPY_MAX_BYTES (an 80M x 768 fp16 shard on one device does without); VQA_RESCORE_COPY=0 / 1 overrides.
         if rescore_copy is None:
-            env = os.environ.get("VQA_RESCORE_COPY", "")
-            rescore_copy = env == "1" if env in ("0", "1") else int(n) * int(d) * N.DTYPE_BYTES[self.dtype] <= RESCORE_COPY_MAX_BYTES
+            rescore_copy = int(n) * int(d) * N.DTYPE_BYTES[self.dtype] <= RESCORE_COPY_MAX_BYTES
         if rescore_copy and (flags & N.VQA_INDEX_SKETCH):
             flags |= N.VQA_INDEX_RESCORE_ROWS
+        self.options = N.index_options(flags, **opts)
         with torch.cuda.device(self.device):
-            N.check(self._lib.vqa_index_create(ctypes.byref(self._handle), self.device, int(n), int(d), self.dtype, None,
-                                               N.VQA_F16, None, int(id_base), flags),
-                    "vqa_index_create")
+            N.check(self._lib.vqa_index_create_ex(ctypes.byref(self._handle), self.device, int(n), int(d), self.dtype, None,
+                                                  N.VQA_F16, None, int(id_base), ctypes.byref(self.options)),
+                    "vqa_index_create_ex")
         self.n, self.d, self.id_base, self.has_ids = int(n), int(d), int(id_base), has_ids
         if vectors is not None and n:
             self.set_rows(0, v, ids, normalize=normalize)
 
     @classmethod
     def empty(cls, n: int, d: int, *, id_base: int = 0, dtype="fp16", device: int = 0, with_ids: bool = False,
-              sketch: Optional[bool] = None, rescore_copy: Optional[bool] = None) -> "DeviceIndex":
+              sketch: Optional[bool] = None, rescore_copy: Optional[bool] = None, options: Optional[dict] = None) -> "DeviceIndex":
         """A shard of ``n`` zero rows to be filled with :meth:`set_rows`."""
         return cls(None, None, id_base=id_base, dtype=dtype, device=device, n=n, d=d, with_ids=with_ids, sketch=sketch,
-                   rescore_copy=rescore_copy)
+                   rescore_copy=rescore_copy, options=options)
 
     # -- filling -------------------------------------------------------------------------------------------------
     def set_rows(self, first: int, vectors, ids=None, *, normalize: bool = False, chunk_rows: int = 1 << 20) -> None:
