@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VQA_VERSION 109 /* 0.1.9: vqa_index_options / vqa_index_create_ex, vqa_encoder_options / vqa_encoder_create_ex (no environment variable is read any more), vqa_launch_info.levels; 0.1.8: vqa_encoder_forward_hidden; 0.1.7: vqa_index_get_sketch_split; 0.1.6: vqa_index_sketch_stats, vqa_index_get_sketch_tile; 0.1.5: vqa_index_sketch_state; 0.1.4: VQA_INDEX_RESCORE_ROWS, vqa_index_device_bytes; 0.1.3: VQA_INDEX_SKETCH */
+#define VQA_VERSION 110 /* 0.1.10: vqa_index_search_host; 0.1.9: vqa_index_options / vqa_index_create_ex, vqa_encoder_options / vqa_encoder_create_ex (no environment variable is read any more), vqa_launch_info.levels; 0.1.8: vqa_encoder_forward_hidden; 0.1.7: vqa_index_get_sketch_split; 0.1.6: vqa_index_sketch_stats, vqa_index_get_sketch_tile; 0.1.5: vqa_index_sketch_state; 0.1.4: VQA_INDEX_RESCORE_ROWS, vqa_index_device_bytes; 0.1.3: VQA_INDEX_SKETCH */
 
 /* error codes */
 #define VQA_OK 0
@@ -191,6 +191,17 @@ int vqa_index_get_sketch_split(vqa_index* index, int64_t tile, float* out_c /* [
  * queueing them one behind the other.) */
 int vqa_index_search(vqa_index* index, const void* q, int32_t q_dtype, int32_t B, int32_t k, float* out_scores,
                      int64_t* out_ids, int64_t* out_pos_or_null, void* hip_stream);
+
+/* The latency form of vqa_index_search for the reference's own calling pattern -- one question per call, limit = 1
+ * (heavy_ranker.py:97-101): HOST pointers in and out, synchronous.  q_host [B, d] fp32 / fp16 host memory; normalize = 1 (fp32
+ * queries only) L2-normalises them on the device with the kernel of vqa_normalize_convert, so the results are those of
+ * normalise-then-vqa_index_search bit for bit.  out_scores [B, k], out_ids [B, k] and out_pos_or_null [B, k] are host arrays,
+ * valid when the call returns.  No allocation and no copy operation per call: the CPU copies the queries into a pinned,
+ * device-mapped buffer the handle keeps (grown on demand), the kernels read them from there and write the results into pinned
+ * memory, and the call polls the stream for completion (up to ~0.2 ms, then blocks).  The launches go to hip_stream: order it
+ * with the handle's other searches as for vqa_index_search. */
+int vqa_index_search_host(vqa_index* index, const void* q_host, int32_t q_dtype, int32_t B, int32_t k, int32_t normalize,
+                          float* out_scores, int64_t* out_ids, int64_t* out_pos_or_null, void* hip_stream);
 
 /* ---- merge: final step after the RCCL all-gather of per-shard candidates (new in this build; the reference is
  * single-process).  scores/ids: R blocks of [B, k] on the device, each [k] list best first, padded with (-inf, -1);

@@ -206,3 +206,62 @@ def test_index_streams_every_document_through_the_encoder_exactly_once(native_li
     calls.clear()
     hit = emb.search("doc 517", 1)[0]
     assert calls == [1] and hit["id"] == 518 and hit["text"] == "doc 517" and abs(hit["score"] - 1.0) < 2e-3
+
+
+# ---- the latency path (vqa_index_search_host): the reference asks ONE question per call with limit = 1 (heavy_ranker.py:97-101)
+@pytest.mark.parametrize("dtype,n,options", [("fp16", 1000, None), ("fp32", 5000, None), ("fp8", 3000, None),
+                                             ("fp16", 200_000, {"stage_min_tiles": 2})])  # the last one: a sketch shard
+def test_host_latency_path_returns_the_batch_paths_bits(native_lib, dtype, n, options):
+    """Host-resident queries of 1 / 17 / 64 rows through vqa_index_search_host (pinned device-mapped staging, normalisation on the
+    device, results written into pinned memory, polled completion) == the torch path on the same index, bit for bit -- scores,
+    ids, positions -- and == the oracle."""
+    from vietnamese_qa_system_amd.index import DeviceIndex
+    rng = np.random.default_rng(5)
+    d = 768
+    x = R.l2_normalize(rng.standard_normal((n, d)).astype(np.float32))
+    q = rng.standard_normal((64, d)).astype(np.float32)  # NOT normalised: the call does it
+    ix = DeviceIndex(x, id_base=1, dtype=dtype, device=0, options=options)
+    if options:
+        assert ix.launch_info(64, 10).sketch_scan == 1
+    for b, k in ((1, 1), (1, 10), (17, 10), (64, 30)):
+        s_h, i_h, p_h = ix.search_host(q[:b], k, normalize=True, return_positions=True)
+        qn = torch.empty((b, d), dtype=torch.float32, device="cuda")
+        N = ix._lib
+        N.vqa_normalize_convert(torch.from_numpy(q[:b]).cuda().data_ptr(), b, d, 1, 0, qn.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        s_t, i_t, p_t = ix.search(qn, k, return_positions=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(s_h, s_t.cpu().numpy()) and np.array_equal(i_h, i_t.cpu().numpy()) and np.array_equal(p_h, p_t.cpu().numpy())
+        assert np.array_equal(i_h, p_h + 1)
+    # fp16 host queries, no normalisation; growing the pinned buffer (B = 300 > the first allocation's share) keeps working
+    q16 = R.l2_normalize(q).astype(np.float16)
+    big = np.tile(q16, (5, 1))[:300]
+    s_h, i_h = ix.search_host(big, 10)
+    s_t, i_t, _ = ix.search(torch.from_numpy(big).cuda(), 10)
+    torch.cuda.synchronize()
+    assert np.array_equal(s_h, s_t.cpu().numpy()) and np.array_equal(i_h, i_t.cpu().numpy())
+    if dtype != "fp8":
+        stored = x.astype(np.float16) if dtype == "fp16" else x
+        R.check_topk(s_h[:64], i_h[:64] - 1, R.full_scores(q16[:64].astype(np.float32), stored, R.DTYPE_F16 if dtype == "fp16" else R.DTYPE_F32), 10,
+                     score_tol=1e-5, tie_tol=2e-6)
+    with pytest.raises(ValueError):
+        ix.search_host(q[:1].astype(np.float64), 1)
+    with pytest.raises(ValueError):
+        ix.search_host(q16[:1], 1, normalize=True)  # only fp32 queries are normalised by the call
+    ix.close()
+
+
+def test_embeddings_search_of_one_vector_takes_the_latency_path(native_lib):
+    """Embeddings.search(vector, 1) -- the reference's call shape -- goes through vqa_index_search_host and returns what batchsearch
+    of a device tensor returns; lists of floats and float64 arrays too."""
+    from vietnamese_qa_system_amd import Embeddings
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((5000, 768)).astype(np.float32)
+    q = rng.standard_normal((8, 768)).astype(np.float32)
+    emb = Embeddings(dtype="fp16", device=0)
+    emb.index_vectors(list(range(1, 5001)), x)
+    via_torch = emb.batchsearch(torch.from_numpy(q), 3)
+    assert [emb.search(q[i], 3) for i in range(8)] == via_torch
+    assert emb.search(q[2].tolist(), 3) == via_torch[2] and emb.search(q[2].astype(np.float64), 3) == via_torch[2]
+    assert emb.batchsearch(q, 3) == via_torch
+    one = emb.search(q[0], 1)
+    assert len(one) == 1 and one[0] == via_torch[0][0]

@@ -153,6 +153,12 @@ struct vqa_index {
     bool timing = false;
     std::vector<hipEvent_t> ev;  // start/stop pairs
     size_t ev_used = 0;
+    // vqa_index_search_host: pinned, device-mapped [queries | scores | ids | positions] and the device copy of the normalised queries (lazy, grow-only)
+    void* hio = nullptr;
+    void* hio_dev = nullptr;
+    size_t hio_bytes = 0;
+    void* hq_norm = nullptr;
+    size_t hq_norm_bytes = 0;
     std::atomic_flag busy = ATOMIC_FLAG_INIT;  // one search at a time per handle (the workspace is shared)
 };
 
@@ -188,6 +194,8 @@ extern "C" void vqa_index_destroy(vqa_index* ix) {
     if (ix->q_stage) (void)hipFree(ix->q_stage);
     if (ix->q_rm) (void)hipFree(ix->q_rm);
     if (ix->q_rows) (void)hipFree(ix->q_rows);
+    if (ix->hio) (void)hipHostFree(ix->hio);
+    if (ix->hq_norm) (void)hipFree(ix->hq_norm);
     for (int b = 0; b < 2; ++b) {
         if (ix->up_pinned[b]) (void)hipHostFree(ix->up_pinned[b]);
         if (ix->up_dev[b]) (void)hipFree(ix->up_dev[b]);
@@ -961,18 +969,102 @@ static int sketch_select(vqa_index* ix, int nq, int k, float* os, int64_t* oi, i
     return rc;
 }
 
+static int search_impl(vqa_index* ix, const void* q, int32_t q_dtype, int32_t B, int32_t k, float* out_scores, int64_t* out_ids,
+                       int64_t* out_pos_or_null, hipStream_t stream);
+
 extern "C" int vqa_index_search(vqa_index* ix, const void* q, int32_t q_dtype, int32_t B, int32_t k, float* out_scores,
                                 int64_t* out_ids, int64_t* out_pos_or_null, void* hip_stream) {
     VQA_REQUIRE(ix, "vqa_index_search: index is null");
     VQA_REQUIRE(q && out_scores && out_ids, "vqa_index_search: null pointer");
     VQA_REQUIRE(B >= 1, "vqa_index_search: B=%d", B);
-    const int max_k = vqa_score_topk_max_k(ix->dtype);  // per pass over the index
     VQA_REQUIRE(k >= 1 && k <= VQA_MAX_K_TOTAL, "vqa_index_search: k=%d outside [1, %d]", k, VQA_MAX_K_TOTAL);
     VQA_REQUIRE(q_dtype == VQA_F32 || q_dtype == VQA_F16, "vqa_index_search: q_dtype %d is not f32/f16", q_dtype);
-    hipStream_t stream = (hipStream_t)hip_stream;
     HandleBusy busy(ix->busy);
     VQA_REQUIRE(busy.ok, "vqa_index_search: this index handle is in use by another host thread (one call at a time per handle)");
     DeviceGuard guard(ix->device);
+    return search_impl(ix, q, q_dtype, B, k, out_scores, out_ids, out_pos_or_null, (hipStream_t)hip_stream);
+}
+
+// ---- the latency form: host pointers in, host pointers out, ONE call (heavy_ranker.py:97-101 asks one question at a time with
+// limit = 1).  Nothing is allocated per call and no copy operation is queued: the queries are copied by the CPU into a pinned,
+// device-mapped buffer of the handle which the first kernel reads over the bus (3 KB per query), the last merge writes the k
+// results straight into pinned memory, and the host waits by polling the stream instead of sleeping on an interrupt.
+extern "C" int vqa_index_search_host(vqa_index* ix, const void* q_host, int32_t q_dtype, int32_t B, int32_t k, int32_t normalize,
+                                     float* out_scores, int64_t* out_ids, int64_t* out_pos_or_null, void* hip_stream) {
+    VQA_REQUIRE(ix, "vqa_index_search_host: index is null");
+    VQA_REQUIRE(q_host && out_scores && out_ids, "vqa_index_search_host: null pointer");
+    VQA_REQUIRE(B >= 1 && B <= 65536, "vqa_index_search_host: B=%d outside [1, 65536]", B);
+    VQA_REQUIRE(k >= 1 && k <= VQA_MAX_K_TOTAL, "vqa_index_search_host: k=%d outside [1, %d]", k, VQA_MAX_K_TOTAL);
+    VQA_REQUIRE(q_dtype == VQA_F32 || q_dtype == VQA_F16, "vqa_index_search_host: q_dtype %d is not f32/f16", q_dtype);
+    VQA_REQUIRE(!normalize || q_dtype == VQA_F32, "vqa_index_search_host: only fp32 queries can be L2-normalised by the call");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    HandleBusy busy(ix->busy);
+    VQA_REQUIRE(busy.ok, "vqa_index_search_host: this index handle is in use by another host thread (one call at a time per handle)");
+    DeviceGuard guard(ix->device);
+    const size_t qbytes = (size_t)B * ix->d * (q_dtype == VQA_F32 ? 4 : 2), nres = (size_t)B * k;
+    const size_t q_off = 0, s_off = (qbytes + 63) / 64 * 64, i_off = s_off + (nres * 4 + 63) / 64 * 64, p_off = i_off + nres * 8;
+    const size_t need = p_off + nres * 8;
+    if (ix->hio_bytes < need || (normalize && ix->hq_norm_bytes < qbytes)) {
+        VQA_HIP_CHECK(hipStreamSynchronize(stream));  // (an earlier call's kernels may still read the buffers about to be replaced)
+        if (ix->hio_bytes < need) {
+            if (ix->hio) (void)hipHostFree(ix->hio);
+            ix->hio = ix->hio_dev = nullptr;
+            ix->hio_bytes = 0;
+            const size_t cap = std::max<size_t>(need, 64 << 10);
+            if (hipHostMalloc(&ix->hio, cap, hipHostMallocMapped) != hipSuccess ||
+                hipHostGetDevicePointer(&ix->hio_dev, ix->hio, 0) != hipSuccess) {
+                (void)hipGetLastError();
+                vqa_set_error("vqa_index_search_host: allocating %zu pinned bytes failed", cap);
+                return VQA_ENOMEM;
+            }
+            ix->hio_bytes = cap;
+        }
+        if (normalize && ix->hq_norm_bytes < qbytes) {
+            if (ix->hq_norm) (void)hipFree(ix->hq_norm);
+            ix->hq_norm = nullptr;
+            ix->hq_norm_bytes = 0;
+            const size_t cap = std::max<size_t>(qbytes, 64 << 10);
+            if (hipMalloc(&ix->hq_norm, cap) != hipSuccess) {
+                (void)hipGetLastError();
+                vqa_set_error("vqa_index_search_host: allocating %zu device bytes failed", cap);
+                return VQA_ENOMEM;
+            }
+            ix->hq_norm_bytes = cap;
+        }
+    }
+    char* h = static_cast<char*>(ix->hio);
+    char* dv = static_cast<char*>(ix->hio_dev);
+    memcpy(h + q_off, q_host, qbytes);
+    const void* q_dev = dv + q_off;
+    if (normalize) {  // x / ||x|| by the kernel every other path uses (Embeddings.batchsearch, vqa_normalize_convert): the same bits
+        int rc = vqa_normalize_convert(reinterpret_cast<const float*>(dv + q_off), B, ix->d, 1, VQA_F32, ix->hq_norm, stream);
+        if (rc != VQA_OK) return rc;
+        q_dev = ix->hq_norm;
+    }
+    int rc = search_impl(ix, q_dev, q_dtype, B, k, reinterpret_cast<float*>(dv + s_off), reinterpret_cast<int64_t*>(dv + i_off),
+                         out_pos_or_null ? reinterpret_cast<int64_t*>(dv + p_off) : nullptr, stream);
+    if (rc != VQA_OK) return rc;
+    // poll: a search of a small shard is a handful of launches of a few microseconds; sleeping on the completion interrupt costs more
+    // than they take.  After ~0.2 ms of polling (large shards) the blocking wait takes over.
+    hipError_t st = hipErrorNotReady;
+    for (int spin = 0; spin < 400 && st == hipErrorNotReady; ++spin) st = hipStreamQuery(stream);
+    if (st == hipErrorNotReady) {
+        (void)hipGetLastError();
+        st = hipStreamSynchronize(stream);
+    }
+    if (st != hipSuccess) {
+        vqa_set_error("vqa_index_search_host: waiting for the search failed: %s", hipGetErrorString(st));
+        return VQA_EHIP;
+    }
+    memcpy(out_scores, h + s_off, nres * 4);
+    memcpy(out_ids, h + i_off, nres * 8);
+    if (out_pos_or_null) memcpy(out_pos_or_null, h + p_off, nres * 8);
+    return VQA_OK;
+}
+
+static int search_impl(vqa_index* ix, const void* q, int32_t q_dtype, int32_t B, int32_t k, float* out_scores, int64_t* out_ids,
+                       int64_t* out_pos_or_null, hipStream_t stream) {
+    const int max_k = vqa_score_topk_max_k(ix->dtype);  // per pass over the index
     const int qeb = q_dtype == VQA_F32 ? 4 : 2;
     const LaunchPlan p = plan_launch(ix, k);
     bool sketch_call = false;  // some query tile of this call ran the sketch search

@@ -258,6 +258,33 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + copysignf(e, x));
 }
 
+// erf GELU of the tile GEMM's epilogue (FFN1: 128 values per lane of a 256 x 256 tile): x Phi(x) with Phi by LINEAR INTERPOLATION in a
+// table held in LDS -- 7 VALU operations and one ds_read_b64 per value against ~15.6 VALU + v_rcp + v_exp of gelu_erf (the GELUs were
+// 6 us of the packed FFN1's 37, VALU-issue-bound: profiles/r04_encoder_gemm_variants.txt).  Table: kGeluN intervals of 1 / 64 over
+// [-8, 8), entry i = {Phi(x_i), Phi(x_i + 1/64) - Phi(x_i)} computed in double; interpolation error <= h^2 / 8 max |Phi''| = 7.4e-6
+// in Phi, i.e. <= 7.4e-6 |x| in the GELU -- 1 / 50 of the fp16 spacing the result is stored with.  Beyond +-8 the end entries apply
+// (Phi = 6e-16 / 1 - 6e-16).
+constexpr int kGeluN = 1024;
+constexpr int kGeluBytes = kGeluN * 8;
+__device__ float2 g_gelu_tab[kGeluN];
+
+__global__ void gelu_table_kernel() {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= kGeluN) return;
+    const double x0 = (double)i / 64.0 - 8.0, x1 = (double)(i + 1) / 64.0 - 8.0;
+    const double p0 = 0.5 * (1.0 + erf(x0 * 0.70710678118654752440)), p1 = 0.5 * (1.0 + erf(x1 * 0.70710678118654752440));
+    g_gelu_tab[i] = make_float2((float)p0, (float)(p1 - p0));
+}
+
+__device__ __forceinline__ float gelu_tab(float x, const char* __restrict__ tab_lds) {
+    float t = __builtin_fmaf(x, 64.0f, 512.0f);
+    t = __builtin_amdgcn_fmed3f(t, 0.0f, 1023.99994f);  // (a NaN input comes out as 0 x anything: the GEMM's operands are finite)
+    const float fr = __builtin_amdgcn_fractf(t);
+    const unsigned idx = (unsigned)t;  // t >= 0: truncation = floor
+    const float2 e = *reinterpret_cast<const float2*>(tab_lds + (idx << 3));
+    return x * __builtin_fmaf(fr, e.y, e.x);
+}
+
 // ---- GEMM: C[M, N] = A[M, K] . W[N, K]^T + bias[N]; EPI 0: identity, 1: erf GELU.  K % 64 == 0 (BK = 64) or K % 32 == 0
 // (BK = 32 instantiation for small hidden sizes). -----------------------------------------------------------------------
 constexpr int kGemmBM = 128, kGemmBN = 128;
@@ -390,15 +417,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const _Float16* __restrict
 // roles: A operand = weight rows, B operand = token rows, so a lane's 4 accumulator values are 4 consecutive output features
 // of one token.  Token rows past M are read (and their results dropped): the caller's activation buffers are padded to 256 rows.
 // EPI 0: + bias; 1: + bias, erf GELU; 2: + bias + residual row (the residual add of the post-LN block, fused here).
+#ifndef VQA_GELU_TABLE
+#define VQA_GELU_TABLE 1  // 0: the polynomial form in the tile kernel's epilogue too (dev / A-B switch)
+#endif
 #ifndef VQA_GEMM_ABLATE
 #define VQA_GEMM_ABLATE 0  // dev-only timing ablations (wrong results): 1 no epilogue stores, 2 no GELU, 4 no MFMAs in the K loop
 #endif
-template <int BM, int BN, int BK>
+template <int BM, int BN, int BK, int RESV = 0>
 struct TileGeom {
     static constexpr int kRowB = 2 * BK;  // bytes of every operand row per K-step (BK = 32 or 64 halves)
     static constexpr int kStageB = (BM + BN) * kRowB;
-    static constexpr int kStages = (160 * 1024 / kStageB) < 8 ? (160 * 1024 / kStageB) : 8;
-    static constexpr int kLds = kStages * kStageB;
+    static constexpr int kStages = ((160 * 1024 - RESV) / kStageB) < 8 ? ((160 * 1024 - RESV) / kStageB) : 8;
+    static constexpr int kRing = kStages * kStageB;
+    static constexpr int kLds = kRing + RESV;  // RESV bytes behind the ring: the GELU table of the EPI 1 form
     static constexpr int kPieceRows = 1024 / kRowB;               // rows of one 1 KiB piece: 16 or 8
     static constexpr int kPieces = (BM + BN) / kPieceRows;
     static constexpr int kPerWave = (kPieces + 7) / 8;
@@ -527,7 +558,7 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
                                                         const float* __restrict__ bias, const _Float16* __restrict__ R,
                                                         _Float16* __restrict__ C, int M, int N, int K, int tiles_n,
                                                         int tiles_total, int nb, FoldArgs fa) {
-    using G = TileGeom<BM, BN, BK>;
+    using G = TileGeom<BM, BN, BK, (EPI == 1 && VQA_GELU_TABLE) ? kGeluBytes : 0>;
     static_assert(WM * WN == 8 && BM % (16 * WM) == 0 && BN % (16 * WN) == 0, "8 waves, whole MFMA tiles per wave");
     constexpr int MT = BM / WM / 16, NT = BN / WN / 16;  // token / feature MFMA tiles per wave
     constexpr int S = G::kStages, D = S - 1, PR = G::kPieceRows, PA = BM / PR, NJ = G::kPerWave;
@@ -678,6 +709,16 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
         __builtin_amdgcn_s_barrier();           \
         __builtin_amdgcn_sched_barrier(0);      \
     } while (0)
+    // EPI 1: the GELU table -> LDS behind the ring, one 1 KiB LDS-DMA piece per wave, issued FIRST: every counted wait below is for
+    // younger pieces, so it has landed long before the first epilogue (and the barriers in between publish it to the other waves)
+    if constexpr (EPI == 1 && VQA_GELU_TABLE) {
+        uint32_t keep;
+        const uint32_t dst = lds_base + G::kRing + wave * 1024;
+        const char* src_tab = reinterpret_cast<const char*>(g_gelu_tab) + wave * 1024;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"((uint32_t)(lane * 16)), "s"(dst), "s"(src_tab) : "memory");
+    }
+    [[maybe_unused]] const char* const gelu_lds = lds + G::kRing;
     // prologue: K-steps 0 .. D - 1 issued, K-step 0 landed; group 1 holds fragments(0)
     for (int i = 0; i < D; ++i) issue_next();
     if constexpr (ONEBAR == 1) wait_keep(std::integral_constant<int, (D >= 2 ? D - 2 : 0)>{}, std::integral_constant<int, 0>{});  // K-steps 0, 1 landed
@@ -952,8 +993,13 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
                         }
 #if !(VQA_GEMM_ABLATE & 2)
                         if (EPI == 1) {
-                            v0 = gelu_erf(v0);
-                            v1 = gelu_erf(v1);
+                            if constexpr (VQA_GELU_TABLE) {
+                                v0 = gelu_tab(v0, gelu_lds);
+                                v1 = gelu_tab(v1, gelu_lds);
+                            } else {
+                                v0 = gelu_erf(v0);
+                                v1 = gelu_erf(v1);
+                            }
                         }
 #endif
                         if constexpr (EPI == 2) {
@@ -991,7 +1037,7 @@ __global__ __launch_bounds__(512) void gemm_tile_kernel(const _Float16* __restri
                         if constexpr (FOLD && EPI != 2) v = acc[NT - 1][mi][j] * rs[mi] - mrs[mi] * tvec[1][j] + tvec[0][j];
                         else v = acc[NT - 1][mi][j] + tvec[0][j];
 #if !(VQA_GEMM_ABLATE & 2)
-                        if (EPI == 1) v = gelu_erf(v);
+                        if (EPI == 1) v = VQA_GELU_TABLE ? gelu_tab(v, gelu_lds) : gelu_erf(v);
 #endif
                         if constexpr (EPI == 2) {
                             if constexpr (FOLD) v += ((float)tres[mi][j] * rs[mi] - mrs[mi]) * tvec[1][j] + tvec[2][j];
@@ -1587,11 +1633,16 @@ constexpr int kTokenPad = 256;  // activation buffers are padded to this many ro
 template <int EPI, int BM, int BN, int WM, int WN, int BK, int FOLD = 0, int ONEBAR = 0, int TIL = 0>
 int launch_tile(const _Float16* A, const _Float16* W, const float* bias, const _Float16* R, _Float16* C, int M, int N, int K,
                 int num_cu, hipStream_t s, const FoldArgs& fa = FoldArgs{}) {
-    using G = TileGeom<BM, BN, BK>;
+    using G = TileGeom<BM, BN, BK, (EPI == 1 && VQA_GELU_TABLE) ? kGeluBytes : 0>;
     static VqaPerDeviceOnce once;
     int rc = once.run([&](int) -> int {
         VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<EPI, BM, BN, WM, WN, BK, FOLD, ONEBAR, TIL>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::kLds));
+        if (EPI == 1 && VQA_GELU_TABLE) {  // the device's GELU table (a first call of a shape is never inside a graph capture)
+            hipLaunchKernelGGL(gelu_table_kernel, dim3(kGeluN / 256), dim3(256), 0, nullptr);
+            VQA_HIP_CHECK(hipGetLastError());
+            VQA_HIP_CHECK(hipStreamSynchronize(nullptr));
+        }
         return VQA_OK;
     });
     if (rc != VQA_OK) return rc;

@@ -54,6 +54,7 @@ def _e4m3_decode_table() -> np.ndarray:
 
 
 FORMAT_VERSION = 1
+HOST_PATH_MAX_QUERIES = 64  # host-resident query batches up to this size take vqa_index_search_host (larger ones: the torch path, asynchronous staging)
 
 Query = Union[str, np.ndarray, torch.Tensor, Sequence[float]]
 
@@ -318,10 +319,20 @@ class Embeddings:
             raise RuntimeError("the index is empty: call index()/load() first")
         if isinstance(queries, str):
             queries = [queries]
+        limit = int(limit)
+        # host-resident vector queries against one shard (the reference asks one question per call, heavy_ranker.py:97-101): the
+        # library's latency entry -- one call, no torch tensor on the way in or out
+        if isinstance(queries, np.ndarray) and queries.dtype == np.float64:
+            queries = queries.astype(np.float32)
+        if (isinstance(queries, np.ndarray) and queries.ndim == 2 and queries.dtype in (np.float32, np.float16) and
+                0 < queries.shape[0] <= HOST_PATH_MAX_QUERIES and not self._searcher.collective):
+            if queries.shape[1] != self.d:
+                raise ValueError(f"query dimension {queries.shape[1]} != index dimension {self.d}")
+            scores, ids = self._index.search_host(queries, limit, normalize=self.normalize and queries.dtype == np.float32)
+            return self._format(scores, ids)
         q = self._query_vectors(queries)
         if q.shape[1] != self.d:
             raise ValueError(f"query dimension {q.shape[1]} != index dimension {self.d}")
-        limit = int(limit)
         texts = list(queries) if not isinstance(queries, (np.ndarray, torch.Tensor)) and len(queries) and isinstance(queries[0], str) else None
         if self.hybrid and self._sparse is not None and texts is not None and 0.0 < self.weights < 1.0:
             return self._hybrid(q, texts, limit)

@@ -223,6 +223,35 @@ class DeviceIndex:
                     "vqa_index_search")
         return scores, ids, pos
 
+    def search_host(self, queries: np.ndarray, k: int, *, normalize: bool = False, return_positions: bool = False):
+        """The latency form (``vqa_index_search_host``): ``queries`` [B, d] float32 / float16 HOST array -> (scores [B, k] float32,
+        ids [B, k] int64[, positions]) as numpy arrays, synchronous -- one library call, no torch tensor, no per-call device
+        allocation, no copy operation (pinned device-mapped staging inside the handle).  ``normalize``: L2-normalise float32
+        queries on the device first (the same kernel, hence the same bits, as the batch path).  The reference's own pattern:
+        one question per call, limit 1 (``heavy_ranker.py:97-101``)."""
+        if not self._handle.value:
+            raise RuntimeError("index is closed")
+        q = np.ascontiguousarray(queries)
+        if q.ndim != 2 or q.shape[1] != self.d:
+            raise ValueError(f"queries must be a [B, {self.d}] array")
+        if q.dtype == np.float32:
+            qd = N.VQA_F32
+        elif q.dtype == np.float16:
+            qd = N.VQA_F16
+        else:
+            raise ValueError(f"queries must be float32 or float16, got {q.dtype}")
+        b = int(q.shape[0])
+        if b == 0:
+            raise ValueError("empty query batch")
+        scores = np.empty((b, k), dtype=np.float32)
+        ids = np.empty((b, k), dtype=np.int64)
+        pos = np.empty((b, k), dtype=np.int64) if return_positions else None
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        N.check(self._lib.vqa_index_search_host(self._handle, q.ctypes.data, qd, b, int(k), int(bool(normalize)), scores.ctypes.data,
+                                                ids.ctypes.data, pos.ctypes.data if pos is not None else None, stream),
+                "vqa_index_search_host")
+        return (scores, ids, pos) if return_positions else (scores, ids)
+
     def set_timing(self, enabled, *, resume: bool = False) -> None:
         """Bracket the main scoring launch of every search with an event pair (``resume``: keep the pairs recorded so far)."""
         N.check(self._lib.vqa_index_set_timing(self._handle, (2 if resume else 1) if enabled else 0), "vqa_index_set_timing")
