@@ -507,10 +507,17 @@ def main():
                                 "max_abs_score_diff": float((s_ex - s_sk).abs().max())}
         exact.close()
     if rank == 0 and world == 1 and not args.no_other and not args.no_cpu:
+        # small and ragged batches on the headline index (the 256-query MFMA tile is paid whatever B is): B = 1 and B = 257
+        big_latency = {}
+        for bb in (1, b + 1):
+            qb = torch.cat([q, q[:1]])[:bb].contiguous()
+            st, _ = timed_search(torch, index, qb, k, 20)
+            big_latency[f"batch{bb}_step_ms"] = round(st, 4)
         index.close()
         del shard
         torch.cuda.empty_cache()
         result["other_configs"] = other_configs(torch, np, device, dev_index, n, d, b, k)
+        result["other_configs"]["latency"][f"{n}_rows_{args.dtype}"] = big_latency
     if rank == 0:
         print(json.dumps(result), flush=True)
     index.close()
@@ -772,9 +779,60 @@ def other_configs(torch, np, device, dev_index, n, d, b, k):
     out["config0_api_1k"] = {"batch256_ms": round(t_batch * 1e3, 3), "single_query_ms": round(t_one * 1e3, 3),
                              "recall_at_10": R.recall_at_k(got, ref_ids)}
     emb._index.close()
+    out["latency"] = latency_legs(torch, np, device, dev_index, d)
     if d == 768:
         out["non_isotropic"] = non_isotropic_legs(torch, np, device, dev_index, b, k)
     out["reference_model_shapes"] = reference_model_shapes(torch, np, device, dev_index, b)
+    return out
+
+
+def latency_legs(torch, np, device, dev_index, d):
+    """The reference's real calling pattern (heavy_ranker.py:97-101): ONE question per call, limit = 1, a corpus of thousands of
+    documents.  Wall clock of `Embeddings.search(vector, 1)` (Python included; vqa_index_search_host underneath: no torch tensor, no
+    copy operation, polled completion) at 1k / 5k / 50k documents, checked against the oracle; and the question encoder alone on one
+    32-token question (event time of the replayed graph)."""
+    from oracle import retrieval as R
+    from vietnamese_qa_system_amd.embeddings import Embeddings
+    rng = np.random.default_rng(3)
+    out = {}
+    for rows in (1000, 5000, 50_000):
+        x = rng.standard_normal((rows, d)).astype(np.float32)
+        qs = rng.standard_normal((64, d)).astype(np.float32)
+        emb = Embeddings(dtype="fp16", device=dev_index)
+        emb.index_vectors(list(range(1, rows + 1)), x)
+        for j in range(10):
+            emb.search(qs[j], 1)
+        ts, got = [], []
+        for j in range(200):
+            t0 = time.perf_counter()
+            r = emb.search(qs[j % 64], 1)
+            ts.append(time.perf_counter() - t0)
+            if j < 64:
+                got.append(r[0][0] if r else -1)
+        stored = emb._index.get_rows()[0]
+        _, ref_ids, _ = R.search(R.l2_normalize(qs).astype(np.float32), stored, 1, dtype=R.DTYPE_F16, id_base=1)
+        ts = np.sort(np.asarray(ts)) * 1e3
+        out[f"search_one_vector_limit1_{rows}_docs_ms"] = {"median": round(float(np.median(ts)), 4), "p10": round(float(ts[20]), 4),
+                                                          "p90": round(float(ts[180]), 4), "top1_equals_oracle": bool(got == ref_ids[:, 0].tolist())}
+        emb._index.close()
+    if d == 768:
+        enc, ids, mask, _, _ = make_encoder(torch, device, dev_index, 1, 32, max_tokens=64)
+        for _ in range(5):
+            enc.forward(ids, mask, pooling="mean", normalize=True, real_tokens=0)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
+        for e0, e1 in ev:
+            e0.record()
+            enc.forward(ids, mask, pooling="mean", normalize=True, real_tokens=0)
+            e1.record()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(30):
+            enc.forward(ids, mask, pooling="mean", normalize=True, real_tokens=0)
+        torch.cuda.synchronize(device)
+        wall = (time.perf_counter() - t0) / 30
+        enc.close()
+        out["encoder_one_question_32_tokens_ms"] = {"event_median": round(float(np.median([e0.elapsed_time(e1) for e0, e1 in ev])), 4),
+                                                    "wall_back_to_back": round(wall * 1e3, 4)}
     return out
 
 

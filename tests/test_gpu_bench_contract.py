@@ -38,6 +38,12 @@ def test_bench_prints_one_json_line_with_the_contract_keys(native_lib):
     assert f8["recall_check"]["ok"] and f8["recall_check"]["stored_codes_equal_oracle_codes"] and f8["rows"] == 300000
     assert f8["recall_check"]["sampled_rows"] >= 1024 and f8["recall_check"]["queries"] == 256
     assert f32["recall_at_10"] == 1.0 and f32["recall_check"]["rows"] == f32["rows"] == 300000 and f32["recall_check"]["max_abs_score_err"] < 1e-5
+    lat = oc["latency"]
+    for rows in (1000, 5000, 50000):
+        one = lat[f"search_one_vector_limit1_{rows}_docs_ms"]
+        assert one["top1_equals_oracle"] and 0 < one["p10"] <= one["median"] <= one["p90"] < 5.0
+    assert lat["encoder_one_question_32_tokens_ms"]["event_median"] > 0
+    assert set(lat["300000_rows_fp16"]) == {"batch1_step_ms", "batch257_step_ms"}
     sm = r["step_ms"]
     assert sm["p10"] <= sm["median"] <= sm["p90"]
     e2e = r["end_to_end"]

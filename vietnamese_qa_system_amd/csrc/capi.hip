@@ -49,6 +49,7 @@ struct PlanRules {
     double profit_offset_f16 = 4e5;
     double per_row_ratio = 0.6;    // per-row form when ||mu||^2 >= 0.6 mean ||x||^2 (level with the centre split at 0.5, ahead from 0.7: r04_per_row_threshold.txt)
     int per_row_min_ksteps = 6;    // ... and rows of >= 6 K-steps of 64 bytes
+    int per_row_min_sample = 4096; // ... decided from at least min(n, 4096) rows of the first fill (a 1-row first fill always looked collapsed)
     int cooldown = 64;             // searches without the sketch after an overflow, doubling up to 64 x (r04_fallback_scan.txt: none of 576 shapes overflow unclustered)
 };
 static const PlanRules kPlan;
@@ -339,7 +340,10 @@ extern "C" int vqa_index_set_rows(vqa_index* ix, int64_t first, int64_t count, c
                 rcm = vqa_launch_center_dir(ix->mu, ix->d_pad8, ix->rotate, ix->wdir, nullptr);
                 if (rcm != VQA_OK) return rcm;
                 // rows collapsed onto the centre direction (an untrained / anisotropic encoder): the per-row form (convert.hip sketch_rows_kernel)
-                ix->per_row = ix->beta && (ix->per_row_env == 1 || (ix->per_row_env < 0 && row2 > 0.0 && n2 >= kPlan.per_row_ratio * row2));
+                // (the per-row form is irreversible: a first fill of a few rows -- a producer feeding row by row -- says nothing about the
+                // shard, and one row alone has ||mu||^2 == ||x||^2: at least min(n, 4096) sampled rows, or the centre split stays)
+                const bool enough = samples >= std::min<int64_t>(ix->n, kPlan.per_row_min_sample);
+                ix->per_row = ix->beta && (ix->per_row_env == 1 || (ix->per_row_env < 0 && enough && row2 > 0.0 && n2 >= kPlan.per_row_ratio * row2));
             }
         }
         int rc = vqa_launch_tile_scales(ix->rows, ix->dtype, t0, t1 - t0 + 1, ix->d_pad, ix->d_pad8, ix->tile_info, ix->rotate, ix->center ? ix->mu : nullptr, nullptr,
@@ -1154,6 +1158,7 @@ static int search_impl(vqa_index* ix, const void* q, int32_t q_dtype, int32_t B,
         // the device and raises wide_flag.  The exact continuation passes below are then launched GATED on the flag: they
         // return at once when the one-pass result stands (no host round trip), and overwrite it when it does not.
         const int* gate = nullptr;
+        MergeSketchTail cascade_report;  // (set by the cascade: the report its fallback's first merge carries)
         if (any_sketch && ix->cascade) {
             // A sketch shard, k <= 64, as a cascade of bounds -- no exact scan of a first stage at all:
             //   exact seeds (2 grid tiles: sub-maxima of real rows)  ->  theta0, a valid lower bound of the k-th best score;
@@ -1175,7 +1180,13 @@ static int search_impl(vqa_index* ix, const void* q, int32_t q_dtype, int32_t B,
             MergeSketchTail t0 = qconst_tail(ix, sk_clear), t2;
             t2.overflow = ix->sketch_flag;
             t2.min_score = ix->thr0;  // theta1: what the first selection left there
-            t2.flag_mirror = q0 + VQA_QUERY_TILE >= B ? ix->sketch_flag_dev_mirror : nullptr;
+            // the call's report to the host: written by the gated fallback's merge BEHIND the last selection (any block of that
+            // selection may still raise the overflow flag when block 0 is done: ADVICE r4), by the last query tile of the call
+            MergeSketchTail tm;
+            tm.overflow = ix->sketch_flag;
+            tm.flag_mirror = q0 + VQA_QUERY_TILE >= B ? ix->sketch_flag_dev_mirror : nullptr;
+            tm.mirror_before_gate = 1;
+            cascade_report = tm;
             rc = seed_pass(ix, pc, a, k, nullptr, stream, ix->thr_seed, &t0);  // theta0 -> thr_seed
             if (rc != VQA_OK) return rc;
             // the stages: [leading quarter of the first (k >= pre_k) |] first | [second (k >= mid_k or a large shard) |] the rest
@@ -1207,7 +1218,8 @@ static int search_impl(vqa_index* ix, const void* q, int32_t q_dtype, int32_t B,
                 rc = vqa_launch_score_topk(ix->dtype, a, stream);
                 if (rc != VQA_OK) return rc;
                 rc = vqa_launch_merge_partials(ix->partial, p.grid1, k, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr,
-                                               1.0f / (ix->scale * ix->scale), k, 0, nullptr, true, ix->sketch_flag, stream);
+                                               1.0f / (ix->scale * ix->scale), k, 0, nullptr, true, ix->sketch_flag, stream, 0, nullptr, 1,
+                                               &cascade_report);
                 if (rc != VQA_OK) return rc;
                 continue;
             }
@@ -1293,9 +1305,11 @@ static int search_impl(vqa_index* ix, const void* q, int32_t q_dtype, int32_t B,
             rc = vqa_launch_score_topk(ix->dtype, a, stream);
             if (rc != VQA_OK) return rc;
             if (time_it && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
+            const bool report_here = cascade_fallback && done == 0;  // (k > 12 behind a cascade: the first gated pass's merge reports)
             rc = vqa_launch_merge_partials(ix->partial, lists, kk, nq, kk, ix->ids, ix->id_base, os, oi, op, nullptr,
                                            1.0f / (ix->scale * ix->scale), k, done, done + kk < k ? ix->upper : nullptr, true,
-                                           staged && use_sketch ? ix->sketch_flag : gate, stream);
+                                           staged && use_sketch ? ix->sketch_flag : gate, stream, 0, nullptr, 1,
+                                           report_here ? &cascade_report : nullptr);
             if (rc != VQA_OK) return rc;
         }
     }

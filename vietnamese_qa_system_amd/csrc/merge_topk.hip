@@ -157,6 +157,17 @@ __device__ __forceinline__ void select_topk_radix(vqa_key* keys, int m, int k, v
     for (int t = threadIdx.x; t < k; t += kMergeThreads) win[t] = keys[t];
 }
 
+// a sketch call's flags -> the pinned mirror the host's pause logic reads: overflow of the last query tile, OR over the earlier ones, the
+// most pairs any tile scored exactly, and LAST (release) the call's number, which tells the host the report is complete
+__device__ __forceinline__ void publish_flags(const MergeSketchTail& tail) {
+    const int f0 = __hip_atomic_load(tail.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(tail.flag_mirror, f0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(tail.flag_mirror + 1, tail.overflow[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(tail.flag_mirror + 3, tail.overflow[4] > tail.overflow[3] ? tail.overflow[4] : tail.overflow[3], __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(tail.flag_mirror + 2, tail.overflow[2], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa_key* __restrict__ partial, int parts,
                                                                        int list_len, int k,
                                                                        const long long* __restrict__ ids,
@@ -169,6 +180,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
                                                                        const int* __restrict__ gate, int row_lists,
                                                                        const unsigned* __restrict__ counts, int count_stride,
                                                                        MergeSketchTail tail, int cap_keys) {
+    if (tail.flag_mirror && tail.mirror_before_gate && blockIdx.x == 0 && threadIdx.x == 0) publish_flags(tail);
     if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     vqa_key* keys = reinterpret_cast<vqa_key*>(smem);    // [cap_keys] (= parts * list_len unless the lists are longer than LDS: counts form)
@@ -281,14 +293,7 @@ __global__ __launch_bounds__(kMergeThreads) void merge_partials_kernel(const vqa
             }
         }
     }
-    if (tail.flag_mirror && q == 0 && threadIdx.x == 0) {
-        __hip_atomic_store(tail.flag_mirror, tail.overflow[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(tail.flag_mirror + 1, tail.overflow[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        // the most pairs any query tile of the call scored exactly: the host's profitability check
-        __hip_atomic_store(tail.flag_mirror + 3, tail.overflow[4] > tail.overflow[3] ? tail.overflow[4] : tail.overflow[3], __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(tail.flag_mirror + 2, tail.overflow[2], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    if (tail.flag_mirror && !tail.mirror_before_gate && q == 0 && threadIdx.x == 0) publish_flags(tail);
 }
 
 // Large k: the k rounds of the selection kernel above cost ~1.5 us each; past k = 32 the lists are sorted instead --

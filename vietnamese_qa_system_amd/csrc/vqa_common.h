@@ -149,6 +149,9 @@ struct MergeSketchTail {
     int* overflow = nullptr;
     int clear = 0, seq = 0;
     int* flag_mirror = nullptr;
+    int mirror_before_gate = 0;  // 1: this launch only REPORTS -- block 0 copies the flags to flag_mirror before the gate test, whatever the gate
+                                 // says.  The cascade's last selection raises overflow[0] from any of its blocks, so the report is written by the
+                                 // launch BEHIND it (the gated fallback's merge), when every block of the selection has finished
     const float* min_score = nullptr;  // [nq] or nullptr: keys scoring below it are dropped before the selection (the cascade's last merge:
                                        // theta1, the exact k-th best score of the first stage -- no key below it can be among the k best);
                                        // a list that still overflows the kernel's LDS raises overflow[0]: the search's exact fallback runs

@@ -170,7 +170,8 @@ class Embeddings:
             if total == 0:
                 vectors, total = torch.zeros((0, 1)), None
         self.index_vectors([d["id"] for d in docs], vectors, documents=docs if self.content else None, total=total,
-                           chunk_rows=max(int(batch_size), 1) * 8)
+                           # (the shard's sketch takes its centre from the FIRST chunk written: at least 65 536 rows of it)
+                           chunk_rows=max(max(int(batch_size), 1) * 8, 1 << 16))
         if self.hybrid:  # every rank indexes the whole corpus' text (host side, small next to the vectors)
             self._sparse = BM25Index().index(str(d.get("text", "")) for d in docs)
 
