@@ -187,9 +187,10 @@ def test_hybrid_search_against_hand_computed_expectation(native_lib):
 def test_index_streams_every_document_through_the_encoder_exactly_once(native_lib):
     """``Embeddings.index(documents)`` feeds the shard chunk by chunk from the encoder (row-producer path).  The encoder hook
     may be stateful (a tokenizer reading from a stream) and an encoder call costs a forward: every document is asked for
-    once, in order, in chunks of ``8 * batch_size`` -- no one-row probe to learn the dimension."""
+    once, in order, in chunks of ``max(8 * batch_size, 65 536)`` rows (the first chunk written fixes the centre of the shard's sketch:
+    it must be a fair sample) -- no one-row probe to learn the dimension."""
     from vietnamese_qa_system_amd import Embeddings
-    d, n = 48, 1000
+    d, n = 48, 140_000
     rng = np.random.default_rng(3)
     table = R.l2_normalize(rng.standard_normal((n, d)).astype(np.float32))
     calls = []
@@ -201,8 +202,8 @@ def test_index_streams_every_document_through_the_encoder_exactly_once(native_li
 
     docs = [{"id": i + 1, "text": f"doc {i}"} for i in range(n)]
     emb = Embeddings(encoder=encoder, content=True)
-    emb.index(docs, batch_size=16)  # chunks of 128 documents
-    assert calls == [128] * 7 + [104]
+    emb.index(docs, batch_size=16)
+    assert calls == [65536, 65536, 8928]
     calls.clear()
     hit = emb.search("doc 517", 1)[0]
     assert calls == [1] and hit["id"] == 518 and hit["text"] == "doc 517" and abs(hit["score"] - 1.0) < 2e-3
