@@ -64,7 +64,7 @@ int main() {
         if (rc_short == VQA_OK) vqa_index_destroy(ix);
         vqa_encoder_options eo;
         vqa_encoder_options_init(&eo);
-        EXPECT(eo.struct_size == sizeof(eo) && eo.fold_layernorm == 1 && eo.first_rows == 1 && eo.graphs == 1);
+        EXPECT(eo.struct_size == sizeof(eo) && eo.fold_layernorm == 1 && eo.first_rows == 1 && eo.graphs == 1 && eo.latency_path == 1);
     }
     int rc = vqa_index_create(&ix, 0, 1000, 64, VQA_F16, nullptr, VQA_F16, nullptr, 1, 0);
     if (rc == VQA_OK) {  // a device is visible: create / use-after-bad-args / destroy cycles

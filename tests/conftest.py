@@ -34,7 +34,7 @@ _INDEX_OPTION = {"VQA_STAGE_MIN": "stage_min_tiles", "VQA_STAGE_PCT": "stage_pct
                  "VQA_SKETCH_CENTER": "sketch_center", "VQA_SKETCH_PER_ROW": "sketch_per_row", "VQA_SKETCH_ROTATE": "sketch_rotate",
                  "VQA_SKETCH_COOLDOWN": "sketch_cooldown", "VQA_SKETCH_PROFIT": "sketch_profit", "VQA_SKETCH_SPLIT": "sketch_split",
                  "VQA_F16_LOOP": "f16_loop", "VQA_RESCORE_COPY": "rescore_copy"}
-_ENCODER_OPTION = {"VQA_ENC_FOLD": "fold_layernorm", "VQA_ENC_FIRST_ROWS": "first_rows", "VQA_ENCODER_GRAPH": "graphs"}
+_ENCODER_OPTION = {"VQA_ENC_FOLD": "fold_layernorm", "VQA_ENC_FIRST_ROWS": "first_rows", "VQA_ENCODER_GRAPH": "graphs", "VQA_ENC_TINY": "latency_path"}
 
 
 def set_option(monkeypatch, name, value):

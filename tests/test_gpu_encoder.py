@@ -443,3 +443,45 @@ def test_hidden_states_of_every_layer_match_hf(native_lib, golden_dir, name, bas
     with pytest.raises(ValueError):
         enc.hidden_states(ids, mask, 5)
     enc.close()
+
+
+# ---- the latency form (gemm_tiny_kernel): one question, <= 64 positions, PhoBERT / XLM-R base sizes -- five launches per layer, the
+# LayerNorms inside the GEMMs.  Token counts 16 / 27 / 48 / 64 take 1 / 2 / 3 / 4 token tiles of 16.
+@pytest.mark.parametrize("b,l", [(1, 16), (1, 32), (3, 9), (2, 24), (1, 64), (2, 32)])
+def test_latency_form_matches_the_general_kernels_and_the_oracle(native_lib, monkeypatch, b, l):
+    from vietnamese_qa_system_amd.encoder import QuestionEncoder
+    cfg = dict(E.PHOBERT_BASE, layers=3)
+    w = E.synthetic_weights(cfg, seed=21, layers=3)
+    rng = np.random.default_rng(4)
+    for k_ in list(w):  # LayerNorm parameters away from (1, 0): the folded gamma / beta terms carry weight
+        if "LayerNorm.weight" in k_:
+            w[k_] = (1.0 + 0.3 * rng.standard_normal(w[k_].shape)).astype(np.float32)
+        elif "LayerNorm.bias" in k_:
+            w[k_] = (0.2 * rng.standard_normal(w[k_].shape)).astype(np.float32)
+    ids, mask = E.synthetic_tokens(cfg, b, l, seed=40 + b + l, min_len=min(5, l))
+    out, hid = {}, {}
+    for on in (1, 0):
+        set_option(monkeypatch, "VQA_ENC_TINY", on)
+        enc = QuestionEncoder(w, cfg, max_tokens=b * l)
+        assert enc.options.latency_path == on
+        for rep in range(3):  # eager, graph capture + replay, replay
+            out[on, rep] = {p: enc.forward(ids, mask, pooling=p).cpu().numpy() for p in ("cls", "mean")}
+        hid[on] = [enc.hidden_states(ids, mask, n).cpu().numpy() for n in (0, 1, 3)]
+        enc.close()
+    real = mask.astype(bool)
+    w64 = {k_: np.asarray(v, np.float64) for k_, v in w.items()}
+    x = E.embed(w64, cfg, ids)
+    refs = [x]
+    for i in range(3):
+        x = E.layer_forward(w64, cfg, i, x, mask)
+        refs.append(x)
+    for p in ("cls", "mean"):
+        ref = E.encode(w, cfg, ids, mask, pooling=p)
+        for rep in range(3):
+            assert np.array_equal(out[1, rep][p], out[1, 0][p])  # the replayed graph returns the eager call's bits
+            d, cos, _ = parity(out[1, rep][p], ref)
+            assert d <= 7e-4 and 1 - cos <= 5.2e-6, (p, rep, d, 1 - cos)  # BOUNDS["phobert", 2]
+        assert np.abs(out[1, 0][p] - out[0, 0][p]).max() < 2e-3
+    for j, n in enumerate((0, 1, 3)):
+        for on in (1, 0):
+            check_parity(f"latency form={on} b={b} l={l} hidden_states[{n}]", hid[on][j][real], refs[n][real], *BOUNDS["hidden_phobert"])

@@ -1166,6 +1166,157 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const _Float16* __rest
     }
 }
 
+// ---- GEMM for ONE question (M <= 64 tokens, K a multiple of 768): the latency form of the reference's own calling pattern --
+// heavy_ranker.py:97-101 asks one question per call.  A forward of 32 tokens is a chain of small launches whose time is the
+// weight stream's first-byte latency, so (a) every load of a wave is in flight before its first MFMA -- eight waves split K, each
+// issues its weight fragments and its token fragments of its K / 8 range at once (gemm_skinny_kernel kept two K-blocks in flight
+// and paid a memory round trip per 64 k) -- and (b) the two LayerNorm launches of a layer disappear: FOLDIN = 1 (QKV, FFN1) runs on
+// the RAW residual sum with the gamma-scaled weights of the tile kernel's fold (Wf, column sums, bias + W beta), adds up every
+// row's sum and sum of squares from the fragments it loads anyway and applies (rstd, mean rstd) in its epilogue; it also writes
+// (mean, rstd) per row, with which the next EPI 2 GEMM (out-projection, FFN2) normalises the residual row it adds.  Five launches
+// per layer instead of seven, each a single memory round trip deep.
+// Lane roles as in gemm_skinny_kernel: A operand = 16 weight rows (features n0 + c), B operand = token rows; a K-block is 32 deep.
+struct TinyArgs {
+    const float* cvec = nullptr;   // FOLDIN: column sums of the folded weights [N]
+    float2* st_out = nullptr;      // FOLDIN: (mean, rstd) of every input row, written by workgroup 0 [M]
+    const float2* st_in = nullptr; // EPI 2 with g != nullptr: (mean, rstd) of the residual's raw rows [M]
+    const float* g = nullptr;      // EPI 2: gamma / beta of the LayerNorm of the residual (nullptr: the residual is added as it is)
+    const float* b = nullptr;
+    float inv_k = 0.f, eps = 0.f;
+};
+
+template <int EPI, int MT, int FOLDIN, int NBC>  // MT token tiles of 16; NBC K-blocks per chunk (all of a chunk's loads in flight together)
+__global__ __launch_bounds__(512) void gemm_tiny_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+                                                        const float* __restrict__ bias, const _Float16* __restrict__ R,
+                                                        _Float16* __restrict__ C, int M, int N, int K, TinyArgs ta) {
+    __shared__ f32x4 red[7][MT][64];
+    __shared__ float2 sred[8][MT][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int kq = K >> 3;  // this wave's K range [wave kq, +kq): a multiple of 32 NBC
+    const int kbase = wave * kq;
+    const _Float16* wp = W + (size_t)(n0 + c) * K + kbase + 8 * g;
+    const _Float16* ap[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        const int row = mi * 16 + c < M ? mi * 16 + c : M - 1;  // rows past M: a copy of the last row, dropped
+        ap[mi] = A + (size_t)row * K + kbase + 8 * g;
+    }
+    f32x4 acc[MT];
+    float s1[MT], s2[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        s1[mi] = s2[mi] = 0.f;
+    }
+    // wave 0 runs the epilogue: its per-feature vectors, residual rows and row statistics are requested NOW, in front of the K loop's
+    // loads (behind the barrier they would be one more memory round trip on the launch's critical path: ~1.5 us of a 5 us launch)
+    typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+    f32x4 bv = f32x4{0.f, 0.f, 0.f, 0.f}, cv = bv, gv = bv, bb = bv;
+    half4 res[MT];
+    float2 st[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        res[mi] = half4{0, 0, 0, 0};
+        st[mi] = make_float2(0.f, 1.f);
+    }
+    if (wave == 0) {
+        bv = *reinterpret_cast<const f32x4*>(bias + n0 + 4 * g);
+        if constexpr (FOLDIN) cv = *reinterpret_cast<const f32x4*>(ta.cvec + n0 + 4 * g);
+        if (EPI == 2 && ta.g) {
+            gv = *reinterpret_cast<const f32x4*>(ta.g + n0 + 4 * g);
+            bb = *reinterpret_cast<const f32x4*>(ta.b + n0 + 4 * g);
+        }
+        if (EPI == 2) {
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+                const int m = mi * 16 + c < M ? mi * 16 + c : M - 1;
+                res[mi] = *reinterpret_cast<const half4*>(R + (size_t)m * N + n0 + 4 * g);
+                if (ta.g) st[mi] = ta.st_in[m];
+            }
+        }
+    }
+    for (int k0 = 0; k0 < kq; k0 += 32 * NBC) {
+        half8 wf[NBC], xf[NBC][MT];
+#pragma unroll
+        for (int j = 0; j < NBC; ++j) wf[j] = *reinterpret_cast<const half8*>(wp + k0 + 32 * j);
+#pragma unroll
+        for (int j = 0; j < NBC; ++j)
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) xf[j][mi] = *reinterpret_cast<const half8*>(ap[mi] + k0 + 32 * j);
+        // every load of the chunk is issued before the first MFMA (left alone, hipcc interleaves them with the MFMAs to save registers:
+        // a memory round trip per few K-blocks again)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NBC; ++j)
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) {
+                acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[j], xf[j][mi], acc[mi], 0, 0, 0);
+                if constexpr (FOLDIN) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = (float)xf[j][mi][e];
+                        s1[mi] += v;
+                        s2[mi] += v * v;
+                    }
+                }
+            }
+    }
+    if constexpr (FOLDIN) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {  // the four k-subblocks g of row c
+            s1[mi] += __shfl_xor(s1[mi], 16, 64);
+            s1[mi] += __shfl_xor(s1[mi], 32, 64);
+            s2[mi] += __shfl_xor(s2[mi], 16, 64);
+            s2[mi] += __shfl_xor(s2[mi], 32, 64);
+            if (g == 0) sred[wave][mi][c] = make_float2(s1[mi], s2[mi]);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) red[wave - 1][mi][lane] = acc[mi];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    f32x4 total[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        total[mi] = acc[mi];
+#pragma unroll
+        for (int w = 0; w < 7; ++w) total[mi] += red[w][mi][lane];  // fixed order: deterministic
+    }
+    // total[mi][j] = C[token 16 mi + c][feature n0 + 4 g + j]
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        const int m = mi * 16 + c;
+        const f32x4 sum = total[mi];
+        float rstd = 1.f, mrs = 0.f;
+        if constexpr (FOLDIN) {
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                a1 += sred[w][mi][c].x;
+                a2 += sred[w][mi][c].y;
+            }
+            const float mean = a1 * ta.inv_k;
+            rstd = rsqrtf(fmaxf(a2 * ta.inv_k - mean * mean, 0.f) + ta.eps);
+            mrs = mean * rstd;
+            if (ta.st_out && blockIdx.x == 0 && g == 0 && m < M) ta.st_out[m] = make_float2(mean, rstd);
+        }
+        if (m >= M) continue;
+        half4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = FOLDIN ? sum[j] * rstd - mrs * cv[j] + bv[j] : sum[j] + bv[j];
+            if (EPI == 1) v = gelu_erf(v);
+            if (EPI == 2) v += ta.g ? ((float)res[mi][j] - st[mi].x) * st[mi].y * gv[j] + bb[j] : (float)res[mi][j];
+            o[j] = (_Float16)v;
+        }
+        *reinterpret_cast<half4*>(C + (size_t)m * N + n0 + 4 * g) = o;
+    }
+}
+
 // ---- attention: one workgroup per (sequence, head); K and V of the head in LDS (fp32), one wave per query row ------
 __global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ mask,
                                                         int L, int H, int heads, _Float16* __restrict__ ctx) {
@@ -1526,6 +1677,8 @@ struct vqa_encoder {
     // activations
     _Float16 *x = nullptr, *qkv = nullptr, *ctx = nullptr, *tmp = nullptr, *ffn = nullptr;
     float2 *st_x = nullptr, *st_tmp = nullptr;  // folded LayerNorms: the statistics slots of the raw rows in x / tmp, [rows][16]
+    float2 *tiny_x = nullptr, *tiny_tmp = nullptr;  // the latency form (gemm_tiny_kernel): (mean, rstd) of the raw rows in x / tmp, [64]
+    bool tiny_on = true;                            // vqa_encoder_options.latency_path
     bool fold_on = true;                        // VQA_ENC_FOLD=0 at create: dev / test switch
     // small batches are launch-bound (12 layers x 7 kernels of a few microseconds each): their launch sequence is captured
     // once per (B, L, pooling, normalize) into a hipGraph over these fixed staging buffers and replayed
@@ -1798,6 +1951,39 @@ int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, const _
     return VQA_OK;
 }
 
+// the latency form's shapes: M <= 64 rows, K a multiple of 768 (K / 256 blocks per wave in chunks of 3, 6 or 12), N a multiple of 16
+constexpr int kTinyMaxM = 64;
+static bool tiny_shape(int M, int N, int K) { return M >= 1 && M <= kTinyMaxM && N % 16 == 0 && K % 768 == 0; }
+
+template <int EPI, int FOLDIN>
+int launch_gemm_tiny(const _Float16* A, const _Float16* W, const float* bias, const _Float16* R, _Float16* C, int M, int N, int K,
+                     const TinyArgs& ta, hipStream_t s) {
+    const int mt = (M + 15) / 16, nbw = K / 256;
+    // all of a wave's loads at once when they fit its registers (NBC (1 + MT) fragments of 4 registers), else in two or more chunks
+    const int nbc = (nbw % 12 == 0 && mt <= 2) ? 12 : (nbw % 6 == 0 && mt <= 4) ? 6 : 3;
+#define VQA_TINY(MT, NBC)                                                                                                       \
+    hipLaunchKernelGGL((gemm_tiny_kernel<EPI, MT, FOLDIN, NBC>), dim3(N / 16), dim3(512), 0, s, A, W, bias, R, C, M, N, K, ta)
+#define VQA_TINY_MT(NBC)                                   \
+    switch (mt) {                                          \
+        case 1: VQA_TINY(1, NBC); break;                   \
+        case 2: VQA_TINY(2, NBC); break;                   \
+        case 3: VQA_TINY(3, NBC); break;                   \
+        default: VQA_TINY(4, NBC); break;                  \
+    }
+    if (nbc == 12) {
+        if (mt == 1) VQA_TINY(1, 12);
+        else VQA_TINY(2, 12);
+    } else if (nbc == 6) {
+        VQA_TINY_MT(6)
+    } else {
+        VQA_TINY_MT(3)
+    }
+#undef VQA_TINY
+#undef VQA_TINY_MT
+    VQA_HIP_CHECK(hipGetLastError());
+    return VQA_OK;
+}
+
 }  // namespace
 
 #ifdef VQA_DEV
@@ -1865,6 +2051,7 @@ extern "C" void vqa_encoder_options_init(vqa_encoder_options* o) {
     o->fold_layernorm = 1;
     o->first_rows = 1;
     o->graphs = 1;
+    o->latency_path = 1;
 }
 
 extern "C" int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encoder_config* cfg, const vqa_encoder_weights* w,
@@ -1887,6 +2074,7 @@ extern "C" int vqa_encoder_create_ex(vqa_encoder** out, int device, const vqa_en
     if (const char* v = vqa_dev_env("VQA_ENC_FIRST_ROWS")) o.first_rows = atoi(v) != 0;
     if (const char* v = vqa_dev_env("VQA_ENC_FOLD")) o.fold_layernorm = atoi(v) != 0;
     if (const char* v = vqa_dev_env("VQA_ENCODER_GRAPH")) o.graphs = v[0] != '0';
+    if (const char* v = vqa_dev_env("VQA_ENC_TINY")) o.latency_path = v[0] != '0';
     VQA_REQUIRE(cfg && w && w->layer, "vqa_encoder_create: null config / weights");
     VQA_REQUIRE(cfg->hidden >= 32 && cfg->hidden <= 2048 && cfg->hidden % 32 == 0,
                 "vqa_encoder_create: hidden=%d must be a multiple of 32 in [32, 2048]", cfg->hidden);
@@ -1915,6 +2103,7 @@ extern "C" int vqa_encoder_create_ex(vqa_encoder** out, int device, const vqa_en
     e->max_tokens = max_tokens;
     e->first_rows_on = o.first_rows != 0;
     e->fold_on = o.fold_layernorm != 0;
+    e->tiny_on = o.latency_path != 0;
     const size_t H = cfg->hidden, F = cfg->ffn;
     int rc = VQA_OK;
     do {
@@ -1982,6 +2171,8 @@ extern "C" int vqa_encoder_create_ex(vqa_encoder** out, int device, const vqa_en
         if ((rc = dev_alloc(e, (void**)&e->ffn, T * F * 2)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->st_x, T * kRowStatSlots * sizeof(float2))) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->st_tmp, T * kRowStatSlots * sizeof(float2))) != VQA_OK) break;
+        if ((rc = dev_alloc(e, (void**)&e->tiny_x, kTinyMaxM * sizeof(float2))) != VQA_OK) break;
+        if ((rc = dev_alloc(e, (void**)&e->tiny_tmp, kTinyMaxM * sizeof(float2))) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->cu, ((size_t)max_tokens + 1) * 4)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->row_seq, (size_t)max_tokens * 4)) != VQA_OK) break;
         if ((rc = dev_alloc(e, (void**)&e->g_ids, (size_t)max_tokens * 4)) != VQA_OK) break;
@@ -2050,9 +2241,13 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
     const bool fold = e->fold_on && p_out >= 4 && p_out <= kRowStatSlots && p_out % 4 == 0 && p_ffn >= 4 && p_ffn <= kRowStatSlots &&
                       p_ffn % 4 == 0 && tile_stat_slots(T, 3 * H, H) > 0 && tile_stat_slots(T, F, H) > 0;
     const int st_stride = (e->max_tokens + kTokenPad - 1) / kTokenPad * kTokenPad;  // rows per statistics slot (the padded row count)
+    // one question (<= 64 positions, hidden / FFN sizes in multiples of 768): the latency form -- raw rows all the way, LayerNorms inside
+    // the GEMMs (gemm_tiny_kernel), five launches per layer
+    const bool tiny = e->tiny_on && e->fold_on && !packed && tiny_shape(T, 3 * H, H) && tiny_shape(T, F, H) && tiny_shape(T, H, F) &&
+                      att_mfma_head_size(dh) && L <= 32 * kAttMaxBlocks;
     hipLaunchKernelGGL(embed_ln_kernel, dim3(row_blocks), dim3(256), 0, s, input_ids, T, L, H, e->cfg.pad_id, e->cfg.vocab_size,
                        e->cfg.position_ids == VQA_POS_ABSOLUTE ? 1 : 0, e->bad_ids_dev, cu, e->row_seq, B, e->word, e->pos, e->type0, e->emb_g, e->emb_b, eps, e->x,
-                       fold ? e->st_x : (float2*)nullptr, st_stride);
+                       (fold || tiny) ? e->st_x : (float2*)nullptr, st_stride);
     VQA_HIP_CHECK(hipGetLastError());
     // fold: x holds RAW rows; (pg, pb, p_x) = gamma / beta / slots in use of the LayerNorm that belongs on them
     const float *pg = e->emb_g, *pb = e->emb_b;
@@ -2067,6 +2262,14 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
     for (const vqa_encoder::Layer& Ly : e->layers) {
         if (hidden_out && layers_done++ == stop_layers) break;
         int rc;
+        if (tiny) {
+            TinyArgs tq;
+            tq.cvec = Ly.cqkv;
+            tq.st_out = e->tiny_x;
+            tq.inv_k = inv_h;
+            tq.eps = eps;
+            rc = launch_gemm_tiny<0, 1>(e->x, Ly.wqkv_f, Ly.bqkv_f, nullptr, e->qkv, T, 3 * H, H, tq, s);
+        } else
         if (fold) rc = launch_gemm_fold<0>(e->x, Ly.wqkv_f, Ly.bqkv_f, nullptr, e->qkv, T, 3 * H, H,
                                            FoldArgs{e->st_x, p_x, st_stride, inv_h, eps, Ly.cqkv, nullptr, nullptr, nullptr}, s);
         else rc = launch_gemm<0>(e->x, Ly.wqkv, Ly.bqkv, nullptr, e->qkv, T, 3 * H, H, s);
@@ -2133,6 +2336,25 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
             VQA_HIP_CHECK(hipGetLastError());
             return VQA_OK;
         }
+        if (tiny) {
+            TinyArgs to, t1, t2;
+            to.st_in = e->tiny_x;  // residual = LN_prev(x): (mean, rstd) left by this layer's QKV launch
+            to.g = pg;
+            to.b = pb;
+            if ((rc = launch_gemm_tiny<2, 0>(e->ctx, Ly.wo, Ly.bo, e->x, e->tmp, T, H, H, to, s)) != VQA_OK) return rc;
+            t1.cvec = Ly.c1;
+            t1.st_out = e->tiny_tmp;
+            t1.inv_k = inv_h;
+            t1.eps = eps;
+            if ((rc = launch_gemm_tiny<1, 1>(e->tmp, Ly.w1_f, Ly.b1_f, nullptr, e->ffn, T, F, H, t1, s)) != VQA_OK) return rc;
+            t2.st_in = e->tiny_tmp;  // residual = LN1(tmp)
+            t2.g = Ly.ln1_g;
+            t2.b = Ly.ln1_b;
+            if ((rc = launch_gemm_tiny<2, 0>(e->ffn, Ly.w2, Ly.b2, e->tmp, e->x, T, H, F, t2, s)) != VQA_OK) return rc;
+            pg = Ly.ln2_g;
+            pb = Ly.ln2_b;
+            continue;
+        }
         if (fold) {
             // raw rows + statistics all the way: out-projection (residual = LN(x) applied in its epilogue) -> tmp, st_tmp;
             // FFN1 on tmp with LN1 folded; FFN2 (residual = LN1(tmp)) -> x, st_x; the next layer's QKV folds LN2
@@ -2159,15 +2381,27 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
         launch_ln(e->tmp, T, H, Ly.ln2_g, Ly.ln2_b, eps, e->x, s);
         VQA_HIP_CHECK(hipGetLastError());
     }
+    const _Float16* x_final = e->x;
+    bool x_raw = fold;  // x holds raw rows + slot statistics
+    if (tiny) {  // the latency form leaves raw rows (the embedding's, or the last FFN2's): their LayerNorm, once
+        if (layers_done == 0 && hidden_out) {
+            x_raw = true;  // (the embedding kernel wrote slot statistics: exported as the folded form is)
+        } else {
+            launch_ln(e->x, T, H, pg, pb, eps, e->tmp, s);
+            VQA_HIP_CHECK(hipGetLastError());
+            x_final = e->tmp;
+            x_raw = false;
+        }
+    }
     if (hidden_out) {
         if (packed) VQA_HIP_CHECK(hipMemsetAsync(hidden_out, 0, (size_t)B * L * H * sizeof(float), s));  // padding positions: not computed
-        hipLaunchKernelGGL(export_hidden_kernel, dim3(row_blocks), dim3(256), 0, s, e->x, T, L, H, cu, e->row_seq, B,
-                           fold ? e->st_x : (const float2*)nullptr, st_stride, p_x, pg, pb, eps, hidden_out);
+        hipLaunchKernelGGL(export_hidden_kernel, dim3(row_blocks), dim3(256), 0, s, x_final, T, L, H, cu, e->row_seq, B,
+                           x_raw ? e->st_x : (const float2*)nullptr, st_stride, p_x, pg, pb, eps, hidden_out);
         VQA_HIP_CHECK(hipGetLastError());
         return VQA_OK;
     }
-    hipLaunchKernelGGL(pool_normalize_kernel, dim3((B + 3) / 4), dim3(256), 0, s, e->x, attn_mask, B, L, H, pooling, normalize, cu, out,
-                       fold ? e->st_x : (const float2*)nullptr, st_stride, p_x, pg, pb, eps);
+    hipLaunchKernelGGL(pool_normalize_kernel, dim3((B + 3) / 4), dim3(256), 0, s, x_final, attn_mask, B, L, H, pooling, normalize, cu, out,
+                       x_raw ? e->st_x : (const float2*)nullptr, st_stride, p_x, pg, pb, eps);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }
