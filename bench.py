@@ -482,6 +482,18 @@ def main():
         if args.dtype == "fp8":  # configs[4]: recall of the fp8 index against the un-quantised fp32 rows
             _, ref32_p = cpu_oracle_topk(np, shard, q16[:nv], k, "ref32", rows=vrows)
             result["recall_at_10_vs_fp32"] = R.recall_at_k(p_gpu[:nv].cpu().numpy(), ref32_p)
+            # ... and the TIMED index itself (all n rows, all b queries): oracle scores of the e4m3 codes of seeded 512-row blocks
+            rng = np.random.default_rng(41)
+            starts = np.sort(rng.choice(max(1, n - 512), size=min(120, max(1, n // 512)), replace=False))
+            pos = np.concatenate([np.arange(s0, min(n, s0 + 512), dtype=np.int64) for s0 in starts])
+            rows = shard[torch.from_numpy(pos).to(device)].float().cpu().numpy()
+            codes = R.e4m3_encode_fast(rows * FP8_SCALE)
+            q8 = R.e4m3_decode(R.e4m3_encode_fast(q16.astype(np.float32) * FP8_SCALE)) / FP8_SCALE ** 2
+            s_all, _, p_all = index.search(q, k, return_positions=True)
+            torch.cuda.synchronize(device)
+            result["recall_check"]["timed_index_sampled_blocks"] = sampled_exactness(np, s_all, p_all, pos, R.full_scores(q8, codes, R.DTYPE_FP8_E4M3), 2e-3, 1e-4)
+            result["recall_check"]["note"] = (f"full oracle over a {vrows}-row prefix index (the fp8 oracle encodes every row on the CPU); the timed {n}-row index "
+                                              "is held to the oracle on sampled blocks: no sampled row beats a returned k-th score, returned rows in the sample carry the oracle's score")
         if world == 1:
             result["cpu_baseline"] = cpu_baseline(np, torch, shard, q16, k, args.dtype, n, args.cpu_sample_rows)
 
@@ -551,6 +563,29 @@ def step_bytes(info, stats, n, d, esize, b, step_ms):
                                   "largest_region": int(stats["largest_region"]), "region_capacity": int(stats["region_capacity"]),
                                   "longest_sublist": int(stats["longest_sublist"]), "sublist_capacity": int(stats["sublist_capacity"])}
     return out
+
+
+def sampled_exactness(np, s_gpu, p_gpu, pos, ref, score_tol, margin):
+    """The full-size check of tests/test_gpu_fullsize.py on the index that was TIMED: `ref` [B, sample] = oracle scores of the
+    sampled rows `pos`.  (1) no sampled row beats a query's returned k-th score by more than `margin` without being in its
+    result; (2) every returned row that falls in the sample carries the oracle's score within `score_tol`."""
+    s_h, p_h = s_gpu.cpu().numpy(), p_gpu.cpu().numpy()
+    kth = s_h[:, -1][:, None].astype(np.float64)
+    beat = ref > kth + margin
+    missed = 0
+    for bq in range(ref.shape[0]):
+        if beat[bq].any():
+            missed += len(set(pos[beat[bq]].tolist()) - set(p_h[bq].tolist()))
+    where = {int(r): j for j, r in enumerate(pos.tolist())}
+    hits, err = 0, 0.0
+    for bq in range(ref.shape[0]):
+        for j in range(p_h.shape[1]):
+            col = where.get(int(p_h[bq, j]))
+            if col is not None:
+                hits += 1
+                err = max(err, abs(float(s_h[bq, j]) - float(ref[bq, col])))
+    return {"sampled_rows": int(pos.size), "queries": int(ref.shape[0]), "sampled_rows_beating_kth_but_not_returned": int(missed),
+            "returned_rows_in_sample": hits, "max_abs_score_err_on_those": err, "ok": bool(missed == 0 and err <= score_tol)}
 
 
 def timed_search(torch, index, q, k, steps, warmup=5):
@@ -624,28 +659,6 @@ def other_configs(torch, np, device, dev_index, n, d, b, k):
                 o = torch.topk(ms, k, dim=1).indices
                 self.best_s, self.best_p = torch.gather(ms, 1, o), torch.gather(mp, 1, o)
 
-    def sampled_exactness(index, s_gpu, p_gpu, pos, ref, score_tol, margin):
-        """The full-size check of tests/test_gpu_fullsize.py on the index that was TIMED: `ref` [B, sample] = oracle scores of the
-        sampled rows `pos`.  (1) no sampled row beats a query's returned k-th score by more than `margin` without being in its
-        result; (2) every returned row that falls in the sample carries the oracle's score within `score_tol`."""
-        s_h, p_h = s_gpu.cpu().numpy(), p_gpu.cpu().numpy()
-        kth = s_h[:, -1][:, None].astype(np.float64)
-        beat = ref > kth + margin
-        missed = 0
-        for bq in range(ref.shape[0]):
-            if beat[bq].any():
-                missed += len(set(pos[beat[bq]].tolist()) - set(p_h[bq].tolist()))
-        where = {int(r): j for j, r in enumerate(pos.tolist())}
-        hits, err = 0, 0.0
-        for bq in range(ref.shape[0]):
-            for j in range(p_h.shape[1]):
-                col = where.get(int(p_h[bq, j]))
-                if col is not None:
-                    hits += 1
-                    err = max(err, abs(float(s_h[bq, j]) - float(ref[bq, col])))
-        return {"sampled_rows": int(pos.size), "queries": int(ref.shape[0]), "sampled_rows_beating_kth_but_not_returned": int(missed),
-                "returned_rows_in_sample": hits, "max_abs_score_err_on_those": err, "ok": bool(missed == 0 and err <= score_tol)}
-
     # ---- configs[4] storage type: fp8 e4m3 (rows and queries stored as e4m3(16 x), block-scaled MFMA at twice the fp16 rate)
     t0 = time.perf_counter()
     nv = min(16, b)
@@ -664,7 +677,7 @@ def other_configs(torch, np, device, dev_index, n, d, b, k):
     stored = np.concatenate([ix8.get_rows(int(blk[0]), int(blk.size))[0] for blk in tap.pos])
     qh = q32.cpu().numpy()
     q8 = R.e4m3_decode(R.e4m3_encode_fast(qh * FP8_SCALE)) / FP8_SCALE ** 2
-    chk = sampled_exactness(ix8, s8, p8, pos, R.full_scores(q8, codes, R.DTYPE_FP8_E4M3), 2e-3, 1e-4)
+    chk = sampled_exactness(np, s8, p8, pos, R.full_scores(q8, codes, R.DTYPE_FP8_E4M3), 2e-3, 1e-4)
     chk["stored_codes_equal_oracle_codes"] = bool(np.array_equal(stored, codes))
     p8h, s8h = p8.cpu().numpy(), s8.cpu().numpy()
     ret_err = 0.0
