@@ -240,6 +240,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip cpu_baseline and the recall check (profiling runs)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (encoder + search) leg")
     ap.add_argument("--e2e-steps", type=int, default=30)
+    ap.add_argument("--no-sketch", action="store_true", help="no int8 sketch: the exact scan of the index type (profiling runs)")
     ap.add_argument("--no-other", action="store_true", help="skip the other_configs legs (fp8, fp32 + encoder, configs[0] API latency)")
     args = ap.parse_args()
 
@@ -282,7 +283,7 @@ def main():
 
     n, d, b, k = args.docs_per_gpu, args.dim, args.batch, args.k
     shard = build_shard(torch, n, d, 1234 + rank, device, args.dtype)
-    index = DeviceIndex(shard, id_base=1 + rank * n, dtype=args.dtype, device=dev_index)
+    index = DeviceIndex(shard, id_base=1 + rank * n, dtype=args.dtype, device=dev_index, sketch=False if args.no_sketch else None)
     gq = torch.Generator(device=device)
     gq.manual_seed(99)
     q = torch.randn((b, d), generator=gq, device=device, dtype=torch.float32)

@@ -1,4 +1,4 @@
-"""Dev helper: A/B of index-level switches that are read at index create (VQA_F16_LOOP, VQA_STAGE_MIN, ...), interleaved rounds in
+"""Dev helper: A/B of index options (named as rounds 1-4 named their environment switches: VQA_F16_LOOP, VQA_STAGE_MIN, ... -> scripts/_options.py), interleaved rounds in
 ONE process on one device (guide rule 24): `python scripts/ab_loops.py VQA_F16_LOOP=0 VQA_F16_LOOP=1 [--n rows] [--rounds R]`.
 Every variant is its own index over the same synthetic shard; per variant: median / min step and main-launch time."""
 import argparse, os, sys
@@ -6,6 +6,7 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vietnamese_qa_system_amd.index import DeviceIndex
+from _options import options as _options
 
 ap = argparse.ArgumentParser()
 ap.add_argument("variants", nargs="+", help="comma-separated NAME=VALUE settings per variant, e.g. VQA_F16_LOOP=1,VQA_STAGE_MIN=0")
@@ -30,11 +31,7 @@ q = (q / q.norm(dim=1, keepdim=True)).to(buf.dtype)
 idx = []
 for v in args.variants:
     kv = dict(s.split("=", 1) for s in v.split(",") if s)
-    old = {k: os.environ.get(k) for k in kv}
-    os.environ.update(kv)
-    idx.append(DeviceIndex(buf, dtype=args.dtype))
-    for k, o in old.items():
-        os.environ.pop(k, None) if o is None else os.environ.__setitem__(k, o)
+    idx.append(DeviceIndex(buf, dtype=args.dtype, options=_options(kv)))
 ref = None
 for v, ix in zip(args.variants, idx):
     s, i, _ = ix.search(q, args.k)

@@ -3,7 +3,7 @@
 # sweeps ranks misc -- default all).  Needs the variant libraries built beforehand on the build host (they travel with the tree):
 #   python -c "from vietnamese_qa_system_amd import build as b; b.build_variant('dev', ['VQA_DEV']); b.build_variant('dev_st', ['VQA_DEV', 'VQA_GSTAMPS']); b.build_variant('stamps', ['VQA_STAMPS=1'])"
 # Everything lands under gpurun_out/; copy what is to be judged into profiles/ afterwards (scripts/collect_profiles.py).
-R=${1:-r04}; shift
+R=${1:-r05}; shift
 PARTS=${@:-search enc gemm sweeps ranks misc}
 cd $GRAFT_REPO_ROOT
 has() { [[ " $PARTS " == *" $1 "* ]]; }
@@ -12,7 +12,7 @@ LIB=$GRAFT_REPO_ROOT/vietnamese_qa_system_amd/lib
 if has search; then
   # fp16 headline (sketch search), the same shard through the exact fp16 scan, fp8: bench line + rocprofv3 kernel stats + PMC passes each
   bash scripts/profile_round.sh ${R}_fp16 > gpurun_out/${R}_fp16.log 2>&1; tail -3 gpurun_out/${R}_fp16.log
-  VQA_SKETCH=0 bash scripts/profile_round.sh ${R}_fp16_exact --no-cpu --no-other > gpurun_out/${R}_fp16_exact.log 2>&1; tail -3 gpurun_out/${R}_fp16_exact.log
+  bash scripts/profile_round.sh ${R}_fp16_exact --no-sketch --no-cpu --no-other > gpurun_out/${R}_fp16_exact.log 2>&1; tail -3 gpurun_out/${R}_fp16_exact.log
   bash scripts/profile_round.sh ${R}_fp8 --dtype fp8 --no-cpu --no-other > gpurun_out/${R}_fp8.log 2>&1; tail -2 gpurun_out/${R}_fp8.log
   # kernel timeline of one sketch-search step, and the s_memtime-stamped timeline of the int8 slot loop (main scan, workgroup 5, tile 40)
   bash scripts/trace_steps_env.sh VQA_NOP 0 2>&1 | grep -v amdgpu > gpurun_out/${R}_step_timeline.txt
@@ -59,6 +59,6 @@ if has ranks; then
 fi
 
 if has misc; then
-  python scripts/ab_loops.py VQA_SKETCH_SX=5 VQA_SKETCH_SX=6 VQA_SKETCH=0 2>&1 | grep -v amdgpu > gpurun_out/${R}_scan_ab.txt; cat gpurun_out/${R}_scan_ab.txt
+  VQA_LIB=$LIB/libvqa_retrieval_dev.so python scripts/ab_loops.py VQA_SKETCH_SX=5 VQA_SKETCH_SX=6 VQA_SKETCH=0 2>&1 | grep -v amdgpu > gpurun_out/${R}_scan_ab.txt; cat gpurun_out/${R}_scan_ab.txt
   timeout 1500 python scripts/stress_races.py > gpurun_out/${R}_race_screen.txt 2>&1; tail -3 gpurun_out/${R}_race_screen.txt
 fi

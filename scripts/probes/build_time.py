@@ -8,11 +8,9 @@ x = torch.empty((n, d), dtype=torch.float16, device=dev)
 for c0 in range(0, n, 1 << 19):
     r = torch.randn((min(n, c0 + (1 << 19)) - c0, d), generator=g, device=dev)
     x[c0:c0 + r.shape[0]] = (r / r.norm(dim=1, keepdim=True)).half()
-for env in ({"VQA_SKETCH": "0"}, {"VQA_SKETCH_ROTATE": "0"}, {}):
-    for k in ("VQA_SKETCH", "VQA_SKETCH_ROTATE"): os.environ.pop(k, None)
-    os.environ.update(env)
+for env in ({"sketch": 0}, {"sketch_rotate": 0}, {}):
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    ix = DeviceIndex(x, dtype="fp16")
+    ix = DeviceIndex(x, dtype="fp16", options=env)
     torch.cuda.synchronize(); t = time.perf_counter() - t0
     print(env or "default (sketch, rotated, centred, copy)", f"build {t:.2f} s, device bytes {ix.device_bytes() / 1e9:.1f} GB", flush=True)
     ix.close()

@@ -66,12 +66,12 @@ for kind in ("isotropic", "two outlier dimensions (20x)", "two constant outlier 
              "1000 clusters, within-cluster sigma 0.3", "50 tight clusters, sigma 0.05", "low rank 32 + 10 % noise"):
     x = torch.cat([make(kind, 1 << 19) for _ in range(0, n, 1 << 19)])[:n]
     q = make(kind, b)
-    os.environ.pop("VQA_SKETCH_PER_ROW", None); os.environ.pop("VQA_SKETCH_SPLIT", None)
+    opts = {}
     if "form off" in kind or "split off" in kind:
-        os.environ["VQA_SKETCH_PER_ROW"] = "0"
+        opts["sketch_per_row"] = 0
     if "split off" in kind:
-        os.environ["VQA_SKETCH_SPLIT"] = "0"
-    ske = DeviceIndex(x, dtype="fp16", sketch=True)
+        opts["sketch_split"] = 0
+    ske = DeviceIndex(x, dtype="fp16", sketch=True, options=opts)
     s1, i1, _ = ske.search(q, k); torch.cuda.synchronize()
     st = ske.sketch_stats(); out = (st['last_scan_pairs'], st['largest_region'], st['longest_sublist'], st['overflow'])
     state = ske.sketch_state()

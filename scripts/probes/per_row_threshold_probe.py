@@ -22,9 +22,7 @@ for w in (1.0, 1.5, 2.0, 2.5, 3.0, 4.0):
     q = draw(b, w)
     out = []
     for form in ("0", "1"):
-        os.environ["VQA_SKETCH_PER_ROW"] = form
-        os.environ["VQA_SKETCH_PROFIT"] = "0"
-        ix = DeviceIndex(x, dtype="fp16", sketch=True)
+        ix = DeviceIndex(x, dtype="fp16", sketch=True, options={"sketch_per_row": int(form), "sketch_profit": 0.0})
         ix.search(q, k); torch.cuda.synchronize()
         st = ix.sketch_stats()
         out.append(f"{'per-row' if ix.sketch_split(0)[3] else 'split'}: pairs {st['rescored_pairs']:8d} overflow {st['overflow']} step {timed(ix, q):.3f} ms")

@@ -10,8 +10,7 @@ def timed(ix, q, k, n=20):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 for n, d in ((1_200_000, 768), (1_200_000, 1024), (3_000_000, 768), (3_000_000, 1024), (1_200_000, 384)):
     x = torch.randn((n, d), generator=g, device=dev); x = (x / x.norm(dim=1, keepdim=True)).half()
-    os.environ["VQA_SKETCH_PROFIT"] = "0"
-    ske = DeviceIndex(x, dtype="fp16", sketch=True)
+    ske = DeviceIndex(x, dtype="fp16", sketch=True, options={"sketch_profit": 0.0})
     ref = DeviceIndex(x, dtype="fp16", sketch=False)
     for b in (256, 1):
         q = torch.randn((b, d), generator=g, device=dev); q = (q / q.norm(dim=1, keepdim=True)).half()

@@ -3,8 +3,9 @@
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-os.environ["VQA_STAGE_MIN"] = "2"
+from vietnamese_qa_system_amd import index as _index_mod
 from vietnamese_qa_system_amd.index import DeviceIndex
+_index_mod.DEFAULT_OPTIONS["stage_min_tiles"] = 2
 from vietnamese_qa_system_amd.sharded import shard_bounds
 world, k = 8, 10
 rng = np.random.default_rng(5)
