@@ -282,8 +282,20 @@ def main():
     from vietnamese_qa_system_amd.sharded import sharded_index_searcher
 
     n, d, b, k = args.docs_per_gpu, args.dim, args.batch, args.k
-    shard = build_shard(torch, n, d, 1234 + rank, device, args.dtype)
-    index = DeviceIndex(shard, id_base=1 + rank * n, dtype=args.dtype, device=dev_index, sketch=False if args.no_sketch else None)
+    # (ranks that share a device -- VQA_BENCH_SHARE_GPU=1: the N-rank program on a 1-GPU box -- build their shards one after the other
+    # and without the row-major re-scoring copy, so that eight full-size shards, configs[3] / configs[4], fit one MI355X)
+    shard = index = None
+    for turn in range(world if share and world > 1 else 1):
+        if not (share and world > 1) or turn == rank:
+            shard = build_shard(torch, n, d, 1234 + rank, device, args.dtype)
+            index = DeviceIndex(shard, id_base=1 + rank * n, dtype=args.dtype, device=dev_index, sketch=False if args.no_sketch else None,
+                                rescore_copy=False if share and world > 1 else None)
+            if rank != 0:  # only rank 0 checks its shard against the oracle afterwards
+                shard = shard[:1].clone()
+                torch.cuda.empty_cache()
+        if share and world > 1:
+            torch.cuda.synchronize(device)
+            dist.barrier()
     gq = torch.Generator(device=device)
     gq.manual_seed(99)
     q = torch.randn((b, d), generator=gq, device=device, dtype=torch.float32)

@@ -4,7 +4,7 @@
 #   python -c "from vietnamese_qa_system_amd import build as b; b.build_variant('dev', ['VQA_DEV']); b.build_variant('dev_st', ['VQA_DEV', 'VQA_GSTAMPS']); b.build_variant('stamps', ['VQA_STAMPS=1'])"
 # Everything lands under gpurun_out/; copy what is to be judged into profiles/ afterwards (scripts/collect_profiles.py).
 R=${1:-r05}; shift
-PARTS=${@:-search enc gemm sweeps ranks misc}
+PARTS=${@:-search enc gemm sweeps ranks fullranks misc}
 cd $GRAFT_REPO_ROOT
 has() { [[ " $PARTS " == *" $1 "* ]]; }
 LIB=$GRAFT_REPO_ROOT/vietnamese_qa_system_amd/lib
@@ -56,6 +56,18 @@ if has ranks; then
       bench.py --gpus $N --docs-per-gpu $((10000000 / N)) --steps 48 --warmup 10 --e2e-steps 10 2> gpurun_out/${R}_${N}_ranks.err | grep '^{' > gpurun_out/${R}_${N}_ranks_one_gpu.json
     cut -c1-300 gpurun_out/${R}_${N}_ranks_one_gpu.json
   done
+fi
+
+if has fullranks; then
+  # BASELINE configs[3] at FULL size as the real 8-rank program on ONE device: 8 shards of 10M x 768 fp16 (80M rows resident: rows + int8
+  # sketch per shard, the row-major copy where the device still has room), ranks time-slice cuda:0 over gloo -- the workload's
+  # correctness and plumbing at its real size, not a scaling point; and configs[4]: 8 shards of 12.5M x 768 fp8 (100M rows)
+  VQA_BENCH_SHARE_GPU=1 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 1500 python bench.py --gpus 8 --steps 24 --warmup 6 --no-e2e \
+      2> gpurun_out/${R}_configs3_full.err | grep '^{' > gpurun_out/${R}_configs3_80M_eight_ranks_one_gpu.json
+  cut -c1-400 gpurun_out/${R}_configs3_80M_eight_ranks_one_gpu.json; tail -2 gpurun_out/${R}_configs3_full.err
+  VQA_BENCH_SHARE_GPU=1 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 1500 python bench.py --gpus 8 --steps 24 --warmup 6 --no-e2e --dtype fp8 --docs-per-gpu 12500000 --verify-queries 4 \
+      2> gpurun_out/${R}_configs4_full.err | grep '^{' > gpurun_out/${R}_configs4_100M_fp8_eight_ranks_one_gpu.json
+  cut -c1-400 gpurun_out/${R}_configs4_100M_fp8_eight_ranks_one_gpu.json; tail -2 gpurun_out/${R}_configs4_full.err
 fi
 
 if has misc; then
