@@ -99,3 +99,18 @@ def test_embeddings_document_normalisation_and_validation():
     assert emb.hybrid and emb.content and emb.weights == 0.5
     with pytest.raises(FileNotFoundError):
         Embeddings().load("/nonexistent/index/dir")
+
+
+def test_bench_bare_multi_gpu_launch_never_raises_systemexit_for_a_missing_launcher():
+    """`python bench.py --gpus N` WITHOUT torch.distributed.run (the driver's 1-GPU command shape with N > 1): bench.py is
+    its own launcher.  On a box with fewer devices than ranks (this CPU container shows none) and no device sharing asked for, it
+    says so and exits 2 before any rank starts -- no traceback, nothing on stdout."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "VQA_BENCH_SHARE_GPU")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    import torch
+    if torch.cuda.device_count() < 8:
+        assert out.returncode == 2 and "GPU(s)" in out.stderr and "Traceback" not in out.stderr and out.stdout.strip() == ""

@@ -126,3 +126,50 @@ def test_embeddings_loads_the_model_named_by_path(native_lib, golden_dir):
     encb.close()
     with pytest.raises(RuntimeError, match="hub names"):
         Embeddings(path="sentence-transformers/paraphrase-multilingual-MiniLM-L12-v2").index([{"id": 1, "text": "q"}])
+
+
+def _write_safetensors(path, tensors):
+    """A minimal safetensors WRITER for the tests (8-byte header length, JSON header, raw little-endian tensors)."""
+    names = {np.dtype(np.float32): "F32", np.dtype(np.float16): "F16", np.dtype(np.int64): "I64"}
+    header, blobs, off = {"__metadata__": {"format": "pt"}}, [], 0
+    for name, a in tensors.items():
+        raw = np.ascontiguousarray(a).tobytes()
+        header[name] = {"dtype": names[a.dtype], "shape": list(a.shape), "data_offsets": [off, off + len(raw)]}
+        blobs.append(raw)
+        off += len(raw)
+    hj = json.dumps(header).encode()
+    hj += b" " * (-len(hj) % 8)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<Q", len(hj)) + hj + b"".join(blobs))
+
+
+@pytest.mark.gpu
+def test_minilm_shaped_directory_in_the_old_sentence_transformers_layout(native_lib, tmp_path):
+    """The shape of paraphrase-multilingual-MiniLM-L12-v2 (heavy_ranker.py:80: BERT, hidden 384, 12 heads of 32, absolute positions;
+    two layers here) as a directory in sentence-transformers' OLDER layout -- the transformer files under `0_Transformer/`, weights
+    stored as fp16 safetensors with the `bert.` prefix, `1_Pooling` asking for the CLS token -- written by the test's own
+    safetensors writer: from_pretrained reads it, and the HIP forward matches the oracle on the same (fp16-rounded) weights."""
+    from oracle import encoder as E
+    from vietnamese_qa_system_amd.encoder import QuestionEncoder
+    cfg = dict(E.MINILM_L12, layers=2, vocab_size=3000)
+    w = {k: v.astype(np.float16) for k, v in E.synthetic_weights(cfg, seed=33, layers=2).items()}
+    root = tmp_path / "minilm"
+    (root / "0_Transformer").mkdir(parents=True)
+    (root / "1_Pooling").mkdir()
+    _write_safetensors(str(root / "0_Transformer" / "model.safetensors"),
+                       {**{"bert." + k: v for k, v in w.items()}, "bert.embeddings.position_ids": np.arange(512, dtype=np.int64)[None]})
+    (root / "0_Transformer" / "config.json").write_text(json.dumps(
+        {"model_type": "bert", "vocab_size": 3000, "hidden_size": 384, "num_hidden_layers": 2, "num_attention_heads": 12,
+         "intermediate_size": 1536, "max_position_embeddings": 512, "type_vocab_size": 2, "pad_token_id": 0, "layer_norm_eps": 1e-12,
+         "hidden_act": "gelu"}))
+    (root / "modules.json").write_text(json.dumps(
+        [{"idx": 0, "name": "0", "path": "0_Transformer", "type": "sentence_transformers.models.Transformer"},
+         {"idx": 1, "name": "1", "path": "1_Pooling", "type": "sentence_transformers.models.Pooling"}]))
+    (root / "1_Pooling" / "config.json").write_text(json.dumps({"pooling_mode_cls_token": True, "pooling_mode_mean_tokens": False}))
+    enc = QuestionEncoder.from_pretrained(str(root), max_tokens=40 * 32)
+    assert enc.pooling == "cls" and enc.normalize is False and enc.config == cfg
+    ids, mask = E.synthetic_tokens(cfg, 40, 32, seed=2)
+    got = enc.forward(ids, mask, pooling=enc.pooling).cpu().numpy()
+    ref = E.encode({k: v.astype(np.float32) for k, v in w.items()}, cfg, ids[:6], mask[:6], pooling="cls")
+    assert np.abs(got[:6] - ref).max() < 8.5e-4  # tests/test_gpu_encoder.py BOUNDS["minilm", 2]
+    enc.close()

@@ -1194,13 +1194,14 @@ __global__ __launch_bounds__(512) void gemm_tiny_kernel(const _Float16* __restri
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
+    const int m0 = blockIdx.y * (16 * MT);  // gridDim.y > 1: the token tiles are spread over workgroups (FFN2: 48 feature slices alone leave 208 CUs idle)
     const int kq = K >> 3;  // this wave's K range [wave kq, +kq): a multiple of 32 NBC
     const int kbase = wave * kq;
     const _Float16* wp = W + (size_t)(n0 + c) * K + kbase + 8 * g;
     const _Float16* ap[MT];
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
-        const int row = mi * 16 + c < M ? mi * 16 + c : M - 1;  // rows past M: a copy of the last row, dropped
+        const int row = m0 + mi * 16 + c < M ? m0 + mi * 16 + c : M - 1;  // rows past M: a copy of the last row, dropped
         ap[mi] = A + (size_t)row * K + kbase + 8 * g;
     }
     f32x4 acc[MT];
@@ -1231,7 +1232,7 @@ __global__ __launch_bounds__(512) void gemm_tiny_kernel(const _Float16* __restri
         if (EPI == 2) {
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) {
-                const int m = mi * 16 + c < M ? mi * 16 + c : M - 1;
+                const int m = m0 + mi * 16 + c < M ? m0 + mi * 16 + c : M - 1;
                 res[mi] = *reinterpret_cast<const half4*>(R + (size_t)m * N + n0 + 4 * g);
                 if (ta.g) st[mi] = ta.st_in[m];
             }
@@ -1289,7 +1290,7 @@ __global__ __launch_bounds__(512) void gemm_tiny_kernel(const _Float16* __restri
     // total[mi][j] = C[token 16 mi + c][feature n0 + 4 g + j]
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
-        const int m = mi * 16 + c;
+        const int m = m0 + mi * 16 + c;
         const f32x4 sum = total[mi];
         float rstd = 1.f, mrs = 0.f;
         if constexpr (FOLDIN) {
@@ -1958,11 +1959,14 @@ static bool tiny_shape(int M, int N, int K) { return M >= 1 && M <= kTinyMaxM &&
 template <int EPI, int FOLDIN>
 int launch_gemm_tiny(const _Float16* A, const _Float16* W, const float* bias, const _Float16* R, _Float16* C, int M, int N, int K,
                      const TinyArgs& ta, hipStream_t s) {
-    const int mt = (M + 15) / 16, nbw = K / 256;
+    // a GEMM of few feature slices and a long K (FFN2: 48 slices x K = 3072) spreads its token tiles over workgroups: every workgroup then
+    // pulls one tile's rows of A (98 KB instead of 196) beside its 98 KB of weights (the weights are re-read from the L2)
+    const int my = (!FOLDIN && N / 16 < 96 && K >= 3072) ? (M + 15) / 16 : 1;
+    const int mt = my > 1 ? 1 : (M + 15) / 16, nbw = K / 256;
     // all of a wave's loads at once when they fit its registers (NBC (1 + MT) fragments of 4 registers), else in two or more chunks
     const int nbc = (nbw % 12 == 0 && mt <= 2) ? 12 : (nbw % 6 == 0 && mt <= 4) ? 6 : 3;
 #define VQA_TINY(MT, NBC)                                                                                                       \
-    hipLaunchKernelGGL((gemm_tiny_kernel<EPI, MT, FOLDIN, NBC>), dim3(N / 16), dim3(512), 0, s, A, W, bias, R, C, M, N, K, ta)
+    hipLaunchKernelGGL((gemm_tiny_kernel<EPI, MT, FOLDIN, NBC>), dim3(N / 16, my), dim3(512), 0, s, A, W, bias, R, C, M, N, K, ta)
 #define VQA_TINY_MT(NBC)                                   \
     switch (mt) {                                          \
         case 1: VQA_TINY(1, NBC); break;                   \
