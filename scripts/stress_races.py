@@ -44,7 +44,7 @@ for dtype, n, d, b, k, reps in (("fp16", 10_000_000, 768, 256, 10, 150), ("fp16"
 cfg = dict(E.PHOBERT_BASE, vocab_size=8000)
 w = E.synthetic_weights(cfg, seed=3)
 enc = QuestionEncoder(w, cfg, max_tokens=256 * 128)
-for b, l, reps in ((256, 32, 150), (256, 128, 40), (96, 48, 100), (40, 32, 100), (1000, 16, 80)):
+for b, l, reps in ((256, 32, 150), (256, 128, 40), (96, 48, 100), (40, 32, 100), (1000, 16, 80), (1, 32, 300), (2, 32, 300), (3, 16, 300)):  # the last three: the latency form
     ids, mask = E.synthetic_tokens(cfg, b, l, seed=b + l)
     ids_t, mask_t = torch.from_numpy(ids).cuda(), torch.from_numpy(mask).cuda()
     for real in (0, int(mask.sum())):
