@@ -2282,6 +2282,8 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
             const int nqb = (L + 31) / 32;
             // heads per workgroup: as many as keep the workgroup at <= 512 threads and divide the head count
             int hpw = nqb <= 2 ? 4 : nqb <= 4 ? 2 : 1;
+            static const int hpw_force = vqa_dev_env("VQA_ATT_HPW") ? atoi(vqa_dev_env("VQA_ATT_HPW")) : 0;  // dev override (A/B)
+            if (hpw_force > 0 && hpw_force <= hpw) hpw = hpw_force;
             while (heads % hpw) hpw >>= 1;
             const size_t lds = (size_t)hpw * nqb * 32 * 2 * dh;  // per head: [32 nqb keys][2 dh bytes]
 #define VQA_ATT(NQB, HPW)                                                                                                   \
