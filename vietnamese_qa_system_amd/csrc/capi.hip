@@ -31,6 +31,7 @@ static int elem_bytes(int dtype) { return dtype == VQA_F32 ? 4 : dtype == VQA_F1
 // fitted it (all on MI355X, i.i.d. unit rows unless said otherwise).  vqa_index_options_init copies them into the caller-visible
 // options; plan_launch / sketch_active / profit_pairs below apply them.  tests/test_gpu_plan.py pins what they give for the five
 // BASELINE per-GPU shard shapes.
+constexpr int kSketchMaxK = 128;  // the sketch search serves k <= 128 (txtai's hybrid search asks the dense index for 10 x limit rows)
 struct PlanRules {
     int seed_mult = 2;             // seed pass = 2 x CUs tiles: 512 tiles halve the main pass's appends against 256 (round 1, net gain) ...
     int seed_div = 16;             // ... capped at 1/16 of the shard (1M x 768 fp32: 13 % of the search in the seed pass without it, 3.37 -> 3.19 ms)
@@ -43,7 +44,7 @@ struct PlanRules {
     int mid_min_tiles = 128;       // ... or from 128 tiles per workgroup on at any k (10M x 768, k = 10, interleaved A/B: 1.936 -> 1.888 ms; 3M rows: +4 %)
     int mid_pct = 200;             // ... of twice the first stage's tiles (profiles/r04_cascade_levels_ab.txt)
     int pre_k = 48;                // a fourth level (the first stage's leading quarter) from k = 48 on (r04_cascade_levels_ab.txt: k = 100: 3.9 -> 3.2 ms)
-    int sketch_max_k = 128;        // the sketch search serves k <= 128 (txtai's hybrid search asks for 10 x limit; r04_k_and_batch.txt)
+    int sketch_max_k = kSketchMaxK;  // (candidates grow linearly with k: 2.0 -> 2.8 ms from k = 10 to 128 at 10M rows, r05_k_and_batch.txt; beyond: the exact forms)
     double profit_f16 = 0.75;      // pause when a query tile scores more than 0.75 n - 4e5 pairs exactly (profiles/r04_profit_probe.txt: 5 shapes x 6 k)
     double profit_f32 = 4.0;       // fp32 shards: 4 n (their exact scan is 16x slower)
     double profit_offset_f16 = 4e5;
@@ -67,13 +68,13 @@ struct vqa_index {
     int num_cu = 0;
     int max_grid = 0;
     bool two_pass = true;
-    int seed_mult = 2;  // seed pass covers seed_mult * CUs tiles (VQA_SEED_MULT = 1..4)
-    int seed_div = 16;  // ... but at most 1 / seed_div of the shard's tiles (VQA_SEED_DIV: dev override, 0 = no cap)
+    int seed_mult = 2;  // seed pass covers seed_mult * CUs tiles (vqa_index_options.seed_mult = 1..4)
+    int seed_div = 16;  // ... but at most 1 / seed_div of the shard's tiles (options.seed_div, 0 = no cap)
     int stage_min_tiles = 24;  // two-stage search when the shard has at least this many tiles per workgroup (1.6M rows: measured
-                               // crossover between 1M rows, +1 % step time, and 2M rows, -2 %; VQA_STAGE_MIN: dev /
-                               // test override, 0 disables); the first stage takes stage_pct % of the tiles (VQA_STAGE_PCT)
+                               // crossover between 1M rows, +1 % step time, and 2M rows, -2 %; options.stage_min_tiles: dev /
+                               // test override, 0 disables); the first stage takes stage_pct % of the tiles (options.stage_pct)
     int stage_pct = 10;
-    int f16_loop = 0;  // fp16 K loop: 0 = anti-phase slots (two barriers per K-step), 1 = K-step pairs on the stagger loop (VQA_F16_LOOP)
+    int f16_loop = 0;  // fp16 K loop: 0 = anti-phase slots (two barriers per K-step), 1 = K-step pairs on the stagger loop (options.f16_loop)
     // workspace (allocated once; search never allocates)
     void* q_stage = nullptr;     // one 256-row tile in TILED layout
     void* q_rm = nullptr;        // ... and row-major (sketch shards with the re-scoring copy: what rescore_kernel reads)
@@ -91,7 +92,7 @@ struct vqa_index {
     float* thr_seed = nullptr;   // [256] the cascade's theta0 (k-th largest exact seed, MFMA arithmetic): kept for its exact fallback
     vqa_key* upper = nullptr;    // [256] last key returned per query (continuation passes of a search with k > 12)
     int* wide_flag = nullptr;    // 1 = the one-pass large-k result could not be verified: the gated continuation passes run
-    bool wide = true;            // VQA_WIDE_K=0 disables the one-pass large-k attempt
+    bool wide = true;            // options.wide_k = 0 disables the one-pass large-k attempt
     // int8 sketch of a large fp16 shard (VQA_INDEX_SKETCH): the rigorous pruning pre-pass of the main launch (score_topk.hip MODE 2)
     bool sketch = false;
     int32_t d_pad8 = 0;             // sketch row length (multiple of 128 elements)
@@ -115,31 +116,31 @@ struct vqa_index {
                                             // search replaces: the handle pauses the sketch as after an overflow.  Fitted to 5 shard shapes x 6 k
                                             // (profiles/r04_profit_probe.txt, the set measured with the radix selections): the sketch search is level
                                             // with the exact forms over a wide band and loses clearly where pairs > 0.75 n - 4e5; the f32 MFMA scan of
-                                            // fp32 shards is 16x slower: 4 n.  VQA_SKETCH_PROFIT sets the factor, 0: never
+                                            // fp32 shards is 16x slower: 4 n.  options.sketch_profit sets the factor, 0: never
     long long* stage_pos = nullptr;         // [256][max_k] row positions of the first stage's top-k
     float* mu = nullptr;                    // [d_pad8] centre of the shard (mean of the rows of its first fill), subtracted before the sketch
     float* wdir = nullptr;                  // [d_pad8] (behind mu, same allocation) w = T mu / ||T mu||: the slack term |z . x_lo| of the bound is split
-                                            // along it (convert.hip sketch_rows_kernel); VQA_SKETCH_SPLIT=0: not (dev / A-B switch)
+                                            // along it (convert.hip sketch_rows_kernel); options.sketch_split = 0: not (A-B switch)
     bool split = true;
     float* beta = nullptr;                  // [tiles * 256] per-row form: beta = w . y of every row (the scan adds alpha beta per (query, row))
     bool per_row = false;                   // decided with the centre, at the first fill: ||mu||^2 >= 0.6 x the sample's mean ||x||^2 (rows collapsed onto one
                                             // direction; unit rows: a mean cosine of 0.6 between two rows; measured: the per-row form is level with the centre split at 0.5 and ahead from 0.7 on,
-                                            // profiles/r04_per_row_threshold.txt) and rows of >= 6 K-steps; VQA_SKETCH_PER_ROW=0 / 1 forces it
+                                            // profiles/r04_per_row_threshold.txt) and rows of >= 6 K-steps; options.sketch_per_row = 0 / 1 forces it
     int per_row_env = -1;
     float* qoff = nullptr;                  // [256] q . mu of the query tile
     float mu_norm = 0.f;
     bool mu_set = false;
-    bool center = true;                     // VQA_SKETCH_CENTER=0: no centring (needs the rotated form)
-    bool rotate = true;                     // the sketch is cut from rotated rows (convert.hip: sketch_rotate); VQA_SKETCH_ROTATE=0: from the rows as they are
-    bool sketch_sx5 = true;                 // the sketch scan's X ring: five stages; VQA_SKETCH_SX=6: six (dev / A-B switch: measured equal)
-    int mid_k = 16, mid_pct = 200;          // a second cascade stage of mid_pct % of the first one's tiles for k >= mid_k (VQA_SKETCH_MID_K, 0: never; VQA_SKETCH_MID_PCT)
-    int pre_k = 48;                         // a leading quarter of the first stage as a stage of its own for k >= pre_k (VQA_SKETCH_PRE_K, 0: never)
-    int mid_min_tiles = 128;                // ... and for any k on shards of that many tiles per workgroup (VQA_SKETCH_MID_MIN, 0: by k only)
-    bool cascade = true;                    // VQA_SKETCH_CASCADE=0: the exact first stage of the narrow sketch form (dev / A-B switch)
+    bool center = true;                     // options.sketch_center = 0: no centring (needs the rotated form)
+    bool rotate = true;                     // the sketch is cut from rotated rows (convert.hip: sketch_rotate); options.sketch_rotate = 0: from the rows as they are
+    bool sketch_sx5 = true;                 // the sketch scan's X ring: five stages; options.sketch_ring_stages = 6: six (A-B switch: measured equal)
+    int mid_k = 16, mid_pct = 200;          // a second cascade stage of mid_pct % of the first one's tiles for k >= mid_k (options.sketch_mid_k, 0: never; options.sketch_mid_pct)
+    int pre_k = 48;                         // a leading quarter of the first stage as a stage of its own for k >= pre_k (options.sketch_pre_k, 0: never)
+    int mid_min_tiles = 128;                // ... and for any k on shards of that many tiles per workgroup (options.sketch_mid_min_tiles, 0: by k only)
+    bool cascade = true;                    // options.sketch_cascade = 0: the exact first stage of the narrow sketch form (A-B switch)
     int* sketch_flag_dev_mirror = nullptr;  // device address of the pinned mirror below (mapped host memory: the cascade's last merge writes it)
     int* sketch_flag_host = nullptr;        // pinned mirror of sketch_flag [3], copied once behind the last query tile of a call (read by LATER calls)
     int sketch_cooldown = 0;                // searches left that skip the sketch: data the bound cannot prune would pay the sketch scan
-                                            // AND the exact fallback every time (VQA_SKETCH_COOLDOWN searches, default 64, then it tries again;
+                                            // AND the exact fallback every time (options.sketch_cooldown searches, default 64, then it tries again;
                                             // every overflow in a row doubles the pause, up to 64 x the base: data the bound never prunes
                                             // ends up paying one wasted sketch scan per 4096 searches)
     int sketch_cooldown_len = 64;           // base length
@@ -751,7 +752,6 @@ struct LaunchPlan {
 // txtai's hybrid search asks the dense index for 10 x limit rows (30 at its default limit).  The candidates of a query grow with k
 // (theta sits at rank k: ~860 rows at k = 10, ~2300 at k = 30, ~13 000 at k = 100 of a 10M-row shard -- half of them from the first
 // stage, whose seed threshold is the weaker one) and the exact re-scoring with them; txtai's hybrid search at limit 10 asks for 100.
-#define kSketchMaxK (kPlan.sketch_max_k)
 
 static LaunchPlan plan_launch(const vqa_index* ix, int k = 0) {
     LaunchPlan p;
@@ -1126,7 +1126,7 @@ static int search_impl(vqa_index* ix, const void* q, int32_t q_dtype, int32_t B,
             sketch_call = true;
         }
         const int sk_clear = q0 == 0 ? 2 : 1;  // the call's first query tile also clears the OR over the tiles
-        const bool use_sketch = any_sketch && k <= max_k && !ix->cascade;  // the round's first form (VQA_SKETCH_CASCADE=0: A/B switch)
+        const bool use_sketch = any_sketch && k <= max_k && !ix->cascade;  // round 3.s form (options.sketch_cascade = 0: A/B switch)
         const void* q_tile = reinterpret_cast<const char*>(q) + (size_t)q0 * ix->d * qeb;
         if (any_sketch) {
             // one launch: the query tile in the storage type (tiled for the exact kernels, row-major for the re-scoring) and its int8

@@ -9,7 +9,10 @@
 //   embed_ln        word + position + type embeddings -> LayerNorm                      (one wave per token)
 //   gemm_tile<..>   C[M,N] = A[M,K] . W[N,K]^T + bias (+ erf GELU | + residual row) for > 320 tokens: persistent, LDS-DMA ring,
 //                   anti-phase slot K loop, tile shape picked per problem (256x288 / 256x192 / 256x128 / 128x192), 16-byte stores
-//   gemm_skinny     <= 512 tokens (single queries, small batches): weights streamed once, fragments straight from global memory
+//                   LayerNorms folded into the GEMMs (FoldArgs); the erf GELU of the FFN1 epilogue by interpolation in an LDS table
+//   gemm_tiny<..>   <= 64 tokens (ONE question: the reference's own call, heavy_ranker.py:97-101): every load of a wave in flight before its
+//                   first MFMA, LayerNorms folded on raw rows, five launches per layer
+//   gemm_skinny     65 .. 320 tokens (small batches): weights streamed once, fragments straight from global memory
 //   gemm_nt<EPI>    the shapes in between: v_mfma_f32_16x16x32_f16, 128x128 tiles, register-staged double-buffered LDS image
 //   attention       per (sequence, head): softmax(q k^T / sqrt(dh) + mask) v, K/V in LDS, wavefront-shuffle softmax
 //   ln              LayerNorm (the residual add is fused into the producing GEMM's epilogue) (one wave per token)

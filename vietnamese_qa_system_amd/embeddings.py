@@ -20,12 +20,10 @@ queries; vector queries are dense only.
 """
 from __future__ import annotations
 
-import ctypes
 import json
 import os
 import shutil
 import time
-import warnings
 from concurrent.futures import ThreadPoolExecutor
 from typing import Callable, Iterable, List, Optional, Sequence, Union
 

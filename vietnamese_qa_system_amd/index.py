@@ -7,7 +7,6 @@ runs in ``libvqa_retrieval.so`` (hand-written HIP, gfx950); torch only owns devi
 from __future__ import annotations
 
 import ctypes
-import os
 from typing import Optional, Tuple
 
 import numpy as np
