@@ -856,9 +856,32 @@ def latency_legs(torch, np, device, dev_index, d):
             enc.forward(ids, mask, pooling="mean", normalize=True, real_tokens=0)
         torch.cuda.synchronize(device)
         wall = (time.perf_counter() - t0) / 30
-        enc.close()
         out["encoder_one_question_32_tokens_ms"] = {"event_median": round(float(np.median([e0.elapsed_time(e1) for e0, e1 in ev])), 4),
                                                     "wall_back_to_back": round(wall * 1e3, 4)}
+        # ... and the whole text call of heavy_ranker.py:98: `search(question, 1)` = tokenizer (a stand-in: a table look-up) -> the
+        # encoder's host entry -> the index's host-result entry, wall clock with Python, 5000 documents
+        from vietnamese_qa_system_amd.encoder import TextEncoder
+        ids_h, mask_h = ids.cpu().numpy(), mask.cpu().numpy()
+        te = TextEncoder(lambda texts: (np.repeat(ids_h, len(texts), 0), np.repeat(mask_h, len(texts), 0)), enc, pooling="mean")
+        x = rng.standard_normal((5000, d)).astype(np.float32)
+        emb = Embeddings(dtype="fp16", device=dev_index, encoder=te)
+        emb.index_vectors(list(range(1, 5001)), x)
+        for _ in range(10):
+            emb.search("cau hoi", 1)
+        ts = []
+        for _ in range(100):
+            t0 = time.perf_counter()
+            hit = emb.search("cau hoi", 1)
+            ts.append(time.perf_counter() - t0)
+        qv = enc.forward(ids, mask, pooling="mean", normalize=True, real_tokens=0).cpu().numpy()
+        stored = emb._index.get_rows()[0]
+        _, ref_ids, _ = R.search(R.l2_normalize(qv).astype(np.float32), stored, 1, dtype=R.DTYPE_F16, id_base=1)
+        ts = np.sort(np.asarray(ts)) * 1e3
+        out["search_one_text_question_limit1_5000_docs_ms"] = {"median": round(float(np.median(ts)), 4), "p10": round(float(ts[10]), 4),
+                                                              "p90": round(float(ts[90]), 4),
+                                                              "top1_equals_oracle_on_the_encoded_vector": bool(hit and hit[0][0] == int(ref_ids[0, 0]))}
+        emb._index.close()
+        enc.close()
     return out
 
 

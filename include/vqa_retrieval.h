@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VQA_VERSION 110 /* 0.1.10: vqa_index_search_host; 0.1.9: vqa_index_options / vqa_index_create_ex, vqa_encoder_options / vqa_encoder_create_ex (no environment variable is read any more), vqa_launch_info.levels; 0.1.8: vqa_encoder_forward_hidden; 0.1.7: vqa_index_get_sketch_split; 0.1.6: vqa_index_sketch_stats, vqa_index_get_sketch_tile; 0.1.5: vqa_index_sketch_state; 0.1.4: VQA_INDEX_RESCORE_ROWS, vqa_index_device_bytes; 0.1.3: VQA_INDEX_SKETCH */
+#define VQA_VERSION 111 /* 0.1.11: vqa_encoder_forward_host, device queries in vqa_index_search_host; 0.1.10: vqa_index_search_host; 0.1.9: vqa_index_options / vqa_index_create_ex, vqa_encoder_options / vqa_encoder_create_ex (no environment variable is read any more), vqa_launch_info.levels; 0.1.8: vqa_encoder_forward_hidden; 0.1.7: vqa_index_get_sketch_split; 0.1.6: vqa_index_sketch_stats, vqa_index_get_sketch_tile; 0.1.5: vqa_index_sketch_state; 0.1.4: VQA_INDEX_RESCORE_ROWS, vqa_index_device_bytes; 0.1.3: VQA_INDEX_SKETCH */
 
 /* error codes */
 #define VQA_OK 0
@@ -200,6 +200,8 @@ int vqa_index_search(vqa_index* index, const void* q, int32_t q_dtype, int32_t B
  * device-mapped buffer the handle keeps (grown on demand), the kernels read them from there and write the results into pinned
  * memory, and the call polls the stream for completion (up to ~0.2 ms, then blocks).  The launches go to hip_stream: order it
  * with the handle's other searches as for vqa_index_search. */
+/* (q_host may also be a DEVICE pointer -- the question encoder's output: vqa_encoder_forward_host + this call are the whole text
+ * query of heavy_ranker.py:98; only the results then travel through the pinned buffer.) */
 int vqa_index_search_host(vqa_index* index, const void* q_host, int32_t q_dtype, int32_t B, int32_t k, int32_t normalize,
                           float* out_scores, int64_t* out_ids, int64_t* out_pos_or_null, void* hip_stream);
 
@@ -300,6 +302,15 @@ void vqa_encoder_destroy(vqa_encoder* enc);
  * report it without a synchronisation). */
 int vqa_encoder_forward(vqa_encoder* enc, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L,
                         int32_t real_tokens, int32_t pooling, int32_t normalize, float* out, void* hip_stream);
+
+/* The forward for HOST token ids / masks (what a tokenizer returns; one question per call in heavy_ranker.py:97-101): the CPU copies
+ * them into a pinned, device-mapped staging buffer of the handle -- no torch tensor, no copy operation per call -- and the launches are
+ * queued on hip_stream like vqa_encoder_forward's (asynchronous; out is a DEVICE pointer [B, hidden] fp32, typically handed to
+ * vqa_index_search_host next).  A right-padded mask is recognised here and packs calls of more than 1024 positions; token ids outside
+ * the table fail the call at once.  The staging buffer is reused: a second call waits (on the host) until the first one's launches
+ * have consumed it.  Not capturable into a hipGraph. */
+int vqa_encoder_forward_host(vqa_encoder* enc, const int32_t* input_ids_host, const int32_t* attn_mask_host, int32_t B, int32_t L,
+                             int32_t pooling, int32_t normalize, float* out_dev, void* hip_stream);
 
 /* Hidden states of the same forward (HF `output_hidden_states`: transformers BaseModelOutput.hidden_states[n_layers], what
  * `q_model(input_ids)` of src/test.py:84-86 carries beside .pooler_output): the embedding output (n_layers = 0) or the output of layer

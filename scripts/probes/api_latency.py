@@ -26,7 +26,7 @@ def tokenize(texts):
 n = 5000
 rng = np.random.default_rng(0)
 vecs = rng.standard_normal((n, 768)).astype(np.float32)
-emb = Embeddings(content=False, encoder=TextEncoder(tokenize, enc, pooling="cls"))
+emb = Embeddings(content=False, encoder=TextEncoder(tokenize, enc, pooling="cls"))  # text queries of <= 64 questions: forward_host + search_host
 emb.index_vectors(np.arange(1, n + 1), vecs)
 qv = rng.standard_normal((1, 768)).astype(np.float32)
 text = "xin chao day la mot cau hoi ve luat giao thong duong bo"

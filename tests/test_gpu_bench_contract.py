@@ -43,6 +43,8 @@ def test_bench_prints_one_json_line_with_the_contract_keys(native_lib):
         one = lat[f"search_one_vector_limit1_{rows}_docs_ms"]
         assert one["top1_equals_oracle"] and 0 < one["p10"] <= one["median"] <= one["p90"] < 5.0
     assert lat["encoder_one_question_32_tokens_ms"]["event_median"] > 0
+    text = lat["search_one_text_question_limit1_5000_docs_ms"]
+    assert text["top1_equals_oracle_on_the_encoded_vector"] and 0 < text["median"] < 5.0
     assert set(lat["300000_rows_fp16"]) == {"batch1_step_ms", "batch257_step_ms"}
     sm = r["step_ms"]
     assert sm["p10"] <= sm["median"] <= sm["p90"]

@@ -266,3 +266,53 @@ def test_embeddings_search_of_one_vector_takes_the_latency_path(native_lib):
     assert emb.batchsearch(q, 3) == via_torch
     one = emb.search(q[0], 1)
     assert len(one) == 1 and one[0] == via_torch[0][0]
+
+
+def test_text_questions_take_two_library_calls_and_return_the_general_paths_results(native_lib):
+    """`Embeddings.search(question, 1)` (heavy_ranker.py:98) with the encoder built here: tokenizer -> vqa_encoder_forward_host (host token ids
+    in, device vectors out) -> vqa_index_search_host (device vectors in, host results out).  Same results as encoding through the torch
+    path and searching the vectors; a question longer than the fast path's workspace, and more questions than it takes, fall back."""
+    from oracle import encoder as E
+    from vietnamese_qa_system_amd import Embeddings
+    from vietnamese_qa_system_amd.encoder import QuestionEncoder, TextEncoder
+    cfg = dict(E.PHOBERT_BASE, layers=2, vocab_size=5000)
+    w = E.synthetic_weights(cfg, seed=8, layers=2)
+    ids, mask = E.synthetic_tokens(cfg, 80, 24, seed=3)
+    table = {f"q{i}": (ids[i], mask[i]) for i in range(80)}
+    calls = []
+
+    def tokenizer(texts):
+        calls.append(len(texts))
+        return np.stack([table[t][0] for t in texts]), np.stack([table[t][1] for t in texts])
+
+    enc = QuestionEncoder(w, cfg, max_tokens=80 * 24)
+    te = TextEncoder(tokenizer, enc, pooling="mean")
+    rng = np.random.default_rng(1)
+    docs = rng.standard_normal((4000, 768)).astype(np.float32)
+    emb = Embeddings(encoder=te, min_score=None)
+    emb.index_vectors(list(range(1, 4001)), docs)
+    texts = [f"q{i}" for i in range(80)]
+
+    def general(sub):  # the torch path on the SAME call shape (the encoder picks its kernels by the number of positions): vectors, then search
+        return emb.batchsearch(te(sub), 3)
+
+    for i in (0, 1, 17):
+        assert emb.search(texts[i], 3) == general([texts[i]])[0]   # one question: the fast path, the latency form of the encoder
+    assert emb.batchsearch(texts[:9], 3) == general(texts[:9])     # nine questions: small-batch kernels
+    want = general(texts)
+    assert emb.batchsearch(texts, 3) == want                       # 80 > 64 questions: the general path itself
+    # the kernels differ between call shapes by fp16 rounding only: same documents, scores within 1e-3
+    nine = emb.batchsearch(texts[:9], 3)
+    assert [[d for d, _ in r] for r in nine] == [[d for d, _ in r] for r in want[:9]]
+    assert max(abs(a[1] - b[1]) for ra, rb in zip(nine, want[:9]) for a, b in zip(ra, rb)) < 1e-3
+    one = emb.search(texts[5], 1)
+    assert len(one) == 1 and one[0] == general([texts[5]])[0][0]
+    # device-resident vectors through the host-result entry: what the fast path's second call is
+    vecs = te(texts[:7])
+    s_h, i_h = emb._index.search_host(vecs.contiguous(), 3, normalize=True)
+    assert [[(int(i), float(s)) for i, s in zip(ir, sr)] for ir, sr in zip(i_h, s_h)] == [list(r) for r in general(texts[:7])]
+    with pytest.raises(ValueError, match="token id"):
+        bad = ids[:1].copy()
+        bad[0, 1] = 5000
+        enc.forward_host(bad, mask[:1], torch.empty((1, 768), dtype=torch.float32, device="cuda"))
+    enc.close()

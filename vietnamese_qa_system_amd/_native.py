@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VQA_LIB") or os.path.join(_HERE, "lib", "libvqa_retrieval.so")  # VQA_LIB: dev override
 
-VQA_VERSION = 110  # include/vqa_retrieval.h: the ABI these bindings were written against
+VQA_VERSION = 111  # include/vqa_retrieval.h: the ABI these bindings were written against
 VQA_F32, VQA_F16, VQA_FP8_E4M3 = 0, 1, 2
 VQA_INDEX_HAS_IDS = 1
 VQA_INDEX_SKETCH = 2
@@ -30,7 +30,7 @@ EXPORTS = (
     "vqa_version", "vqa_last_error", "vqa_index_create", "vqa_index_options_init", "vqa_index_create_ex", "vqa_index_set_rows", "vqa_index_get_rows", "vqa_index_destroy", "vqa_index_size", "vqa_index_dim",
     "vqa_index_dtype", "vqa_index_device_bytes", "vqa_index_sketch_state", "vqa_index_sketch_stats", "vqa_index_get_sketch_tile", "vqa_index_get_sketch_split", "vqa_index_search", "vqa_index_search_host", "vqa_merge_topk", "vqa_index_launch_info", "vqa_index_set_timing",
     "vqa_index_get_timing", "vqa_encoder_create", "vqa_encoder_options_init", "vqa_encoder_create_ex",
-    "vqa_encoder_destroy", "vqa_encoder_forward", "vqa_encoder_forward_hidden", "vqa_normalize_convert",
+    "vqa_encoder_destroy", "vqa_encoder_forward", "vqa_encoder_forward_host", "vqa_encoder_forward_hidden", "vqa_normalize_convert",
 )
 
 
@@ -143,6 +143,7 @@ def load() -> ctypes.CDLL:
     lib.vqa_encoder_destroy.restype = None
     lib.vqa_encoder_forward.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int32, c.c_int32, c.c_int32, c.c_int32, c.c_int32,
                                         c.c_void_p, c.c_void_p]
+    lib.vqa_encoder_forward_host.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int32, c.c_int32, c.c_int32, c.c_int32, c.c_void_p, c.c_void_p]
     lib.vqa_encoder_forward_hidden.argtypes = [c.c_void_p, c.c_void_p, c.c_void_p, c.c_int32, c.c_int32, c.c_int32, c.c_int32, c.c_void_p,
                                                c.c_void_p]
     lib.vqa_normalize_convert.argtypes = [c.c_void_p, c.c_int64, c.c_int32, c.c_int32, c.c_int32, c.c_void_p, c.c_void_p]

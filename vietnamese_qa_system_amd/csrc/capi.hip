@@ -1038,10 +1038,18 @@ extern "C" int vqa_index_search_host(vqa_index* ix, const void* q_host, int32_t 
     }
     char* h = static_cast<char*>(ix->hio);
     char* dv = static_cast<char*>(ix->hio_dev);
-    memcpy(h + q_off, q_host, qbytes);
-    const void* q_dev = dv + q_off;
+    // the queries may already be on the device (the question encoder's output: the text form of the reference's call, one C call for the
+    // forward and this one for the search, heavy_ranker.py:98): then only the results travel through the pinned buffer
+    hipPointerAttribute_t qattr;
+    const bool q_on_device = hipPointerGetAttributes(&qattr, q_host) == hipSuccess && qattr.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();  // an unregistered host pointer reports an error: not ours
+    const void* q_dev = q_host;
+    if (!q_on_device) {
+        memcpy(h + q_off, q_host, qbytes);
+        q_dev = dv + q_off;
+    }
     if (normalize) {  // x / ||x|| by the kernel every other path uses (Embeddings.batchsearch, vqa_normalize_convert): the same bits
-        int rc = vqa_normalize_convert(reinterpret_cast<const float*>(dv + q_off), B, ix->d, 1, VQA_F32, ix->hq_norm, stream);
+        int rc = vqa_normalize_convert(reinterpret_cast<const float*>(q_dev), B, ix->d, 1, VQA_F32, ix->hq_norm, stream);
         if (rc != VQA_OK) return rc;
         q_dev = ix->hq_norm;
     }

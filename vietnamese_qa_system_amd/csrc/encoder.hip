@@ -1698,6 +1698,10 @@ struct vqa_encoder {
     hipStream_t cap_stream = nullptr;  // capture happens on a stream of our own (the caller's may be the null stream, which
                                        // cannot be captured); the instantiated graph is launched on the caller's stream
     bool use_graphs = true;
+    int32_t* stage_host = nullptr;  // vqa_encoder_forward_host: pinned, device-mapped [2][max_tokens] token ids | masks
+    int32_t* stage_dev = nullptr;   // ... its device alias
+    hipEvent_t stage_done = nullptr;  // recorded behind the launches of the last forward_host call: the staging buffer is free again
+    bool stage_pending = false;
     int* bad_ids_host = nullptr;  // pinned, device-mapped: set by embed_ln when a token id lies outside [0, vocab_size)
     int* bad_ids_dev = nullptr;
     std::atomic_flag busy = ATOMIC_FLAG_INIT;  // one forward at a time per handle (staging buffers and graphs are shared)
@@ -2049,6 +2053,8 @@ extern "C" void vqa_encoder_destroy(vqa_encoder* e) {
         if (gr.exec) (void)hipGraphExecDestroy(gr.exec);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     if (e->bad_ids_host) (void)hipHostFree(e->bad_ids_host);
+    if (e->stage_host) (void)hipHostFree(e->stage_host);
+    if (e->stage_done) (void)hipEventDestroy(e->stage_done);
     delete e;
 }
 
@@ -2446,6 +2452,62 @@ extern "C" int vqa_encoder_forward_hidden(vqa_encoder* e, const int32_t* input_i
     return encoder_launch(e, input_ids, attn_mask, B, L, real_tokens, VQA_POOL_MEAN, 0, nullptr, (hipStream_t)hip_stream, n_layers, out_hidden);
 }
 
+static int forward_locked(vqa_encoder* e, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L, int32_t real_tokens,
+                          int32_t pooling, int32_t normalize, float* out, hipStream_t s);
+
+extern "C" int vqa_encoder_forward_host(vqa_encoder* e, const int32_t* ids_host, const int32_t* mask_host, int32_t B, int32_t L,
+                                        int32_t pooling, int32_t normalize, float* out_dev, void* hip_stream) {
+    VQA_REQUIRE(e, "vqa_encoder_forward_host: encoder is null");
+    VQA_REQUIRE(ids_host && mask_host && out_dev, "vqa_encoder_forward_host: null pointer");
+    VQA_REQUIRE(B >= 1 && L >= 1, "vqa_encoder_forward_host: B=%d L=%d", B, L);
+    VQA_REQUIRE((long long)B * L <= e->max_tokens, "vqa_encoder_forward_host: B*L=%lld exceeds the workspace of %d tokens", (long long)B * L,
+                e->max_tokens);
+    hipStream_t s = (hipStream_t)hip_stream;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    VQA_REQUIRE(cap == hipStreamCaptureStatusNone, "vqa_encoder_forward_host: the stream is being captured (this entry waits on the host)");
+    EncBusy busy(e->busy);
+    VQA_REQUIRE(busy.ok, "vqa_encoder_forward_host: this encoder handle is in use by another host thread (one forward at a time per handle)");
+    DevGuard guard(e->device);
+    const int T = B * L;
+    // host-side checks a device-pointer call can only make after the fact: ids inside the table, a right-padded mask (then packed)
+    int real = 0;
+    bool right_padded = true;
+    for (int b = 0; b < B; ++b) {
+        int n = 0;
+        for (int l = 0; l < L; ++l) {
+            const int32_t id = ids_host[b * L + l];
+            VQA_REQUIRE(id >= 0 && id < e->cfg.vocab_size, "vqa_encoder_forward_host: token id %d outside [0, %d) (tokenizer / vocabulary mismatch?)", id,
+                        e->cfg.vocab_size);
+            const bool m = mask_host[b * L + l] != 0;
+            right_padded = right_padded && !(m && n != l);
+            n += m;
+        }
+        right_padded = right_padded && n >= 1;
+        real += n;
+    }
+    if (!e->stage_host) {
+        if (hipHostMalloc((void**)&e->stage_host, (size_t)2 * e->max_tokens * 4, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void**)&e->stage_dev, e->stage_host, 0) != hipSuccess ||
+            hipEventCreateWithFlags(&e->stage_done, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            vqa_set_error("vqa_encoder_forward_host: allocating the pinned staging buffer failed");
+            return VQA_ENOMEM;
+        }
+    }
+    if (e->stage_pending) {  // the previous call's launches may still read the staging buffer
+        VQA_HIP_CHECK(hipEventSynchronize(e->stage_done));
+        e->stage_pending = false;
+    }
+    memcpy(e->stage_host, ids_host, (size_t)T * 4);
+    memcpy(e->stage_host + e->max_tokens, mask_host, (size_t)T * 4);
+    int rc = forward_locked(e, e->stage_dev, e->stage_dev + e->max_tokens, B, L, right_padded ? real : 0, pooling, normalize, out_dev, s);
+    if (rc != VQA_OK) return rc;
+    VQA_HIP_CHECK(hipEventRecord(e->stage_done, s));
+    e->stage_pending = true;
+    return VQA_OK;
+}
+
 extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L,
                                    int32_t real_tokens, int32_t pooling, int32_t normalize, float* out, void* hip_stream) {
     VQA_REQUIRE(e, "vqa_encoder_forward: encoder is null");
@@ -2461,6 +2523,16 @@ extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, con
     hipStream_t s = (hipStream_t)hip_stream;
     EncBusy busy(e->busy);
     VQA_REQUIRE(busy.ok, "vqa_encoder_forward: this encoder handle is in use by another host thread (one forward at a time per handle)");
+    DevGuard guard(e->device);
+    return forward_locked(e, input_ids, attn_mask, B, L, real_tokens, pooling, normalize, out, s);
+}
+
+// the body of a forward call: arguments checked by the caller, handle held, device set
+static int forward_locked(vqa_encoder* e, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L, int32_t real_tokens,
+                          int32_t pooling, int32_t normalize, float* out, hipStream_t s) {
+    const int last_pos = e->cfg.position_ids == VQA_POS_ABSOLUTE ? L - 1 : L + e->cfg.pad_id;
+    VQA_REQUIRE(last_pos < e->cfg.max_pos, "vqa_encoder_forward: L=%d needs position %d, the table has %d rows", L, last_pos, e->cfg.max_pos);
+    VQA_REQUIRE(pooling == VQA_POOL_CLS || pooling == VQA_POOL_MEAN, "vqa_encoder_forward: pooling %d", pooling);
     if (__atomic_load_n(e->bad_ids_host, __ATOMIC_RELAXED)) {
         __atomic_store_n(e->bad_ids_host, 0, __ATOMIC_RELAXED);
         vqa_set_error("vqa_encoder_forward: an earlier forward on this handle saw token ids outside [0, %d) (embedded as the pad token: "
@@ -2468,7 +2540,6 @@ extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, con
                       "differed from the announced one (its output is invalid)", e->cfg.vocab_size);
         return VQA_EINVAL;
     }
-    DevGuard guard(e->device);
     const int T = B * L;
     // Launch-bound sizes replay a captured graph (unless the caller's stream is itself being captured: then the kernels
     // simply join the caller's capture).  Above 1024 tokens the kernels are long enough for eager launches to stay ahead of
@@ -2487,8 +2558,8 @@ extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, con
         return encoder_launch(e, input_ids, attn_mask, B, L, 0, pooling, normalize, out, s);
     }
     const size_t H = e->cfg.hidden;
-    VQA_HIP_CHECK(hipMemcpyAsync(e->g_ids, input_ids, (size_t)T * 4, hipMemcpyDeviceToDevice, s));
-    VQA_HIP_CHECK(hipMemcpyAsync(e->g_mask, attn_mask, (size_t)T * 4, hipMemcpyDeviceToDevice, s));
+    VQA_HIP_CHECK(hipMemcpyAsync(e->g_ids, input_ids, (size_t)T * 4, hipMemcpyDefault, s));
+    VQA_HIP_CHECK(hipMemcpyAsync(e->g_mask, attn_mask, (size_t)T * 4, hipMemcpyDefault, s));
     if (!gr->exec) {
         hipGraph_t graph = nullptr;
         VQA_HIP_CHECK(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));

@@ -90,6 +90,7 @@ class Embeddings:
         self._sparse: Optional[BM25Index] = None
         self._row_ids: Optional[np.ndarray] = None  # device-level id of every global row position (sparse hits -> ids)
         self._index: Optional[DeviceIndex] = None
+        self._qbuf: Optional[torch.Tensor] = None  # query vectors of the text fast path (encoder output -> search input, on the device)
         self._searcher: Optional[ShardedSearcher] = None
         self._host_ids: Optional[list] = None  # non-integer external ids, by row position
         self._docs_db: Optional[str] = None
@@ -329,6 +330,10 @@ class Embeddings:
                 raise ValueError(f"query dimension {queries.shape[1]} != index dimension {self.d}")
             scores, ids = self._index.search_host(queries, limit, normalize=self.normalize and queries.dtype == np.float32)
             return self._format(scores, ids)
+        # a few text questions against one shard, encoder built here (TextEncoder over QuestionEncoder): tokenizer -> ONE library call for
+        # the forward (host ids in, device vectors out) -> ONE for the search (device vectors in, host results out)
+        if self._text_fast_path(queries):
+            return self._search_texts_fast(list(queries), limit)
         q = self._query_vectors(queries)
         if q.shape[1] != self.d:
             raise ValueError(f"query dimension {q.shape[1]} != index dimension {self.d}")
@@ -338,6 +343,35 @@ class Embeddings:
         scores, ids = self._searcher.search(q, limit)
         torch.cuda.current_stream(q.device).synchronize()
         return self._format(scores.cpu().numpy(), ids.cpu().numpy())
+
+    def _text_fast_path(self, queries) -> bool:
+        from .encoder import QuestionEncoder, TextEncoder
+        if isinstance(queries, (np.ndarray, torch.Tensor)) or not len(queries) or not isinstance(queries[0], str):
+            return False
+        if len(queries) > HOST_PATH_MAX_QUERIES or self._searcher.collective or (self.hybrid and self._sparse is not None and 0.0 < self.weights < 1.0):
+            return False
+        if self.encoder is None and self.path and os.path.isdir(str(self.path)):
+            self.encoder = self._encoder_from_path()
+        enc = self.encoder
+        return isinstance(enc, TextEncoder) and isinstance(enc.encoder, QuestionEncoder) and enc.encoder.device == self.device
+
+    def _search_texts_fast(self, texts: List[str], limit: int) -> List[list]:
+        te = self.encoder
+        ids, mask = te.tokenizer(texts)
+        ids = ids.cpu().numpy() if isinstance(ids, torch.Tensor) else np.asarray(ids)
+        mask = mask.cpu().numpy() if isinstance(mask, torch.Tensor) else np.asarray(mask)
+        if ids.ndim != 2:
+            raise ValueError("the tokenizer must return [B, L] input_ids")
+        if ids.size > te.encoder.max_tokens:  # (a long question: the general path slices it)
+            return self.batchsearch(self._encode(texts), limit)
+        h = int(te.encoder.config["hidden"])
+        if h != self.d:
+            raise ValueError(f"query dimension {h} != index dimension {self.d}")
+        if self._qbuf is None or self._qbuf.shape[1] != h:
+            self._qbuf = torch.empty((HOST_PATH_MAX_QUERIES, h), dtype=torch.float32, device=torch.device("cuda", self.device))
+        q = te.encoder.forward_host(ids, mask, self._qbuf, pooling=te.pooling, normalize=te.normalize)
+        scores, out_ids = self._index.search_host(q, limit, normalize=self.normalize)
+        return self._format(scores, out_ids)
 
     def _hybrid(self, q: torch.Tensor, texts: List[str], limit: int) -> List[list]:
         """txtai's hybrid search [recalled, see sparse.py]: 10 x limit candidates from each half, per-id convex combination

@@ -178,6 +178,30 @@ class QuestionEncoder:
 
     __call__ = forward
 
+    def forward_host(self, input_ids: np.ndarray, attention_mask: np.ndarray, out: torch.Tensor, *, pooling: str = "cls",
+                     normalize: bool = True) -> torch.Tensor:
+        """The forward for HOST token ids / masks (``vqa_encoder_forward_host``): [B, L] integer numpy arrays in, ``out`` [>= B, hidden]
+        fp32 cuda tensor filled (its first B rows) -- one library call, no torch tensor created, no copy operation; asynchronous on the
+        current stream.  The text form of the reference's one-question call (``heavy_ranker.py:98``) pairs it with
+        ``DeviceIndex.search_host(out[:B], ...)``."""
+        if not self._handle.value:
+            raise RuntimeError("encoder is closed")
+        if pooling not in POOLING:
+            raise ValueError(f"pooling must be one of {sorted(POOLING)}")
+        ids = np.ascontiguousarray(input_ids, dtype=np.int32)
+        mask = np.ascontiguousarray(attention_mask, dtype=np.int32)
+        if ids.ndim != 2 or mask.shape != ids.shape:
+            raise ValueError("input_ids and attention_mask must both be [B, L]")
+        b, l = int(ids.shape[0]), int(ids.shape[1])
+        h = int(self.config["hidden"])
+        if (not isinstance(out, torch.Tensor) or not out.is_cuda or out.device.index != self.device or out.dtype != torch.float32 or
+                out.dim() != 2 or out.shape[0] < b or out.shape[1] != h or not out.is_contiguous()):
+            raise ValueError(f"out must be a contiguous [>= {b}, {h}] float32 tensor on cuda:{self.device}")
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        N.check(self._lib.vqa_encoder_forward_host(self._handle, ids.ctypes.data, mask.ctypes.data, b, l, POOLING[pooling],
+                                                   int(bool(normalize)), out.data_ptr(), stream), "vqa_encoder_forward_host")
+        return out[:b]
+
     def hidden_states(self, input_ids, attention_mask, n_layers: Optional[int] = None, *,
                       real_tokens: Optional[int] = None) -> torch.Tensor:
         """Hidden state of every position after ``n_layers`` layers (``None``: all = HF ``last_hidden_state``; 0: the embedding

@@ -222,7 +222,7 @@ class DeviceIndex:
                     "vqa_index_search")
         return scores, ids, pos
 
-    def search_host(self, queries: np.ndarray, k: int, *, normalize: bool = False, return_positions: bool = False):
+    def search_host(self, queries, k: int, *, normalize: bool = False, return_positions: bool = False):
         """The latency form (``vqa_index_search_host``): ``queries`` [B, d] float32 / float16 HOST array -> (scores [B, k] float32,
         ids [B, k] int64[, positions]) as numpy arrays, synchronous -- one library call, no torch tensor, no per-call device
         allocation, no copy operation (pinned device-mapped staging inside the handle).  ``normalize``: L2-normalise float32
@@ -230,15 +230,25 @@ class DeviceIndex:
         one question per call, limit 1 (``heavy_ranker.py:97-101``)."""
         if not self._handle.value:
             raise RuntimeError("index is closed")
-        q = np.ascontiguousarray(queries)
-        if q.ndim != 2 or q.shape[1] != self.d:
-            raise ValueError(f"queries must be a [B, {self.d}] array")
-        if q.dtype == np.float32:
-            qd = N.VQA_F32
-        elif q.dtype == np.float16:
-            qd = N.VQA_F16
+        if isinstance(queries, torch.Tensor):
+            # device-resident queries (the question encoder's output): host results all the same -- polled completion, no torch op
+            q = queries
+            if not q.is_cuda or q.device.index != self.device or q.dim() != 2 or q.shape[1] != self.d or not q.is_contiguous():
+                raise ValueError(f"a tensor of queries must be a contiguous [B, {self.d}] tensor on cuda:{self.device}")
+            if q.dtype not in _SRC_DTYPE:
+                raise ValueError(f"queries must be float32 or float16, got {q.dtype}")
+            qd, qptr = _SRC_DTYPE[q.dtype], q.data_ptr()
         else:
-            raise ValueError(f"queries must be float32 or float16, got {q.dtype}")
+            q = np.ascontiguousarray(queries)
+            if q.ndim != 2 or q.shape[1] != self.d:
+                raise ValueError(f"queries must be a [B, {self.d}] array")
+            if q.dtype == np.float32:
+                qd = N.VQA_F32
+            elif q.dtype == np.float16:
+                qd = N.VQA_F16
+            else:
+                raise ValueError(f"queries must be float32 or float16, got {q.dtype}")
+            qptr = q.ctypes.data
         b = int(q.shape[0])
         if b == 0:
             raise ValueError("empty query batch")
@@ -246,7 +256,7 @@ class DeviceIndex:
         ids = np.empty((b, k), dtype=np.int64)
         pos = np.empty((b, k), dtype=np.int64) if return_positions else None
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        N.check(self._lib.vqa_index_search_host(self._handle, q.ctypes.data, qd, b, int(k), int(bool(normalize)), scores.ctypes.data,
+        N.check(self._lib.vqa_index_search_host(self._handle, qptr, qd, b, int(k), int(bool(normalize)), scores.ctypes.data,
                                                 ids.ctypes.data, pos.ctypes.data if pos is not None else None, stream),
                 "vqa_index_search_host")
         return (scores, ids, pos) if return_positions else (scores, ids)
