@@ -135,6 +135,9 @@ int main() {
     vqa_encoder_destroy(nullptr);
     int32_t tok[4] = {0, 1, 2, 3};
     EXPECT(vqa_encoder_forward(nullptr, tok, tok, 1, 4, 0, VQA_POOL_CLS, 1, s, nullptr) == VQA_EINVAL);
+    EXPECT(vqa_encoder_forward_host(nullptr, tok, tok, 1, 4, VQA_POOL_CLS, 1, s, nullptr) == VQA_EINVAL);
+    EXPECT(vqa_encoder_forward_hidden(nullptr, tok, tok, 1, 4, 0, 1, s, nullptr) == VQA_EINVAL);
+    EXPECT(vqa_index_search_host(nullptr, s, VQA_F32, 1, 1, 0, s, ids, nullptr, nullptr) == VQA_EINVAL);
     EXPECT(vqa_normalize_convert(nullptr, 1, 4, 1, VQA_F16, s, nullptr) == VQA_EINVAL);
     EXPECT(vqa_normalize_convert(s, -1, 4, 1, VQA_F16, s, nullptr) == VQA_EINVAL);
     EXPECT(vqa_normalize_convert(s, 1, 4, 1, 9, s, nullptr) == VQA_EINVAL);
