@@ -117,6 +117,15 @@ def test_embeddings_loads_the_model_named_by_path(native_lib, golden_dir):
     res = emb.search("text 2", 4)
     want = np.argsort(-(ref @ ref[2]))
     assert [r["id"] for r in res] == [10 + int(j) for j in want]
+    # heavy_ranker.py:87 / :91-94: save, then a FRESH object loads the directory; the model path travels in meta.json, so text queries work
+    # again as soon as a tokenizer is there (the reference re-creates Embeddings() and calls .load(...) before it searches)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        emb.save(tmp)
+        again = Embeddings(tokenizer=tokenizer, max_tokens=64, min_score=None).load(tmp)
+        assert again.path == f"{golden_dir}/hf_tiny_roberta_st" and again.content is True
+        assert again.search("text 2", 4) == res
+        again._index.close()
     # the BERT directory (prefixed pytorch_model.bin, no modules.json): pooling stays what the caller asked for
     gb, _ = _npz_weights(golden_dir, "enc_bert_tiny.npz")
     encb = QuestionEncoder.from_pretrained(f"{golden_dir}/hf_tiny_bert_bin", max_tokens=64)

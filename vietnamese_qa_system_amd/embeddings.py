@@ -124,6 +124,7 @@ class Embeddings:
         """``path=<local model directory>`` -> ``TextEncoder`` over the HIP encoder (built once, on first use)."""
         from .encoder import QuestionEncoder, TextEncoder
         enc = QuestionEncoder.from_pretrained(self.path, device=self.device, max_tokens=self.max_tokens)
+        self._auto_encoder_path = self.path  # (load() of an index built with another model drops this encoder)
         tok = self.tokenizer
         if tok is None:
             try:
@@ -530,6 +531,8 @@ class Embeddings:
             raise ValueError(f"unsupported index format {meta.get('format')}")
         n, d = int(meta["n"]), int(meta["d"])
         self.dtype, self.normalize, self.pooling = meta["dtype"], meta["normalize"], meta["pooling"]
+        if getattr(self, "_auto_encoder_path", None) not in (None, meta["path"]):
+            self.encoder, self._auto_encoder_path = None, None  # built from the path of ANOTHER model: the loaded index names its own
         self.path, self.content, self.hybrid = meta["path"], meta["content"], meta["hybrid"]
         self._host_ids = meta.get("host_ids")
         lo, hi = shard_bounds(n, self.world, self.rank)
