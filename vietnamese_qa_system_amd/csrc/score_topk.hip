@@ -153,6 +153,28 @@ __device__ __forceinline__ void mma_block(f32x4 (&acc)[8][4], const frag_t (&a)[
     }
 }
 
+// fp32 (exact f32 MFMA at 1/16 of the fp16 rate: the one scan that is bound by its MFMAs) with a partly filled query tile: only the
+// wave's first `ng` query column groups are multiplied (wave-uniform; the skipped accumulators stay 0 and their queries' thresholds
+// are +inf).  One question against a small fp32 index (the reference's call on BASELINE configs[0]'s shape) then costs 1/16 of a
+// full tile's matrix time.  Query group outermost, sub-step and row group inside: consecutive MFMAs still hit different accumulators.
+template <int DT>
+__device__ __forceinline__ void mma_block_groups(f32x4 (&acc)[8][4], const frag_t (&a)[8], const frag_t (&b)[4], int ng) {
+    static_assert(MfmaTraits<DT>::kSub == 4, "the f32 form");
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        if (ni < ng) {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) acc[mi][ni] = MfmaTraits<DT>::template mma<0>(a[mi], b[ni], acc[mi][ni]);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) acc[mi][ni] = MfmaTraits<DT>::template mma<1>(a[mi], b[ni], acc[mi][ni]);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) acc[mi][ni] = MfmaTraits<DT>::template mma<2>(a[mi], b[ni], acc[mi][ni]);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) acc[mi][ni] = MfmaTraits<DT>::template mma<3>(a[mi], b[ni], acc[mi][ni]);
+        }
+    }
+}
+
 typedef __attribute__((address_space(3))) char* lds_char_ptr;
 
 constexpr int kThreads = 512;           // 8 waves: 2 (row halves = ping-pong groups) x 4 (query quarters)
@@ -894,11 +916,19 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         } else {
             // fp32: 4x the MFMAs per K-step and one register set (a second one spills): issue the DMA pieces, multiply,
             // then refill the same registers; the reads' latency hides under the partner wave's MFMAs
+            // query column groups of this wave that hold a live query (4 for a full tile: the plain block)
+            [[maybe_unused]] const int live_q = nq - 64 * wn;
+            [[maybe_unused]] const int ng = live_q >= 64 ? 4 : live_q <= 0 ? 0 : (live_q + 15) >> 4;
             for (int kt = 0; kt < KT; ++kt) {
                 const int kappa = ti * KT + kt;
                 VQA_ISSUE();
                 VQA_SB();
-                VQA_MMA(a0, b0);
+                if constexpr (DT == VQA_F32 && !(VQA_ABLATE & 4)) {
+                    if (ng == 4) VQA_MMA(a0, b0);
+                    else mma_block_groups<DT>(acc, a0, b0, ng);
+                } else {
+                    VQA_MMA(a0, b0);
+                }
                 VQA_SB();
                 if (kt + 1 < KT || ti + 1 < ntile) VQA_READ_FRAGS(a0, b0);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
