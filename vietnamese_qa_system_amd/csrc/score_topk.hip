@@ -924,8 +924,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
                 VQA_ISSUE();
                 VQA_SB();
                 if constexpr (DT == VQA_F32 && !(VQA_ABLATE & 4)) {
-                    if (ng == 4) VQA_MMA(a0, b0);
-                    else mma_block_groups<DT>(acc, a0, b0, ng);
+                    mma_block_groups<DT>(acc, a0, b0, ng);  // (ONE code path: a second, unconditional copy of the block made the kernel spill)
                 } else {
                     VQA_MMA(a0, b0);
                 }
