@@ -37,7 +37,7 @@ int main() {
         memset(&o, 0xAB, sizeof(o));
         vqa_index_options_init(&o);
         EXPECT(o.struct_size == sizeof(o) && o.flags == 0 && o.stage_min_tiles == -1 && o.stage_pct == 10 && o.sketch_cooldown == 64 &&
-               o.sketch_profit < 0.f && o.poison_workspace == -1 && o.rescore_copy == -1 && o.sketch_per_row == -1 && o.seed_mult == 2);
+               o.sketch_profit < 0.f && o.poison_workspace == -1 && o.rescore_copy == -1 && o.sketch_per_row == -1 && o.seed_mult == 2 && o.one_launch == 1);
         vqa_index_options_init(nullptr);
         vqa_index_options bad_o = o;
         bad_o.struct_size = 0;

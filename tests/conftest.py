@@ -30,7 +30,7 @@ def native_lib():
 # field it became, through the Python-side default dictionaries (index.DEFAULT_OPTIONS / encoder.DEFAULT_OPTIONS).
 _INDEX_OPTION = {"VQA_STAGE_MIN": "stage_min_tiles", "VQA_STAGE_PCT": "stage_pct", "VQA_WIDE_K": "wide_k", "VQA_TWO_PASS": "two_pass",
                  "VQA_SKETCH": "sketch", "VQA_SKETCH_CASCADE": "sketch_cascade", "VQA_SKETCH_MID_K": "sketch_mid_k",
-                 "VQA_SKETCH_MID_MIN": "sketch_mid_min_tiles", "VQA_SKETCH_PRE_K": "sketch_pre_k", "VQA_POISON_WORKSPACE": "poison_workspace",
+                 "VQA_SKETCH_MID_MIN": "sketch_mid_min_tiles", "VQA_SKETCH_PRE_K": "sketch_pre_k", "VQA_POISON_WORKSPACE": "poison_workspace", "VQA_ONE_LAUNCH": "one_launch",
                  "VQA_SKETCH_CENTER": "sketch_center", "VQA_SKETCH_PER_ROW": "sketch_per_row", "VQA_SKETCH_ROTATE": "sketch_rotate",
                  "VQA_SKETCH_COOLDOWN": "sketch_cooldown", "VQA_SKETCH_PROFIT": "sketch_profit", "VQA_SKETCH_SPLIT": "sketch_split",
                  "VQA_F16_LOOP": "f16_loop", "VQA_RESCORE_COPY": "rescore_copy"}

@@ -251,6 +251,57 @@ def test_host_latency_path_returns_the_batch_paths_bits(native_lib, dtype, n, op
     ix.close()
 
 
+@pytest.mark.parametrize("n,d,with_ids", [(1, 768, False), (63, 64, True), (257, 100, False), (5000, 768, True), (16384, 768, False),
+                                          (16385, 256, True), (40000, 768, False), (131072, 128, False)])
+def test_one_launch_search_returns_the_general_paths_bits(native_lib, n, d, with_ids):
+    """K4 (csrc/tiny_search.hip): on an fp16 shard of <= 131 072 rows, vqa_index_search_host with <= 16 questions, k <= 16 and questions x k <= 64 is ONE
+    kernel -- normalise, score, select, merge.  Same scores / ids / positions, bit for bit, as the general launches on a handle with
+    options.one_launch = 0, for raw fp32 questions (normalised by the call or not) and fp16 questions; rows stored twice tie and come
+    back in position order; fewer rows than k: padding; 50 calls in a row (the ticket returns to zero) agree; and == the oracle."""
+    from vietnamese_qa_system_amd.index import DeviceIndex
+    rng = np.random.default_rng(n + d)
+    x = R.l2_normalize(rng.standard_normal((n, d)).astype(np.float32))
+    if n >= 257:
+        x[n // 2] = x[3]   # ties across workgroups ...
+        x[5] = x[3]        # ... and inside one
+    ids = (np.arange(n, dtype=np.int64) * 7 + 11) if with_ids else None
+    q = rng.standard_normal((16, d)).astype(np.float32)
+    q[0] = x[min(3, n - 1)] * 2.5
+    kw = dict(dtype="fp16", device=0)
+    one = DeviceIndex(x, ids=ids, id_base=1, **kw)
+    gen = DeviceIndex(x, ids=ids, id_base=1, options={"one_launch": 0}, **kw)
+    for b, k in ((1, 1), (1, 3), (1, 16), (4, 16), (16, 4), (5, 12), (8, 8), (2, 5), (16, 16)):  # (the last one: past questions x k <= 64, the general launches)
+        for norm in (True, False):
+            a = one.search_host(q[:b], k, normalize=norm, return_positions=True)
+            g = gen.search_host(q[:b], k, normalize=norm, return_positions=True)
+            for u, v in zip(a, g):
+                assert np.array_equal(u, v), (b, k, norm)
+            if n < k:
+                assert (a[1][:, n:] == -1).all() and np.isneginf(a[0][:, n:]).all() and (a[2][:, n:] == -1).all()
+            if n >= 257 and k >= 3 and norm:
+                assert list(a[2][0, :3]) == [3, 5, n // 2]
+            if with_ids:
+                live = a[2] >= 0
+                assert np.array_equal(a[1][live], a[2][live] * 7 + 11)
+    q16 = R.l2_normalize(q).astype(np.float16)
+    a, g = one.search_host(q16[:9], 10, return_positions=True), gen.search_host(q16[:9], 10, return_positions=True)
+    for u, v in zip(a, g):
+        assert np.array_equal(u, v)
+    if n >= 10:
+        R.check_topk(a[0], a[2], R.full_scores(q16[:9].astype(np.float32), x.astype(np.float16), R.DTYPE_F16), 10, score_tol=1e-5, tie_tol=2e-6)
+    first = one.search_host(q[:3], 4, normalize=True, return_positions=True)
+    for _ in range(50):
+        again = one.search_host(q[:3], 4, normalize=True, return_positions=True)
+        for u, v in zip(first, again):
+            assert np.array_equal(u, v)
+    # past its limits the same call takes the general launches
+    s17 = one.search_host(np.tile(q, (2, 1))[:17], 3, normalize=True)
+    g17 = gen.search_host(np.tile(q, (2, 1))[:17], 3, normalize=True)
+    assert np.array_equal(s17[0], g17[0]) and np.array_equal(s17[1], g17[1])
+    one.close()
+    gen.close()
+
+
 def test_embeddings_search_of_one_vector_takes_the_latency_path(native_lib):
     """Embeddings.search(vector, 1) -- the reference's call shape -- goes through vqa_index_search_host and returns what batchsearch
     of a device tensor returns; lists of floats and float64 arrays too."""

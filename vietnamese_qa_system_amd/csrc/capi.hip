@@ -161,6 +161,8 @@ struct vqa_index {
     size_t hio_bytes = 0;
     void* hq_norm = nullptr;
     size_t hq_norm_bytes = 0;
+    bool one_launch = true;   // options.one_launch: small fp16 shards answer vqa_index_search_host with ONE kernel (tiny_search.hip)
+    void* tiny_ws = nullptr;  // its per-workgroup lists + ticket (lazy)
     std::atomic_flag busy = ATOMIC_FLAG_INIT;  // one search at a time per handle (the workspace is shared)
 };
 
@@ -198,6 +200,7 @@ extern "C" void vqa_index_destroy(vqa_index* ix) {
     if (ix->q_rows) (void)hipFree(ix->q_rows);
     if (ix->hio) (void)hipHostFree(ix->hio);
     if (ix->hq_norm) (void)hipFree(ix->hq_norm);
+    if (ix->tiny_ws) (void)hipFree(ix->tiny_ws);
     for (int b = 0; b < 2; ++b) {
         if (ix->up_pinned[b]) (void)hipHostFree(ix->up_pinned[b]);
         if (ix->up_dev[b]) (void)hipFree(ix->up_dev[b]);
@@ -391,6 +394,7 @@ extern "C" void vqa_index_options_init(vqa_index_options* o) {
     o->sketch_profit = -1.0f;
     o->rescore_copy = -1;
     o->poison_workspace = -1;
+    o->one_launch = 1;
 }
 
 // -DVQA_DEV variant libraries only (scripts/: ab_loops.py, probes): the rounds-1-4 environment switches laid over the options
@@ -418,6 +422,7 @@ static void dev_env_overlay(vqa_index_options* o) {
     geti("VQA_SKETCH_COOLDOWN", &o->sketch_cooldown);
     if (const char* v = vqa_dev_env("VQA_SKETCH_PROFIT")) o->sketch_profit = (float)atof(v);
     geti("VQA_RESCORE_COPY", &o->rescore_copy);
+    geti("VQA_ONE_LAUNCH", &o->one_launch);
     if (const char* v = vqa_dev_env("VQA_POISON_WORKSPACE")) o->poison_workspace = (int)strtol(v, nullptr, 0) & 0xFF;
     if (const char* v = vqa_dev_env("VQA_SKETCH")) {
         if (v[0] == '0') o->flags &= ~(uint32_t)VQA_INDEX_SKETCH;
@@ -488,6 +493,7 @@ extern "C" int vqa_index_create_ex(vqa_index** out, int device, int64_t n, int32
     ix->max_grid = ix->num_cu;
     ix->two_pass = o.two_pass != 0;
     ix->wide = o.wide_k != 0;
+    ix->one_launch = o.one_launch != 0;
     ix->seed_div = o.seed_div;
     ix->seed_mult = o.seed_mult;
     const bool stage_given = o.stage_min_tiles >= 0;  // (tests, A/B runs: a plan forced at a size production would not pick it at)
@@ -1008,7 +1014,19 @@ extern "C" int vqa_index_search_host(vqa_index* ix, const void* q_host, int32_t 
     const size_t qbytes = (size_t)B * ix->d * (q_dtype == VQA_F32 ? 4 : 2), nres = (size_t)B * k;
     const size_t q_off = 0, s_off = (qbytes + 63) / 64 * 64, i_off = s_off + (nres * 4 + 63) / 64 * 64, p_off = i_off + nres * 8;
     const size_t need = p_off + nres * 8;
-    if (ix->hio_bytes < need || (normalize && ix->hq_norm_bytes < qbytes)) {
+    // one launch for the whole call where K4 applies (tiny_search.hip); `timing` handles time the scan kernel of the general path
+    const bool one_launch = ix->one_launch && !ix->timing && !ix->sketch && ix->scale == 1.0f && vqa_tiny_search_applies(ix->dtype, ix->n, ix->d_pad, B, k);
+    if (one_launch && !ix->tiny_ws) {
+        const size_t ws = vqa_tiny_search_workspace_bytes();
+        if (hipMalloc(&ix->tiny_ws, ws) != hipSuccess) {
+            (void)hipGetLastError();
+            ix->tiny_ws = nullptr;
+            vqa_set_error("vqa_index_search_host: allocating %zu device bytes failed", ws);
+            return VQA_ENOMEM;
+        }
+        VQA_HIP_CHECK(hipMemsetAsync(ix->tiny_ws, 0, ws, stream));  // the ticket starts at zero; every call leaves it there
+    }
+    if (ix->hio_bytes < need || ((normalize || one_launch) && ix->hq_norm_bytes < qbytes)) {
         VQA_HIP_CHECK(hipStreamSynchronize(stream));  // (an earlier call's kernels may still read the buffers about to be replaced)
         if (ix->hio_bytes < need) {
             if (ix->hio) (void)hipHostFree(ix->hio);
@@ -1023,7 +1041,7 @@ extern "C" int vqa_index_search_host(vqa_index* ix, const void* q_host, int32_t 
             }
             ix->hio_bytes = cap;
         }
-        if (normalize && ix->hq_norm_bytes < qbytes) {
+        if ((normalize || one_launch) && ix->hq_norm_bytes < qbytes) {
             if (ix->hq_norm) (void)hipFree(ix->hq_norm);
             ix->hq_norm = nullptr;
             ix->hq_norm_bytes = 0;
@@ -1048,13 +1066,20 @@ extern "C" int vqa_index_search_host(vqa_index* ix, const void* q_host, int32_t 
         memcpy(h + q_off, q_host, qbytes);
         q_dev = dv + q_off;
     }
-    if (normalize) {  // x / ||x|| by the kernel every other path uses (Embeddings.batchsearch, vqa_normalize_convert): the same bits
-        int rc = vqa_normalize_convert(reinterpret_cast<const float*>(q_dev), B, ix->d, 1, VQA_F32, ix->hq_norm, stream);
-        if (rc != VQA_OK) return rc;
-        q_dev = ix->hq_norm;
-    }
-    int rc = search_impl(ix, q_dev, q_dtype, B, k, reinterpret_cast<float*>(dv + s_off), reinterpret_cast<int64_t*>(dv + i_off),
+    int rc;
+    if (one_launch) {
+        rc = vqa_launch_tiny_search(ix->rows, ix->n, ix->d, ix->d_pad, q_dev, q_on_device ? nullptr : q_host, ix->hq_norm, q_dtype, normalize, B, k, ix->ids, ix->id_base, ix->tiny_ws,
+                                    reinterpret_cast<float*>(dv + s_off), reinterpret_cast<int64_t*>(dv + i_off),
+                                    out_pos_or_null ? reinterpret_cast<int64_t*>(dv + p_off) : nullptr, stream);
+    } else {
+        if (normalize) {  // x / ||x|| by the kernel every other path uses (Embeddings.batchsearch, vqa_normalize_convert): the same bits
+            rc = vqa_normalize_convert(reinterpret_cast<const float*>(q_dev), B, ix->d, 1, VQA_F32, ix->hq_norm, stream);
+            if (rc != VQA_OK) return rc;
+            q_dev = ix->hq_norm;
+        }
+        rc = search_impl(ix, q_dev, q_dtype, B, k, reinterpret_cast<float*>(dv + s_off), reinterpret_cast<int64_t*>(dv + i_off),
                          out_pos_or_null ? reinterpret_cast<int64_t*>(dv + p_off) : nullptr, stream);
+    }
     if (rc != VQA_OK) return rc;
     // poll: a search of a small shard is a handful of launches of a few microseconds; sleeping on the completion interrupt costs more
     // than they take.  After ~0.2 ms of polling (large shards) the blocking wait takes over.

@@ -15,46 +15,11 @@ namespace {
 constexpr int kMergeThreads = 256;
 constexpr int kRadixSelectK = 32;  // merge_partials_kernel: from this k on the k-th key is found by radix descent instead of k selection rounds
 
-// Largest key of the wave, in every lane.  Four DPP steps inside each row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror,
-// row_mirror: the partner's two halves arrive with one VALU move each), then v_permlane16_swap / v_permlane32_swap of a register
-// with itself across the rows -- no LDS crossbar (six 64-bit __shfl_xor steps are twelve dependent ds_bpermute round trips, which
-// was most of a selection round).
-template <int CTRL>
-__device__ __forceinline__ vqa_key dpp_max_step(vqa_key v) {
-    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false);
-    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false);
-    const vqa_key o = ((vqa_key)ohi << 32) | olo;
-    return o > v ? o : v;
-}
-
-__device__ __forceinline__ vqa_key wave_max_key(vqa_key v) {
-    v = dpp_max_step<0xB1>(v);   // quad_perm [1, 0, 3, 2]
-    v = dpp_max_step<0x4E>(v);   // quad_perm [2, 3, 0, 1]
-    v = dpp_max_step<0x141>(v);  // row_half_mirror
-    v = dpp_max_step<0x140>(v);  // row_mirror: every lane holds its row's maximum
-    {
-        const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);  // {rows 0 0 2 2, rows 1 1 3 3}
-        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-        const vqa_key x = ((vqa_key)(unsigned)b[0] << 32) | (unsigned)a[0], y = ((vqa_key)(unsigned)b[1] << 32) | (unsigned)a[1];
-        v = x > y ? x : y;
-    }
-    {
-        const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
-        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);  // {lower half twice, upper half twice}
-        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-        const vqa_key x = ((vqa_key)(unsigned)b[0] << 32) | (unsigned)a[0], y = ((vqa_key)(unsigned)b[1] << 32) | (unsigned)a[1];
-        v = x > y ? x : y;
-    }
-    return v;
-}
-
 // block-wide max of per-thread values; every thread gets the result.  red: LDS [2][4], `round` picks the half -- ONE barrier per
 // call: the half written in round r is next written in round r + 2, behind the barrier of round r + 1 that every reader of round r
 // has passed.
 __device__ __forceinline__ vqa_key block_max_key(vqa_key v, vqa_key* red, int round) {
-    v = wave_max_key(v);
+    v = vqa_wave_max_key(v);
     const int wave = threadIdx.x >> 6;
     vqa_key* slot = red + 4 * (round & 1);
     if ((threadIdx.x & 63) == 0) slot[wave] = v;

@@ -78,6 +78,41 @@ __host__ __device__ __forceinline__ vqa_key vqa_make_key(float score, uint32_t p
 __host__ __device__ __forceinline__ float vqa_key_score(vqa_key k) { return vqa_ordered_f32((uint32_t)(k >> 32)); }
 __host__ __device__ __forceinline__ uint32_t vqa_key_pos(vqa_key k) { return 0xFFFFFFFFu - (uint32_t)k; }
 
+// Largest key of the wave, in every lane.  Four DPP steps inside each row of 16 lanes (quad_perm xor 1, xor 2, row_half_mirror,
+// row_mirror: the partner's two halves arrive with one VALU move each), then v_permlane16_swap / v_permlane32_swap of a register
+// with itself across the rows -- no LDS crossbar (six 64-bit __shfl_xor steps are twelve dependent ds_bpermute round trips, which
+// was most of a selection round).
+template <int CTRL>
+__device__ __forceinline__ vqa_key vqa_dpp_max_step(vqa_key v) {
+    const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+    const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, 0xf, 0xf, false);
+    const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, 0xf, 0xf, false);
+    const vqa_key o = ((vqa_key)ohi << 32) | olo;
+    return o > v ? o : v;
+}
+
+__device__ __forceinline__ vqa_key vqa_wave_max_key(vqa_key v) {
+    v = vqa_dpp_max_step<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+    v = vqa_dpp_max_step<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+    v = vqa_dpp_max_step<0x141>(v);  // row_half_mirror
+    v = vqa_dpp_max_step<0x140>(v);  // row_mirror: every lane holds its row's maximum
+    {
+        const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);  // {rows 0 0 2 2, rows 1 1 3 3}
+        const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        const vqa_key x = ((vqa_key)(unsigned)b[0] << 32) | (unsigned)a[0], y = ((vqa_key)(unsigned)b[1] << 32) | (unsigned)a[1];
+        v = x > y ? x : y;
+    }
+    {
+        const unsigned lo = (unsigned)v, hi = (unsigned)(v >> 32);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);  // {lower half twice, upper half twice}
+        const auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        const vqa_key x = ((vqa_key)(unsigned)b[0] << 32) | (unsigned)a[0], y = ((vqa_key)(unsigned)b[1] << 32) | (unsigned)a[1];
+        v = x > y ? x : y;
+    }
+    return v;
+}
+
 // internal storage code of the int8 sketch of a large fp16 shard (never a public index type: include/vqa_retrieval.h)
 #define VQA_I8_SKETCH 3
 
@@ -246,3 +281,12 @@ int vqa_launch_rescore(const unsigned long long* regions, const unsigned* counts
                        vqa_key* cand_keys, unsigned* cand_cnt, int capq, int* overflow, hipStream_t stream);
 // rows [first, first + count) of a tiled shard -> its row-major copy (rows of row_bytes = padded row length in bytes)
 int vqa_launch_rows_to_rowmajor(const void* tiled, int64_t first, int64_t count, int32_t row_bytes, void* out, hipStream_t stream);
+
+// K4 (tiny_search.hip): the whole search of a small fp16 shard for <= 16 questions and k <= 16 in ONE launch -- the latency form of
+// vqa_index_search_host.  `workspace`: vqa_tiny_search_workspace_bytes() of device memory, zeroed once; results go to out_* (device
+// pointers, here: the handle's mapped pinned buffer).  Same bits as the general path (tests/test_gpu_embeddings.py).
+bool vqa_tiny_search_applies(int32_t dtype, int64_t n, int32_t d_pad, int32_t B, int32_t k);
+size_t vqa_tiny_search_workspace_bytes();
+int vqa_launch_tiny_search(const void* rows_tiled, int64_t n, int32_t d, int32_t d_pad, const void* q, const void* q_host_or_null, void* q_stage, int32_t q_dtype,
+                           int32_t normalize, int32_t nq, int32_t k, const int64_t* ids, int64_t id_base, void* workspace, float* out_scores,
+                           int64_t* out_ids, int64_t* out_pos, hipStream_t stream);
