@@ -29,13 +29,13 @@ for n in (1000, 5000, 16384, 20000, 50000, 131072):
     x /= np.linalg.norm(x, axis=1, keepdims=True)
     q = rng.standard_normal((1, d)).astype(np.float32)
     q16 = rng.standard_normal((16, d)).astype(np.float32)
-    for one in (1, 0):
-        ix = DeviceIndex(x, id_base=1, dtype="fp16", device=0, options={"one_launch": one})
+    for dtype, one in ((t, o) for t in os.environ.get("DTYPES", "fp16,fp32").split(",") for o in (1, 0)):
+        ix = DeviceIndex(x, id_base=1, dtype=dtype, device=0, options={"one_launch": one})
         s, i = np.empty((1, 1), np.float32), np.empty((1, 1), np.int64)
         stream = torch.cuda.current_stream(0).cuda_stream
         lib = ix._lib
         raw = lambda: lib.vqa_index_search_host(ix._handle, q.ctypes.data, N.VQA_F32, 1, 1, 1, s.ctypes.data, i.ctypes.data, None, stream)
-        print(f"n={n:6d} one_launch={one}: C call {wall(raw)} | DeviceIndex.search_host {wall(lambda: ix.search_host(q, 1, normalize=True))}", flush=True)
+        print(f"n={n:6d} {dtype} one_launch={one}: C call {wall(raw)} | DeviceIndex.search_host {wall(lambda: ix.search_host(q, 1, normalize=True))}", flush=True)
         print("      " + " | ".join(f"B={b} k={k}: {wall(lambda: ix.search_host(q16[:b], k, normalize=True))}" for b, k in ((1, 10), (4, 16), (16, 4))), flush=True)
         ix.close()
 emb = Embeddings(dtype="fp16", device=0)

@@ -251,10 +251,11 @@ def test_host_latency_path_returns_the_batch_paths_bits(native_lib, dtype, n, op
     ix.close()
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
 @pytest.mark.parametrize("n,d,with_ids", [(1, 768, False), (63, 64, True), (257, 100, False), (5000, 768, True), (16384, 768, False),
                                           (16385, 256, True), (40000, 768, False), (131072, 128, False)])
-def test_one_launch_search_returns_the_general_paths_bits(native_lib, n, d, with_ids):
-    """K4 (csrc/tiny_search.hip): on an fp16 shard of <= 131 072 rows, vqa_index_search_host with <= 16 questions, k <= 16 and questions x k <= 64 is ONE
+def test_one_launch_search_returns_the_general_paths_bits(native_lib, n, d, with_ids, dtype):
+    """K4 (csrc/tiny_search.hip): on an fp16 or fp32 shard of <= 131 072 rows, vqa_index_search_host with <= 16 questions, k <= 16 and questions x k <= 64 is ONE
     kernel -- normalise, score, select, merge.  Same scores / ids / positions, bit for bit, as the general launches on a handle with
     options.one_launch = 0, for raw fp32 questions (normalised by the call or not) and fp16 questions; rows stored twice tie and come
     back in position order; fewer rows than k: padding; 50 calls in a row (the ticket returns to zero) agree; and == the oracle."""
@@ -267,7 +268,7 @@ def test_one_launch_search_returns_the_general_paths_bits(native_lib, n, d, with
     ids = (np.arange(n, dtype=np.int64) * 7 + 11) if with_ids else None
     q = rng.standard_normal((16, d)).astype(np.float32)
     q[0] = x[min(3, n - 1)] * 2.5
-    kw = dict(dtype="fp16", device=0)
+    kw = dict(dtype=dtype, device=0)
     one = DeviceIndex(x, ids=ids, id_base=1, **kw)
     gen = DeviceIndex(x, ids=ids, id_base=1, options={"one_launch": 0}, **kw)
     for b, k in ((1, 1), (1, 3), (1, 16), (4, 16), (16, 4), (5, 12), (8, 8), (2, 5), (16, 16)):  # (the last one: past questions x k <= 64, the general launches)
@@ -288,7 +289,8 @@ def test_one_launch_search_returns_the_general_paths_bits(native_lib, n, d, with
     for u, v in zip(a, g):
         assert np.array_equal(u, v)
     if n >= 10:
-        R.check_topk(a[0], a[2], R.full_scores(q16[:9].astype(np.float32), x.astype(np.float16), R.DTYPE_F16), 10, score_tol=1e-5, tie_tol=2e-6)
+        stored, code = (x.astype(np.float16), R.DTYPE_F16) if dtype == "fp16" else (x, R.DTYPE_F32)
+        R.check_topk(a[0], a[2], R.full_scores(q16[:9].astype(np.float32), stored, code), 10, score_tol=1e-5, tie_tol=2e-6)
     first = one.search_host(q[:3], 4, normalize=True, return_positions=True)
     for _ in range(50):
         again = one.search_host(q[:3], 4, normalize=True, return_positions=True)

@@ -1068,7 +1068,7 @@ extern "C" int vqa_index_search_host(vqa_index* ix, const void* q_host, int32_t 
     }
     int rc;
     if (one_launch) {
-        rc = vqa_launch_tiny_search(ix->rows, ix->n, ix->d, ix->d_pad, q_dev, q_on_device ? nullptr : q_host, ix->hq_norm, q_dtype, normalize, B, k, ix->ids, ix->id_base, ix->tiny_ws,
+        rc = vqa_launch_tiny_search(ix->rows, ix->dtype, ix->n, ix->d, ix->d_pad, q_dev, q_on_device ? nullptr : q_host, ix->hq_norm, q_dtype, normalize, B, k, ix->ids, ix->id_base, ix->tiny_ws,
                                     reinterpret_cast<float*>(dv + s_off), reinterpret_cast<int64_t*>(dv + i_off),
                                     out_pos_or_null ? reinterpret_cast<int64_t*>(dv + p_off) : nullptr, stream);
     } else {
@@ -1084,7 +1084,10 @@ extern "C" int vqa_index_search_host(vqa_index* ix, const void* q_host, int32_t 
     // poll: a search of a small shard is a handful of launches of a few microseconds; sleeping on the completion interrupt costs more
     // than they take.  After ~0.2 ms of polling (large shards) the blocking wait takes over.
     hipError_t st = hipErrorNotReady;
-    for (int spin = 0; spin < 400 && st == hipErrorNotReady; ++spin) st = hipStreamQuery(stream);
+    // (ONE short kernel: the blocking wait itself spins first and sees the completion ~3.5 us sooner than a hipStreamQuery loop --
+    // scripts/probes/launch_sync_floor.hip: 10.8 against 14.6 us around an empty kernel)
+    const int spins = one_launch ? 0 : 400;
+    for (int spin = 0; spin < spins && st == hipErrorNotReady; ++spin) st = hipStreamQuery(stream);
     if (st == hipErrorNotReady) {
         (void)hipGetLastError();
         st = hipStreamSynchronize(stream);

@@ -1,20 +1,24 @@
-// K4 -- ONE-launch search of a small fp16 shard for a handful of questions, gfx950 only.
+// K4 -- ONE-launch search of a small fp16 / fp32 shard for a handful of questions, gfx950 only.
 //
 // The reference asks ONE question per call with limit = 1 against a corpus of a few thousand documents
 // (inference_pipeline/db_utils/heavy_ranker.py:97-101).  At that size the general search
 // (normalise -> query staging -> seed scan -> threshold merge -> main scan -> list merge: six dependent launches, capi.hip) is all
 // launch latency: 0.05 ms of device time for a few MB of rows.  This kernel does the whole call in one launch.  Every workgroup
-// (W waves -- 2 up to 16 384 rows, else 4 --, one per 32 W rows of the shard)
-//   (1) L2-normalises the raw fp32 questions and rounds them to fp16 -- the arithmetic of normalize_convert_kernel followed by the
-//       staging conversion (convert.hip), bit for bit --,
-//   (2) scores its rows against them with v_mfma_f32_16x16x32_f16 (A = corpus rows, B = questions, K-steps in ascending order: the
-//       exact scan's accumulation chains, so the scores are the exact scan's bits), fragments straight from the shard's tiled layout
-//       (a wave's 16 rows of a K-block are 1 KiB contiguous), every load of a 12-K-block chunk in flight before its first MFMA,
+// (W waves of RG row groups of 16: 64 rows of a shard of up to 16 384 rows, else 128)
+//   (1) L2-normalises the raw fp32 questions and converts them to the storage type -- the arithmetic of normalize_convert_kernel
+//       followed by the staging conversion (convert.hip), bit for bit --,
+//   (2) scores its rows against them on the exact scan's MFMA (fp16: one v_mfma_f32_16x16x32_f16 per K-block; fp32: four
+//       v_mfma_f32_16x16x4_f32, the lane's float t of its fragment in sub-step t) -- A = corpus rows, B = questions, K-blocks and
+//       sub-steps in ascending order: the exact scan's accumulation chains (score_topk.hip MfmaTraits / mma_block), hence its bits --,
+//       fragments straight from the shard's tiled layout (a wave's 16 rows of a K-block are 1 KiB contiguous), every load of a chunk
+//       of K-blocks in flight before its first MFMA, the first chunk requested before the questions are touched,
 //   (3) keeps its k best (score, position) keys per question (k rounds of a wave maximum),
 //   (4) publishes them and takes a ticket; the LAST workgroup to arrive merges all lists and writes scores, external ids and
 //       positions -- straight into the caller's pinned memory.
-// Limits (vqa_tiny_search_applies): fp16 storage, <= 16 questions, k <= 16, questions x k <= 64, <= 131 072 rows.
+// Limits (vqa_tiny_search_applies): fp16 / fp32 storage, <= 16 questions, k <= 16, questions x k <= 64, <= 131 072 rows.
 #include <string.h>
+
+#include <type_traits>
 
 #include "vqa_common.h"
 
@@ -22,15 +26,16 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int frag_t __attribute__((ext_vector_type(4)));  // 16 bytes of one row: 8 fp16 | 4 fp32
 
 constexpr int kTinyQ = 16;      // questions per call (one MFMA column group)
 constexpr int kTinyK = 16;      // results per question
 constexpr int kTinyMaxResults = 64;  // questions x results per call
-constexpr int kTinyChunk = 12;  // K-blocks whose fragments a wave keeps in flight together
+constexpr int kTinyChunk = 12;  // K-blocks whose fragments a wave keeps in flight together (fp16, RG = 2: 96 registers; all 24 of a 768-element row at once: measured equal)
 constexpr int kTinyMaxUnits = 1024;
 constexpr int kTinyArgBytes = 3584;  // of questions inside the launch packet (4 KB of kernel arguments at most)
 constexpr int kTinyMaxRows = 131072;
-constexpr int kTinySmallRows = 16384;  // up to here: workgroups of 64 rows (a 5000-row shard on 79 CUs instead of 20)
+constexpr int kTinySmallRows = 16384;  // up to here: workgroups of 64 rows (a 5000-row shard on 79 CUs instead of 40)
 
 // the k largest of the keys a wave holds (PER per lane; real keys are distinct, 0 = empty), largest first
 template <int PER, typename EMIT>
@@ -54,105 +59,138 @@ struct TinyQArg {
     uint4 v[kTinyArgBytes / 16];
 };
 
-template <int W>
-__global__ __launch_bounds__(64 * W) void tiny_search_kernel(const _Float16* __restrict__ X, long long n, int KT, int d, const void* __restrict__ q,
-                                                             const TinyQArg qa, int q_in_args, int q_is_f16, int normalize, int nq, int k,
-                                                             const long long* __restrict__ ids,
-                                                             long long id_base, vqa_key* partial, unsigned* ticket,
-                                                             float* __restrict__ out_scores, long long* __restrict__ out_ids,
-                                                             long long* __restrict__ out_pos) {
-    constexpr int RU = 32 * W;  // rows per workgroup
+struct TinyArgs {
+    const void* x;  // the shard's rows, tiled (convert.hip)
+    long long n;
+    int KT, d;      // K-blocks of 64 bytes per row; elements per row
+    const void* q;  // questions [nq, d] fp32 / fp16 as the device sees them (unused when they travel in the launch packet)
+    int q_in_args, q_is_f16, normalize, nq, k;
+    const long long* ids;
+    long long id_base;
+    vqa_key* partial;  // [16 questions][16 slots][kTinyMaxUnits]
+    unsigned* ticket;
+    float* out_scores;
+    long long* out_ids;
+    long long* out_pos;
+};
+
+// one K-block of one 16 x 16 accumulator: the exact scan's instruction(s) on the lane's 16-byte fragments
+template <int DT>
+__device__ __forceinline__ f32x4 mma_kblock(frag_t a, frag_t b, f32x4 c) {
+    if constexpr (DT == VQA_F16) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8, a), __builtin_bit_cast(half8, b), c, 0, 0, 0);
+    } else {
+        const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0], bf[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1], bf[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(af[2], bf[2], c, 0, 0, 0);
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(af[3], bf[3], c, 0, 0, 0);
+    }
+}
+
+template <int W, int RG, int DT>
+__global__ __launch_bounds__(64 * W) void tiny_search_kernel(const TinyArgs p, const TinyQArg qa) {
+    constexpr int RW = 16 * RG;          // rows per wave
+    constexpr int RU = RW * W;           // rows per workgroup
+    constexpr int CH = kTinyChunk * 2 / RG;  // K-blocks per chunk: 96 registers of fragments whatever RG
+    typedef typename std::conditional<DT == VQA_F16, _Float16, float>::type store_t;
+    static_assert(RU % 64 == 0 && 256 % RU == 0, "a workgroup's rows: whole 64-key groups inside one 256-row tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int unit = blockIdx.x, units = gridDim.x;
+    const int KT = p.KT, d = p.d, nq = p.nq, k = p.k;
     const int qstride = KT * 64 + 16;  // bytes per question of the LDS image (+16: the 16 questions of a fragment read start in different banks)
     vqa_key* keys = reinterpret_cast<vqa_key*>(smem + kTinyQ * qstride);  // [16 questions][RU rows]
     __shared__ unsigned last_flag;
+    __shared__ int sel[W][kTinyK];
 
     // ---- (0) the first chunk of this wave's rows is requested before anything else: it travels while the questions are prepared
-    const long long row0 = (long long)unit * RU + wave * 32;  // first row of the wave; its 32 rows lie in one 256-row tile
     // (addresses as a wave-uniform base per K-block + ONE per-lane byte offset: scalar registers instead of a vector pair per load)
+    const long long row0 = (long long)unit * RU + wave * RW;  // first row of the wave; its rows lie in one 256-row tile
     const int tile = __builtin_amdgcn_readfirstlane((int)(row0 >> 8));
-    const char* xb = reinterpret_cast<const char*>(X) + (size_t)tile * KT * 16384;
-    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-    const int r_lo = (int)(row0 & 255) + c;  // the lane's row of the first 16; its row of the second 16 lies 16 x 64 bytes further
+    const char* xb = reinterpret_cast<const char*>(p.x) + (size_t)tile * KT * 16384;
+    f32x4 acc[RG];
+#pragma unroll
+    for (int mi = 0; mi < RG; ++mi) acc[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r_lo = (int)(row0 & 255) + c;  // the lane's row of the first 16; its row of the next 16 lies 16 x 64 bytes further
     const unsigned voff = (unsigned)(r_lo * 4 + (g ^ (((r_lo >> 3) & 1) * 3))) * 16u;  // slot g of the row inside a 16 KiB K-block (convert.hip: tiled_unit)
     const char* qfrag = smem + (size_t)c * qstride + g * 16;
-    half8 a[kTinyChunk][2];
+    frag_t a[CH][RG];
     auto load_chunk = [&](int k0) {
 #pragma unroll
-        for (int j = 0; j < kTinyChunk; ++j) {
+        for (int j = 0; j < CH; ++j) {
             const int kap = k0 + j < KT ? k0 + j : KT - 1;  // (past the end: the last block again, not multiplied)
             const char* blk = xb + (size_t)kap * 16384;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a[j][mi] = *reinterpret_cast<const half8*>(blk + voff + mi * 1024);
+            for (int mi = 0; mi < RG; ++mi) a[j][mi] = *reinterpret_cast<const frag_t*>(blk + voff + mi * 1024);
         }
     };
     load_chunk(0);
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- (1) the questions.  Raw bytes -> LDS in 16-byte units (one round trip, whatever the source), then x / ||x|| in fp32 (sum of
-    // squares strided over the lanes, xor-shuffle reduction, true division) rounded to fp16; columns past d are zeros.  Questions past
-    // nq are left as they are: an MFMA output column depends on ITS question only, and those columns are never read.
+    // squares strided over the lanes, xor-shuffle reduction, true division) converted to the storage type; columns past d are zeros.
+    // Questions past nq are left as they are: an MFMA output column depends on ITS question only, and those columns are never read.
     char* raw = smem + kTinyQ * qstride;  // (the keys' space and beyond: lds_bytes)
     {
-        const int total = nq * d * (q_is_f16 ? 2 : 4);
-        if (q_in_args) {
+        const int total = nq * d * (p.q_is_f16 ? 2 : 4);
+        if (p.q_in_args) {
             for (int u = tid; u * 16 < total; u += 64 * W) reinterpret_cast<uint4*>(raw)[u] = qa.v[u];
-        } else if (((reinterpret_cast<uintptr_t>(q) | (uintptr_t)total) & 15) == 0) {
-            for (int u = tid; u * 16 < total; u += 64 * W) reinterpret_cast<uint4*>(raw)[u] = reinterpret_cast<const uint4*>(q)[u];
+        } else if (((reinterpret_cast<uintptr_t>(p.q) | (uintptr_t)total) & 15) == 0) {
+            for (int u = tid; u * 16 < total; u += 64 * W) reinterpret_cast<uint4*>(raw)[u] = reinterpret_cast<const uint4*>(p.q)[u];
         } else {
 #pragma unroll 1
-            for (int u = tid; u * 2 < total; u += 64 * W) reinterpret_cast<unsigned short*>(raw)[u] = reinterpret_cast<const unsigned short*>(q)[u];
+            for (int u = tid; u * 2 < total; u += 64 * W) reinterpret_cast<unsigned short*>(raw)[u] = reinterpret_cast<const unsigned short*>(p.q)[u];
         }
     }
     __syncthreads();
+    const int cols = KT * (64 / (int)sizeof(store_t));  // padded row length in elements
     for (int qi = wave; qi < nq; qi += W) {
-        _Float16* dst = reinterpret_cast<_Float16*>(smem + (size_t)qi * qstride);
-        if (q_is_f16) {
+        store_t* dst = reinterpret_cast<store_t*>(smem + (size_t)qi * qstride);
+        if (p.q_is_f16) {
             const _Float16* src = reinterpret_cast<const _Float16*>(raw) + (size_t)qi * d;
-            for (int j = lane; j < KT * 32; j += 64) dst[j] = j < d ? src[j] : (_Float16)0.f;
+            for (int j = lane; j < cols; j += 64) dst[j] = j < d ? (store_t)src[j] : (store_t)0.f;
         } else {
             const float* src = reinterpret_cast<const float*>(raw) + (size_t)qi * d;
             float nrm = 0.f;
-            if (normalize) {
+            if (p.normalize) {
                 float ss = 0.f;
                 for (int j = lane; j < d; j += 64) ss += src[j] * src[j];
 #pragma unroll
                 for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
                 nrm = sqrtf(ss);
             }
-            for (int j = lane; j < KT * 32; j += 64) {
+            for (int j = lane; j < cols; j += 64) {
                 float v = 0.f;
                 if (j < d) v = nrm > 0.f ? src[j] / nrm : src[j];
-                dst[j] = (_Float16)v;
+                dst[j] = (store_t)v;
             }
         }
     }
     __syncthreads();
 
-    // ---- (2) scores of this wave's 32 rows x 16 questions
-    for (int k0 = 0; k0 < KT; k0 += kTinyChunk) {
+    // ---- (2) scores of this wave's rows x 16 questions
+    for (int k0 = 0; k0 < KT; k0 += CH) {
         if (k0) load_chunk(k0);
         __builtin_amdgcn_sched_barrier(0);  // every load of the chunk is issued before the first MFMA
 #pragma unroll
-        for (int j = 0; j < kTinyChunk; ++j) {
+        for (int j = 0; j < CH; ++j) {
             if (k0 + j < KT) {
-                const half8 b = *reinterpret_cast<const half8*>(qfrag + (k0 + j) * 64);
+                const frag_t b = *reinterpret_cast<const frag_t*>(qfrag + (k0 + j) * 64);
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) acc[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[j][mi], b, acc[mi], 0, 0, 0);
+                for (int mi = 0; mi < RG; ++mi) acc[mi] = mma_kblock<DT>(a[j][mi], b, acc[mi]);
             }
         }
     }
     // acc[mi][j] = score(row row0 + 16 mi + 4 g + j, question c)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < RG; ++mi)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int r = wave * 32 + mi * 16 + g * 4 + j;
+            const int r = wave * RW + mi * 16 + g * 4 + j;
             const long long pos = (long long)unit * RU + r;
-            keys[c * RU + r] = pos < n ? vqa_make_key(acc[mi][j], (uint32_t)pos) : 0ull;
+            keys[c * RU + r] = pos < p.n ? vqa_make_key(acc[mi][j], (uint32_t)pos) : 0ull;
         }
     __syncthreads();
 
@@ -162,7 +200,7 @@ __global__ __launch_bounds__(64 * W) void tiny_search_kernel(const _Float16* __r
         vqa_key mine[PER];
 #pragma unroll
         for (int i = 0; i < PER; ++i) mine[i] = keys[qi * RU + lane + 64 * i];
-        vqa_key* dst = partial + (size_t)qi * kTinyK * kTinyMaxUnits + unit;
+        vqa_key* dst = p.partial + (size_t)qi * kTinyK * kTinyMaxUnits + unit;
         wave_topk<PER>(mine, k, [&](int r, vqa_key best) {  // (device-scope stores: past this XCD's L2, which the others do not see)
             if (lane == 0) __hip_atomic_store(dst + (size_t)r * kTinyMaxUnits, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         });
@@ -173,28 +211,27 @@ __global__ __launch_bounds__(64 * W) void tiny_search_kernel(const _Float16* __r
     // invalidates the XCD's whole L2, once per workgroup -- 103 us instead of 40 at 131 072 rows.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) last_flag = atomicAdd(ticket, 1u) == (unsigned)(units - 1) ? 1u : 0u;
+    if (tid == 0) last_flag = atomicAdd(p.ticket, 1u) == (unsigned)(units - 1) ? 1u : 0u;
     __syncthreads();
     if (!last_flag) return;
-    if (tid == 0) *ticket = 0u;  // for the next call on this handle (stream order)
+    if (tid == 0) *p.ticket = 0u;  // for the next call on this handle (stream order)
     // Two levels, one wave per question.  A key of the overall top k belongs to a workgroup whose BEST key is one of the k largest
     // best keys (otherwise k keys of other workgroups beat it): select those k workgroups from the <= 1024 best keys (16 per lane, one
     // round of loads), then the answer from their k lists (k * k <= 256 keys, 4 per lane).
-    __shared__ int sel[W][kTinyK];
     for (int qi = wave; qi < nq; qi += W) {
-        const vqa_key* mine_q = partial + (size_t)qi * kTinyK * kTinyMaxUnits;
+        const vqa_key* mine_q = p.partial + (size_t)qi * kTinyK * kTinyMaxUnits;
         auto emit = [&](int r, vqa_key best) {
             if (lane != 0) return;
             const size_t o = (size_t)qi * k + r;
             if (best == 0ull) {  // fewer than k rows: padding, as the general merge writes it
-                out_scores[o] = -INFINITY;
-                out_ids[o] = -1;
-                if (out_pos) out_pos[o] = -1;
+                p.out_scores[o] = -INFINITY;
+                p.out_ids[o] = -1;
+                if (p.out_pos) p.out_pos[o] = -1;
             } else {
                 const long long pos = (long long)vqa_key_pos(best);
-                out_scores[o] = vqa_key_score(best);
-                out_ids[o] = ids ? ids[pos] : id_base + pos;
-                if (out_pos) out_pos[o] = pos;
+                p.out_scores[o] = vqa_key_score(best);
+                p.out_ids[o] = p.ids ? p.ids[pos] : p.id_base + pos;
+                if (p.out_pos) p.out_pos[o] = pos;
             }
         };
         vqa_key head[kTinyMaxUnits / 64];
@@ -231,38 +268,28 @@ __global__ __launch_bounds__(256) void stage_questions_kernel(const void* __rest
     }
 }
 
-template <int W>
-int launch(int units, size_t lds, hipStream_t stream, const void* rows, int64_t n, int KT, int32_t d, const void* q, const void* q_host, void* q_stage, int32_t q_dtype,
-           int32_t normalize, int32_t nq, int32_t k, const int64_t* ids, int64_t id_base, vqa_key* partial, unsigned* ticket, float* out_scores,
-           int64_t* out_ids, int64_t* out_pos) {
-    TinyQArg qa;
-    const size_t qbytes = (size_t)nq * d * (q_dtype == VQA_F16 ? 2 : 4);
-    const int q_in_args = q_host && qbytes <= sizeof(qa);
-    if (q_in_args) {
-        memcpy(&qa, q_host, qbytes);
-    } else if (q_host) {
-        hipLaunchKernelGGL(stage_questions_kernel, dim3((unsigned)((qbytes + 4095) / 4096)), dim3(256), 0, stream, q, q_stage, (int)qbytes);
-        q = q_stage;
-    }
+// the storage-type image of 16 questions + the larger of the keys [16][rows per workgroup] and the raw questions (fp32 at most) they overlay
+size_t lds_bytes(int32_t row_bytes, int32_t d_pad, int rows_per_wg, int nq) {
+    const size_t keys = (size_t)kTinyQ * rows_per_wg * sizeof(vqa_key), raw = (size_t)nq * d_pad * 4;
+    return (size_t)kTinyQ * (row_bytes + 16) + (keys > raw ? keys : raw);
+}
+constexpr size_t kTinyLdsMax = 160 * 1024 - 1024;  // (the kernel's static LDS: a flag and the merge's selections)
+
+template <int W, int RG, int DT>
+int launch(const TinyArgs& p, const TinyQArg& qa, int32_t d_pad, hipStream_t stream) {
+    constexpr int RU = 16 * RG * W;
+    const size_t lds = lds_bytes(p.KT * 64, d_pad, RU, p.nq);
     if (lds > 64 * 1024) {
         static VqaPerDeviceOnce once;
         int rc = once.run([&](int) -> int {
-            VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tiny_search_kernel<W>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+            VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(tiny_search_kernel<W, RG, DT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTinyLdsMax));
             return VQA_OK;
         });
         if (rc != VQA_OK) return rc;
     }
-    hipLaunchKernelGGL(tiny_search_kernel<W>, dim3(units), dim3(64 * W), lds, stream, reinterpret_cast<const _Float16*>(rows), (long long)n, KT, d, q,
-                       qa, q_in_args, q_dtype == VQA_F16 ? 1 : 0, normalize, nq, k, reinterpret_cast<const long long*>(ids), (long long)id_base, partial, ticket,
-                       out_scores, reinterpret_cast<long long*>(out_ids), reinterpret_cast<long long*>(out_pos));
+    hipLaunchKernelGGL((tiny_search_kernel<W, RG, DT>), dim3((unsigned)((p.n + RU - 1) / RU)), dim3(64 * W), lds, stream, p, qa);
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
-}
-
-// the fp16 image of 16 questions + the larger of the keys [16][rows per workgroup] and the raw questions (fp32 at most) they overlay
-size_t lds_bytes(int32_t d_pad, int rows_per_wg, int nq) {
-    const size_t keys = (size_t)kTinyQ * rows_per_wg * sizeof(vqa_key), raw = (size_t)nq * d_pad * 4;
-    return (size_t)kTinyQ * (d_pad * 2 + 16) + (keys > raw ? keys : raw);
 }
 
 }  // namespace
@@ -270,8 +297,8 @@ size_t lds_bytes(int32_t d_pad, int rows_per_wg, int nq) {
 bool vqa_tiny_search_applies(int32_t dtype, int64_t n, int32_t d_pad, int32_t B, int32_t k) {
     // (B k <= 64: every selection round is a wave-wide maximum, a question's rounds run in ONE wave, and past that the general path's
     // block-wide selections are level or ahead -- 16 questions x 16 results: 122-194 us here, 120-170 us there)
-    return dtype == VQA_F16 && n >= 1 && n <= kTinyMaxRows && B >= 1 && B <= kTinyQ && k >= 1 && k <= kTinyK && B * k <= kTinyMaxResults &&
-           lds_bytes(d_pad, 128, kTinyQ) <= 160 * 1024 - 1024;
+    return (dtype == VQA_F16 || dtype == VQA_F32) && n >= 1 && n <= kTinyMaxRows && B >= 1 && B <= kTinyQ && k >= 1 && k <= kTinyK &&
+           B * k <= kTinyMaxResults && lds_bytes(d_pad * (dtype == VQA_F16 ? 2 : 4), d_pad, 128, kTinyQ) <= kTinyLdsMax;
 }
 
 size_t vqa_tiny_search_workspace_bytes() { return (size_t)kTinyMaxUnits * kTinyQ * kTinyK * sizeof(vqa_key) + 64; }
@@ -279,15 +306,42 @@ size_t vqa_tiny_search_workspace_bytes() { return (size_t)kTinyMaxUnits * kTinyQ
 // workspace: [16][16][kTinyMaxUnits] keys, then the ticket (zero before the first call; the kernel leaves it zero).  q: the questions
 // as the device sees them; q_host: the same bytes in host memory or nullptr (questions that live on the device); q_stage: device memory for
 // them (host questions larger than the launch packet's share are copied there by a kernel in front)
-int vqa_launch_tiny_search(const void* rows_tiled, int64_t n, int32_t d, int32_t d_pad, const void* q, const void* q_host, void* q_stage, int32_t q_dtype,
-                           int32_t normalize, int32_t nq, int32_t k, const int64_t* ids, int64_t id_base, void* workspace, float* out_scores,
-                           int64_t* out_ids, int64_t* out_pos, hipStream_t stream) {
-    const int KT = d_pad * 2 / 64;
-    vqa_key* partial = static_cast<vqa_key*>(workspace);
-    unsigned* ticket = reinterpret_cast<unsigned*>(partial + (size_t)kTinyMaxUnits * kTinyQ * kTinyK);
-    if (n <= kTinySmallRows && nq <= 4)  // (more questions: twice the waves to share their normalisation and selection rounds)
-        return launch<2>((int)((n + 63) / 64), lds_bytes(d_pad, 64, nq), stream, rows_tiled, n, KT, d, q, q_host, q_stage, q_dtype, normalize, nq, k, ids, id_base,
-                         partial, ticket, out_scores, out_ids, out_pos);
-    return launch<4>((int)((n + 127) / 128), lds_bytes(d_pad, 128, nq), stream, rows_tiled, n, KT, d, q, q_host, q_stage, q_dtype, normalize, nq, k, ids, id_base,
-                     partial, ticket, out_scores, out_ids, out_pos);
+int vqa_launch_tiny_search(const void* rows_tiled, int32_t dtype, int64_t n, int32_t d, int32_t d_pad, const void* q, const void* q_host, void* q_stage,
+                           int32_t q_dtype, int32_t normalize, int32_t nq, int32_t k, const int64_t* ids, int64_t id_base, void* workspace,
+                           float* out_scores, int64_t* out_ids, int64_t* out_pos, hipStream_t stream) {
+    TinyArgs p;
+    TinyQArg qa;
+    const size_t qbytes = (size_t)nq * d * (q_dtype == VQA_F16 ? 2 : 4);
+    p.q_in_args = q_host && qbytes <= sizeof(qa);
+    if (p.q_in_args) {
+        memcpy(&qa, q_host, qbytes);
+    } else if (q_host) {
+        hipLaunchKernelGGL(stage_questions_kernel, dim3((unsigned)((qbytes + 4095) / 4096)), dim3(256), 0, stream, q, q_stage, (int)qbytes);
+        q = q_stage;
+    }
+    p.x = rows_tiled;
+    p.n = n;
+    p.KT = d_pad * (dtype == VQA_F16 ? 2 : 4) / 64;
+    p.d = d;
+    p.q = q;
+    p.q_is_f16 = q_dtype == VQA_F16;
+    p.normalize = normalize;
+    p.nq = nq;
+    p.k = k;
+    p.ids = reinterpret_cast<const long long*>(ids);
+    p.id_base = id_base;
+    p.partial = static_cast<vqa_key*>(workspace);
+    p.ticket = reinterpret_cast<unsigned*>(p.partial + (size_t)kTinyMaxUnits * kTinyQ * kTinyK);
+    p.out_scores = out_scores;
+    p.out_ids = reinterpret_cast<long long*>(out_ids);
+    p.out_pos = reinterpret_cast<long long*>(out_pos);
+    const bool small = n <= kTinySmallRows;
+    if (dtype == VQA_F16) {
+        // (64 rows as 2 waves x 32; more than 4 questions: twice the waves to share their normalisation and selection rounds)
+        if (small && nq <= 4) return launch<2, 2, VQA_F16>(p, qa, d_pad, stream);
+        return launch<4, 2, VQA_F16>(p, qa, d_pad, stream);
+    }
+    // fp32: four MFMAs per K-block of 16 elements at 1/16 of the fp16 rate per element -- 16 rows per wave keep a wave's matrix time at 2.6 us (768 columns)
+    if (small) return launch<4, 1, VQA_F32>(p, qa, d_pad, stream);
+    return launch<8, 1, VQA_F32>(p, qa, d_pad, stream);
 }

@@ -282,11 +282,11 @@ int vqa_launch_rescore(const unsigned long long* regions, const unsigned* counts
 // rows [first, first + count) of a tiled shard -> its row-major copy (rows of row_bytes = padded row length in bytes)
 int vqa_launch_rows_to_rowmajor(const void* tiled, int64_t first, int64_t count, int32_t row_bytes, void* out, hipStream_t stream);
 
-// K4 (tiny_search.hip): the whole search of a small fp16 shard for <= 16 questions and k <= 16 in ONE launch -- the latency form of
+// K4 (tiny_search.hip): the whole search of a small fp16 / fp32 shard for <= 16 questions and k <= 16 in ONE launch -- the latency form of
 // vqa_index_search_host.  `workspace`: vqa_tiny_search_workspace_bytes() of device memory, zeroed once; results go to out_* (device
 // pointers, here: the handle's mapped pinned buffer).  Same bits as the general path (tests/test_gpu_embeddings.py).
 bool vqa_tiny_search_applies(int32_t dtype, int64_t n, int32_t d_pad, int32_t B, int32_t k);
 size_t vqa_tiny_search_workspace_bytes();
-int vqa_launch_tiny_search(const void* rows_tiled, int64_t n, int32_t d, int32_t d_pad, const void* q, const void* q_host_or_null, void* q_stage, int32_t q_dtype,
-                           int32_t normalize, int32_t nq, int32_t k, const int64_t* ids, int64_t id_base, void* workspace, float* out_scores,
-                           int64_t* out_ids, int64_t* out_pos, hipStream_t stream);
+int vqa_launch_tiny_search(const void* rows_tiled, int32_t dtype, int64_t n, int32_t d, int32_t d_pad, const void* q, const void* q_host_or_null,
+                           void* q_stage, int32_t q_dtype, int32_t normalize, int32_t nq, int32_t k, const int64_t* ids, int64_t id_base,
+                           void* workspace, float* out_scores, int64_t* out_ids, int64_t* out_pos, hipStream_t stream);
