@@ -58,5 +58,27 @@ for b, l, reps in ((256, 32, 150), (256, 128, 40), (96, 48, 100), (40, 32, 100),
         print(f"encoder B={b} L={l} real_tokens={real}: {reps} repeats, {diff} differ", flush=True)
         bad += diff
 enc.close()
+
+# K4 (csrc/tiny_search.hip): per-workgroup lists -> ticket -> merge by the last arriver, ordered WITHOUT device-scope fences.  Two question
+# sets alternate call by call, so a list read before its writer's store landed would be the OTHER set's (a stale result, not a repeat
+# of the right one); every call must equal the general launches' answer for its set.
+rng = np.random.default_rng(11)
+for dtype, n, d, b, k, reps in (("fp16", 131072, 768, 1, 1, 3000), ("fp16", 131072, 768, 4, 16, 1500), ("fp16", 16384, 768, 4, 16, 2000),
+                                ("fp16", 5000, 768, 1, 10, 3000), ("fp32", 16385, 768, 16, 4, 1500), ("fp32", 100000, 256, 1, 10, 2000)):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    qs = [rng.standard_normal((b, d)).astype(np.float32) for _ in range(2)]
+    gen = DeviceIndex(x, dtype=dtype, options={"one_launch": 0})
+    want = [gen.search_host(q, k, normalize=True, return_positions=True) for q in qs]
+    gen.close()
+    one = DeviceIndex(x, dtype=dtype)
+    diff = 0
+    t0 = time.perf_counter()
+    for r in range(reps):
+        got = one.search_host(qs[r & 1], k, normalize=True, return_positions=True)
+        if not all(np.array_equal(u, v) for u, v in zip(got, want[r & 1])):
+            diff += 1
+    print(f"one-launch search {dtype} {n}x{d} B={b} k={k}: {reps} alternating calls, {diff} differ, {(time.perf_counter() - t0) / reps * 1e6:.1f} us each", flush=True)
+    bad += diff
+    one.close()
 print("TOTAL DIFFERING RUNS:", bad)
 sys.exit(1 if bad else 0)
