@@ -914,6 +914,19 @@ def reference_model_shapes(torch, np, device, dev_index, b, L=32):
         out[name] = {"questions_256x32": timed(ids, mask, lens)}
         ids2, mask2, lens2 = make_tokens(torch, device, g, cfg, 64, 128)
         out[name]["passages_64x128"] = timed(ids2, mask2, lens2)
+        # one 32-token question (heavy_ranker.py:98 asks one at a time): the latency form of the encoder, event time of the replayed graph
+        ids1, mask1 = ids[:1].clone(), torch.ones_like(mask[:1])
+        ids1[0, 1:L - 1] = torch.randint(3, cfg["vocab_size"], (L - 2,), generator=g, device=device, dtype=torch.int32)
+        ids1[0, L - 1] = 2
+        for _ in range(5):
+            enc.forward(ids1, mask1, pooling="mean", normalize=True, real_tokens=0)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(30)]
+        for e0, e1 in ev:
+            e0.record()
+            enc.forward(ids1, mask1, pooling="mean", normalize=True, real_tokens=0)
+            e1.record()
+        torch.cuda.synchronize(device)
+        out[name]["one_question_32_tokens_ms"] = round(float(np.median([e0.elapsed_time(e1) for e0, e1 in ev])), 4)
         enc.close()
         torch.cuda.empty_cache()
     return out

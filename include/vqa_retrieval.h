@@ -287,7 +287,7 @@ typedef struct vqa_encoder_options {
     int32_t first_rows;     /* [1] CLS pooling of a large batch: the last layer past its attention on the first-token rows only */
     int32_t graphs;         /* [1] calls of <= 1024 positions replay a captured hipGraph */
     int32_t latency_path;   /* [1] calls of <= 64 positions (one question: heavy_ranker.py:97-101) on models whose hidden and FFN sizes are
-                             * multiples of 768 run the latency form: five launches per layer, LayerNorms inside the GEMMs; 0: the general small-batch kernels */
+                             * multiples of 384 (the reference's two models: hidden 384 / 768) run the latency form: five launches per layer, LayerNorms inside the GEMMs; 0: the general small-batch kernels */
 } vqa_encoder_options;
 void vqa_encoder_options_init(vqa_encoder_options* opt);
 int vqa_encoder_create_ex(vqa_encoder** out, int device, const vqa_encoder_config* cfg, const vqa_encoder_weights* w, int32_t max_tokens,

@@ -1188,17 +1188,18 @@ struct TinyArgs {
     float inv_k = 0.f, eps = 0.f;
 };
 
-template <int EPI, int MT, int FOLDIN, int NBC>  // MT token tiles of 16; NBC K-blocks per chunk (all of a chunk's loads in flight together)
-__global__ __launch_bounds__(512) void gemm_tiny_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+template <int EPI, int MT, int FOLDIN, int NBC, int WV = 8>  // MT token tiles of 16; NBC K-blocks per chunk (all of a chunk's loads in flight together);
+                                                             // WV waves split K (8; 4 for K = 384, the MiniLM-L12 hidden size of heavy_ranker.py:80)
+__global__ __launch_bounds__(64 * WV) void gemm_tiny_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
                                                         const float* __restrict__ bias, const _Float16* __restrict__ R,
                                                         _Float16* __restrict__ C, int M, int N, int K, TinyArgs ta) {
-    __shared__ f32x4 red[7][MT][64];
-    __shared__ float2 sred[8][MT][16];
+    __shared__ f32x4 red[WV - 1][MT][64];
+    __shared__ float2 sred[WV][MT][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int m0 = blockIdx.y * (16 * MT);  // gridDim.y > 1: the token tiles are spread over workgroups (FFN2: 48 feature slices alone leave 208 CUs idle)
-    const int kq = K >> 3;  // this wave's K range [wave kq, +kq): a multiple of 32 NBC
+    const int kq = K / WV;  // this wave's K range [wave kq, +kq): a multiple of 32 NBC
     const int kbase = wave * kq;
     const _Float16* wp = W + (size_t)(n0 + c) * K + kbase + 8 * g;
     const _Float16* ap[MT];
@@ -1288,7 +1289,7 @@ __global__ __launch_bounds__(512) void gemm_tiny_kernel(const _Float16* __restri
     for (int mi = 0; mi < MT; ++mi) {
         total[mi] = acc[mi];
 #pragma unroll
-        for (int w = 0; w < 7; ++w) total[mi] += red[w][mi][lane];  // fixed order: deterministic
+        for (int w = 0; w < WV - 1; ++w) total[mi] += red[w][mi][lane];  // fixed order: deterministic
     }
     // total[mi][j] = C[token 16 mi + c][feature n0 + 4 g + j]
 #pragma unroll
@@ -1299,7 +1300,7 @@ __global__ __launch_bounds__(512) void gemm_tiny_kernel(const _Float16* __restri
         if constexpr (FOLDIN) {
             float a1 = 0.f, a2 = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) {
+            for (int w = 0; w < WV; ++w) {
                 a1 += sred[w][mi][c].x;
                 a2 += sred[w][mi][c].y;
             }
@@ -1959,35 +1960,40 @@ int launch_gemm(const _Float16* A, const _Float16* W, const float* bias, const _
     return VQA_OK;
 }
 
-// the latency form's shapes: M <= 64 rows, K a multiple of 768 (K / 256 blocks per wave in chunks of 3, 6 or 12), N a multiple of 16
+// the latency form's shapes: M <= 64 rows, N a multiple of 16, K a multiple of 768 (eight waves, K / 256 blocks each in chunks of 3, 6 or
+// 12) or of 384 (four waves, K / 128 blocks each in chunks of 3: hidden size 384, paraphrase-multilingual-MiniLM-L12-v2)
 constexpr int kTinyMaxM = 64;
-static bool tiny_shape(int M, int N, int K) { return M >= 1 && M <= kTinyMaxM && N % 16 == 0 && K % 768 == 0; }
+static bool tiny_shape(int M, int N, int K) { return M >= 1 && M <= kTinyMaxM && N % 16 == 0 && K % 384 == 0; }
 
 template <int EPI, int FOLDIN>
 int launch_gemm_tiny(const _Float16* A, const _Float16* W, const float* bias, const _Float16* R, _Float16* C, int M, int N, int K,
                      const TinyArgs& ta, hipStream_t s) {
-    // a GEMM of few feature slices and a long K (FFN2: 48 slices x K = 3072) spreads its token tiles over workgroups: every workgroup then
-    // pulls one tile's rows of A (98 KB instead of 196) beside its 98 KB of weights (the weights are re-read from the L2)
-    const int my = (!FOLDIN && N / 16 < 96 && K >= 3072) ? (M + 15) / 16 : 1;
-    const int mt = my > 1 ? 1 : (M + 15) / 16, nbw = K / 256;
+    // a GEMM of few feature slices and a long K (FFN2: 48 slices x K = 3072; 24 x 1536) spreads its token tiles over workgroups: every
+    // workgroup then pulls one tile's rows of A (98 KB instead of 196) beside its 98 KB of weights (the weights are re-read from the L2)
+    const int my = (!FOLDIN && N / 16 < 96 && K >= 1536 && K >= 4 * N) ? (M + 15) / 16 : 1;
+    const int mt = my > 1 ? 1 : (M + 15) / 16;
+    const bool four = K % 768 != 0;
+    const int nbw = four ? K / 128 : K / 256;
     // all of a wave's loads at once when they fit its registers (NBC (1 + MT) fragments of 4 registers), else in two or more chunks
-    const int nbc = (nbw % 12 == 0 && mt <= 2) ? 12 : (nbw % 6 == 0 && mt <= 4) ? 6 : 3;
-#define VQA_TINY(MT, NBC)                                                                                                       \
-    hipLaunchKernelGGL((gemm_tiny_kernel<EPI, MT, FOLDIN, NBC>), dim3(N / 16, my), dim3(512), 0, s, A, W, bias, R, C, M, N, K, ta)
-#define VQA_TINY_MT(NBC)                                   \
-    switch (mt) {                                          \
-        case 1: VQA_TINY(1, NBC); break;                   \
-        case 2: VQA_TINY(2, NBC); break;                   \
-        case 3: VQA_TINY(3, NBC); break;                   \
-        default: VQA_TINY(4, NBC); break;                  \
+    const int nbc = four ? 3 : (nbw % 12 == 0 && mt <= 2) ? 12 : (nbw % 6 == 0 && mt <= 4) ? 6 : 3;
+#define VQA_TINY(MT, NBC, WV)                                                                                                          \
+    hipLaunchKernelGGL((gemm_tiny_kernel<EPI, MT, FOLDIN, NBC, WV>), dim3(N / 16, my), dim3(64 * WV), 0, s, A, W, bias, R, C, M, N, K, ta)
+#define VQA_TINY_MT(NBC, WV)                                   \
+    switch (mt) {                                              \
+        case 1: VQA_TINY(1, NBC, WV); break;                   \
+        case 2: VQA_TINY(2, NBC, WV); break;                   \
+        case 3: VQA_TINY(3, NBC, WV); break;                   \
+        default: VQA_TINY(4, NBC, WV); break;                  \
     }
-    if (nbc == 12) {
-        if (mt == 1) VQA_TINY(1, 12);
-        else VQA_TINY(2, 12);
+    if (four) {
+        VQA_TINY_MT(3, 4)
+    } else if (nbc == 12) {
+        if (mt == 1) VQA_TINY(1, 12, 8);
+        else VQA_TINY(2, 12, 8);
     } else if (nbc == 6) {
-        VQA_TINY_MT(6)
+        VQA_TINY_MT(6, 8)
     } else {
-        VQA_TINY_MT(3)
+        VQA_TINY_MT(3, 8)
     }
 #undef VQA_TINY
 #undef VQA_TINY_MT
@@ -2250,12 +2256,17 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
     }
     // LayerNorms folded into the GEMMs (FoldArgs): every GEMM of the layer must take the LDS-DMA tile kernel and the two that
     // produce statistics must fit their slices into the 16 slots of a row
-    const int p_out = e->fold_on ? tile_stat_slots(T, H, H) : 0, p_ffn = e->fold_on ? tile_stat_slots(T, H, F) : 0;
-    const bool fold = e->fold_on && p_out >= 4 && p_out <= kRowStatSlots && p_out % 4 == 0 && p_ffn >= 4 && p_ffn <= kRowStatSlots &&
-                      p_ffn % 4 == 0 && tile_stat_slots(T, 3 * H, H) > 0 && tile_stat_slots(T, F, H) > 0;
+    // (a reader's lane adds up FOUR slots: a slice count that is no multiple of 4 -- hidden size 384: 6 slices of 64 -- is rounded up and the
+    // slots in between are zeroed once per forward, below)
+    const int w_out = e->fold_on ? tile_stat_slots(T, H, H) : 0, w_ffn = e->fold_on ? tile_stat_slots(T, H, F) : 0;  // slots written
+    const int p_out = (w_out + 3) & ~3, p_ffn = (w_ffn + 3) & ~3;                                                      // slots read
+    const bool fold = e->fold_on && w_out >= 1 && p_out <= kRowStatSlots && w_ffn >= 1 && p_ffn <= kRowStatSlots &&
+                      tile_stat_slots(T, 3 * H, H) > 0 && tile_stat_slots(T, F, H) > 0;
     const int st_stride = (e->max_tokens + kTokenPad - 1) / kTokenPad * kTokenPad;  // rows per statistics slot (the padded row count)
-    // one question (<= 64 positions, hidden / FFN sizes in multiples of 768): the latency form -- raw rows all the way, LayerNorms inside
+    // one question (<= 64 positions, hidden / FFN sizes in multiples of 384): the latency form -- raw rows all the way, LayerNorms inside
     // the GEMMs (gemm_tiny_kernel), five launches per layer
+    if (fold && p_out != w_out)  // (st_tmp is written by the out-projections only)
+        VQA_HIP_CHECK(hipMemsetAsync(e->st_tmp + (size_t)w_out * st_stride, 0, (size_t)(p_out - w_out) * st_stride * sizeof(float2), s));
     const bool tiny = e->tiny_on && e->fold_on && !packed && tiny_shape(T, 3 * H, H) && tiny_shape(T, F, H) && tiny_shape(T, H, F) &&
                       att_mfma_head_size(dh) && L <= 32 * kAttMaxBlocks;
     hipLaunchKernelGGL(embed_ln_kernel, dim3(row_blocks), dim3(256), 0, s, input_ids, T, L, H, e->cfg.pad_id, e->cfg.vocab_size,
@@ -2379,6 +2390,8 @@ static int encoder_launch(vqa_encoder* e, const int32_t* input_ids, const int32_
             if ((rc = launch_gemm_fold<1>(e->tmp, Ly.w1_f, Ly.b1_f, nullptr, e->ffn, T, F, H,
                                           FoldArgs{e->st_tmp, p_out, st_stride, inv_h, eps, Ly.c1, nullptr, nullptr, nullptr}, s)) != VQA_OK)
                 return rc;
+            if (p_ffn != w_ffn && &Ly == &e->layers.front())  // (behind the last reader of the embedding's four slots, in front of FFN2's first write)
+                VQA_HIP_CHECK(hipMemsetAsync(e->st_x + (size_t)w_ffn * st_stride, 0, (size_t)(p_ffn - w_ffn) * st_stride * sizeof(float2), s));
             if ((rc = launch_gemm_fold<2>(e->ffn, Ly.w2, Ly.b2, e->tmp, e->x, T, H, F,
                                           FoldArgs{e->st_tmp, p_out, st_stride, inv_h, eps, nullptr, Ly.ln1_g, Ly.ln1_b, e->st_x}, s)) != VQA_OK)
                 return rc;
