@@ -291,6 +291,12 @@ def test_one_launch_search_returns_the_general_paths_bits(native_lib, n, d, with
     if n >= 10:
         stored, code = (x.astype(np.float16), R.DTYPE_F16) if dtype == "fp16" else (x, R.DTYPE_F32)
         R.check_topk(a[0], a[2], R.full_scores(q16[:9].astype(np.float32), stored, code), 10, score_tol=1e-5, tie_tol=2e-6)
+    # device-resident questions (the encoder's output): fp32 normalised by the call, and an fp16 slice whose address is no multiple of 16
+    qd, qd16 = torch.from_numpy(q).cuda(), torch.from_numpy(q16).cuda()
+    for dev_q, host_q, norm in ((qd[:5], q[:5], True), (qd16[1:4], q16[1:4], False), (qd[2:3], q[2:3], False)):
+        a, g = one.search_host(dev_q, 7, normalize=norm, return_positions=True), gen.search_host(host_q, 7, normalize=norm, return_positions=True)
+        for u, v in zip(a, g):
+            assert np.array_equal(u, v)
     first = one.search_host(q[:3], 4, normalize=True, return_positions=True)
     for _ in range(50):
         again = one.search_host(q[:3], 4, normalize=True, return_positions=True)
