@@ -882,7 +882,50 @@ def latency_legs(torch, np, device, dev_index, d):
                                                               "top1_equals_oracle_on_the_encoded_vector": bool(hit and hit[0][0] == int(ref_ids[0, 0]))}
         emb._index.close()
         enc.close()
+        out["one_question_through_both_reference_models_ms"] = both_reference_models(torch, np, device, dev_index)
     return out
+
+
+def both_reference_models(torch, np, device, dev_index, L=32):
+    """The reference's loop body (heavy_ranker.py:98-101): ONE question through its two retrievers -- paraphrase-multilingual-MiniLM-L12-v2
+    (d = 384) and paraphrase-multilingual-mpnet-base-v2 (XLM-R base, d = 768) by their shapes, random weights, a stand-in tokenizer
+    (32 tokens), 5000 documents each, limit 1; wall clock with Python: the two `search(question, 1)` calls one after the other, and
+    `heavy_ranker.rank_query` (the two forwards on a stream each)."""
+    from vietnamese_qa_system_amd import heavy_ranker
+    from vietnamese_qa_system_amd.embeddings import Embeddings
+    from vietnamese_qa_system_amd.encoder import MINILM_L12, XLMR_BASE, TextEncoder
+    rng = np.random.default_rng(5)
+    embs, encs = [], []
+    for cfg in (MINILM_L12, XLMR_BASE):
+        enc, ids, mask, _, _ = make_encoder(torch, device, dev_index, 1, L, max_tokens=2 * L, cfg=cfg)
+        ids_h = ids.cpu().numpy()
+        ids_h[0, 1:L - 1] = rng.integers(3, cfg["vocab_size"], L - 2)
+        ids_h[0, L - 1] = 2
+        mask_h = np.ones_like(ids_h)
+        te = TextEncoder(lambda texts, i=ids_h, m=mask_h: (np.repeat(i, len(texts), 0), np.repeat(m, len(texts), 0)), enc, pooling="mean")
+        emb = Embeddings(dtype="fp16", device=dev_index, encoder=te)
+        emb.index_vectors(list(range(1, 5001)), rng.standard_normal((5000, cfg["hidden"])).astype(np.float32))
+        embs.append(emb)
+        encs.append(enc)
+    a, b = embs
+    res = {}
+    same = heavy_ranker.rank_query(a, b, "cau hoi", 1) == (a.search("cau hoi", 1), b.search("cau hoi", 1))
+    for name, fn in (("two_searches_in_turn", lambda: (a.search("cau hoi", 1), b.search("cau hoi", 1))),
+                     ("rank_query_two_streams", lambda: heavy_ranker.rank_query(a, b, "cau hoi", 1))):
+        for _ in range(10):
+            fn()
+        ts = []
+        for _ in range(60):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        res[name] = round(float(np.median(ts)) * 1e3, 4)
+    res["same_results"] = bool(same)
+    for emb, enc in zip(embs, encs):
+        emb._index.close()
+        enc.close()
+    torch.cuda.empty_cache()
+    return res
 
 
 def reference_model_shapes(torch, np, device, dev_index, b, L=32):

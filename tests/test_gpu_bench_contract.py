@@ -45,6 +45,9 @@ def test_bench_prints_one_json_line_with_the_contract_keys(native_lib):
     assert lat["encoder_one_question_32_tokens_ms"]["event_median"] > 0
     text = lat["search_one_text_question_limit1_5000_docs_ms"]
     assert text["top1_equals_oracle_on_the_encoded_vector"] and 0 < text["median"] < 5.0
+    both = lat["one_question_through_both_reference_models_ms"]
+    assert both["same_results"] and 0 < both["rank_query_two_streams"] < 5.0 and 0 < both["two_searches_in_turn"] < 5.0
+    assert all(v["one_question_32_tokens_ms"] > 0 for v in oc["reference_model_shapes"].values())
     assert set(lat["300000_rows_fp16"]) == {"batch1_step_ms", "batch257_step_ms"}
     sm = r["step_ms"]
     assert sm["p10"] <= sm["median"] <= sm["p90"]

@@ -375,3 +375,46 @@ def test_text_questions_take_two_library_calls_and_return_the_general_paths_resu
         bad[0, 1] = 5000
         enc.forward_host(bad, mask[:1], torch.empty((1, 768), dtype=torch.float32, device="cuda"))
     enc.close()
+
+
+def test_rank_query_runs_the_two_retrievers_side_by_side_and_returns_what_two_searches_return(native_lib):
+    """heavy_ranker.py:98-101 asks its two retrievers the same question one after the other.  `heavy_ranker.rank_query` enqueues the
+    two encoder forwards on a stream each (`Embeddings.search_begin`), then completes the two searches (`search_end`): the results are
+    those of two `search(question, limit)` calls -- two different models (hidden 768 / 384), content on and off; a retriever whose
+    encoder is a plain callable takes the ordinary path inside `search_end`."""
+    from oracle import encoder as E
+    from vietnamese_qa_system_amd import Embeddings, heavy_ranker
+    from vietnamese_qa_system_amd.encoder import QuestionEncoder, TextEncoder
+    rng = np.random.default_rng(2)
+    embs, encs = [], []
+    for j, base in enumerate((E.PHOBERT_BASE, E.MINILM_L12)):
+        cfg = dict(base, layers=2, vocab_size=5000)
+        w = E.synthetic_weights(cfg, seed=30 + j, layers=2)
+        ids, mask = E.synthetic_tokens(cfg, 12, 20, seed=5)
+        table = {f"q{i}": (ids[i], mask[i]) for i in range(12)}
+        enc = QuestionEncoder(w, cfg, max_tokens=64)
+        te = TextEncoder(lambda texts, table=table: (np.stack([table[t][0] for t in texts]), np.stack([table[t][1] for t in texts])), enc, pooling="mean")
+        emb = Embeddings(encoder=te, min_score=None, content=bool(j))
+        docs = rng.standard_normal((3000, cfg["hidden"])).astype(np.float32)
+        if j:
+            emb.index([{"id": i + 1, "text": f"q{i % 12}"} for i in range(24)])  # (content=True: through the text route; a small corpus the stand-in tokenizer knows)
+        else:
+            emb.index_vectors(list(range(1, 3001)), docs)
+        embs.append(emb)
+        encs.append(enc)
+    a, b = embs
+    for i in range(12):
+        for limit in (1, 3):
+            want = (a.search(f"q{i}", limit), b.search(f"q{i}", limit))
+            assert heavy_ranker.rank_query(a, b, f"q{i}", limit) == want
+    tok = a.search_begin("q3")
+    assert tok[1] is not None and a.search_end(tok, 2) == a.search("q3", 2)
+    plain = Embeddings(encoder=lambda texts: torch.ones((len(texts), 768), device="cuda"), min_score=None)
+    plain.index_vectors(list(range(1, 101)), rng.standard_normal((100, 768)).astype(np.float32))
+    tok = plain.search_begin("anything")
+    assert tok[1] is None and plain.search_end(tok, 1) == plain.search("anything", 1)
+    assert heavy_ranker.rank_query(a, plain, "q1", 1) == (a.search("q1", 1), plain.search("q1", 1))
+    with pytest.raises(ValueError):
+        a.search_begin(np.zeros(768, np.float32))
+    for enc in encs:
+        enc.close()

@@ -356,23 +356,51 @@ class Embeddings:
         enc = self.encoder
         return isinstance(enc, TextEncoder) and isinstance(enc.encoder, QuestionEncoder) and enc.encoder.device == self.device
 
-    def _search_texts_fast(self, texts: List[str], limit: int) -> List[list]:
+    def _encode_texts_fast(self, texts: List[str]):
+        """The first of the fast path's two library calls: tokenizer, then the encoder's host entry ENQUEUED on the current stream (no
+        wait).  Returns the device vectors, or None for a question longer than the encoder's workspace (the general path slices it)."""
         te = self.encoder
         ids, mask = te.tokenizer(texts)
         ids = ids.cpu().numpy() if isinstance(ids, torch.Tensor) else np.asarray(ids)
         mask = mask.cpu().numpy() if isinstance(mask, torch.Tensor) else np.asarray(mask)
         if ids.ndim != 2:
             raise ValueError("the tokenizer must return [B, L] input_ids")
-        if ids.size > te.encoder.max_tokens:  # (a long question: the general path slices it)
-            return self.batchsearch(self._encode(texts), limit)
+        if ids.size > te.encoder.max_tokens:
+            return None
         h = int(te.encoder.config["hidden"])
         if h != self.d:
             raise ValueError(f"query dimension {h} != index dimension {self.d}")
         if self._qbuf is None or self._qbuf.shape[1] != h:
             self._qbuf = torch.empty((HOST_PATH_MAX_QUERIES, h), dtype=torch.float32, device=torch.device("cuda", self.device))
-        q = te.encoder.forward_host(ids, mask, self._qbuf, pooling=te.pooling, normalize=te.normalize)
+        return te.encoder.forward_host(ids, mask, self._qbuf, pooling=te.pooling, normalize=te.normalize)
+
+    def _search_texts_fast(self, texts: List[str], limit: int) -> List[list]:
+        q = self._encode_texts_fast(texts)
+        if q is None:
+            return self.batchsearch(self._encode(texts), limit)
         scores, out_ids = self._index.search_host(q, limit, normalize=self.normalize)
         return self._format(scores, out_ids)
+
+    def search_begin(self, query: str):
+        """First half of ``search(query, limit)`` for a caller that asks SEVERAL retrievers the same question (``heavy_ranker.py:98-100``
+        asks two, one after the other): the question's encoder forward is enqueued on the current stream and the call returns at once,
+        so the forwards of two models -- each far too small to fill the device -- run side by side when the caller gives every
+        retriever a stream of its own (``heavy_ranker.rank_query``).  ``search_end`` completes the call.  Not part of txtai."""
+        if self._index is None:
+            raise RuntimeError("the index is empty: call index()/load() first")
+        if not isinstance(query, str):
+            raise ValueError("search_begin() takes one text question")
+        q = self._encode_texts_fast([query]) if self._text_fast_path([query]) else None
+        return (query, q)
+
+    def search_end(self, token, limit: int = 3) -> list:
+        """Second half: the search of the vector ``search_begin`` left on the device (waits for it), or the whole ``search`` when the
+        question did not take the fast path."""
+        query, q = token
+        if q is None:
+            return self.search(query, limit)
+        scores, out_ids = self._index.search_host(q, int(limit), normalize=self.normalize)
+        return self._format(scores, out_ids)[0]
 
     def _hybrid(self, q: torch.Tensor, texts: List[str], limit: int) -> List[list]:
         """txtai's hybrid search [recalled, see sparse.py]: 10 x limit candidates from each half, per-id convex combination
