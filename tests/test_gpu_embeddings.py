@@ -394,7 +394,7 @@ def test_rank_query_runs_the_two_retrievers_side_by_side_and_returns_what_two_se
         table = {f"q{i}": (ids[i], mask[i]) for i in range(12)}
         enc = QuestionEncoder(w, cfg, max_tokens=64)
         te = TextEncoder(lambda texts, table=table: (np.stack([table[t][0] for t in texts]), np.stack([table[t][1] for t in texts])), enc, pooling="mean")
-        emb = Embeddings(encoder=te, min_score=None, content=bool(j))
+        emb = Embeddings(encoder=te, min_score=None, content=bool(j), hybrid=bool(j))  # (the second one as heavy_ranker.py:78 builds it)
         docs = rng.standard_normal((3000, cfg["hidden"])).astype(np.float32)
         if j:
             emb.index([{"id": i + 1, "text": f"q{i % 12}"} for i in range(24)])  # (content=True: through the text route; a small corpus the stand-in tokenizer knows)
@@ -407,6 +407,10 @@ def test_rank_query_runs_the_two_retrievers_side_by_side_and_returns_what_two_se
         for limit in (1, 3):
             want = (a.search(f"q{i}", limit), b.search(f"q{i}", limit))
             assert heavy_ranker.rank_query(a, b, f"q{i}", limit) == want
+    # hybrid=True with the encoder built here: the dense half takes the two library calls as well; same results as the torch route
+    for i in (0, 4, 9):
+        for limit in (1, 3):
+            assert b.search(f"q{i}", limit) == b._hybrid(b._query_vectors([f"q{i}"]), [f"q{i}"], limit)[0]
     tok = a.search_begin("q3")
     assert tok[1] is not None and a.search_end(tok, 2) == a.search("q3", 2)
     plain = Embeddings(encoder=lambda texts: torch.ones((len(texts), 768), device="cuda"), min_score=None)

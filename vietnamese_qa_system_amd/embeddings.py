@@ -335,6 +335,10 @@ class Embeddings:
         # the forward (host ids in, device vectors out) -> ONE for the search (device vectors in, host results out)
         if self._text_fast_path(queries):
             return self._search_texts_fast(list(queries), limit)
+        if self._text_fast_path(queries, hybrid_ok=True):  # hybrid=True (heavy_ranker.py:78): the same two library calls for the dense half
+            qd = self._encode_texts_fast(list(queries))
+            if qd is not None:
+                return self._hybrid(qd, list(queries), limit, host_results=True)
         q = self._query_vectors(queries)
         if q.shape[1] != self.d:
             raise ValueError(f"query dimension {q.shape[1]} != index dimension {self.d}")
@@ -345,11 +349,13 @@ class Embeddings:
         torch.cuda.current_stream(q.device).synchronize()
         return self._format(scores.cpu().numpy(), ids.cpu().numpy())
 
-    def _text_fast_path(self, queries) -> bool:
+    def _text_fast_path(self, queries, hybrid_ok: bool = False) -> bool:
         from .encoder import QuestionEncoder, TextEncoder
         if isinstance(queries, (np.ndarray, torch.Tensor)) or not len(queries) or not isinstance(queries[0], str):
             return False
-        if len(queries) > HOST_PATH_MAX_QUERIES or self._searcher.collective or (self.hybrid and self._sparse is not None and 0.0 < self.weights < 1.0):
+        if len(queries) > HOST_PATH_MAX_QUERIES or self._searcher.collective:
+            return False
+        if not hybrid_ok and self.hybrid and self._sparse is not None and 0.0 < self.weights < 1.0:
             return False
         if self.encoder is None and self.path and os.path.isdir(str(self.path)):
             self.encoder = self._encoder_from_path()
@@ -390,7 +396,7 @@ class Embeddings:
             raise RuntimeError("the index is empty: call index()/load() first")
         if not isinstance(query, str):
             raise ValueError("search_begin() takes one text question")
-        q = self._encode_texts_fast([query]) if self._text_fast_path([query]) else None
+        q = self._encode_texts_fast([query]) if self._text_fast_path([query], hybrid_ok=True) else None
         return (query, q)
 
     def search_end(self, token, limit: int = 3) -> list:
@@ -399,16 +405,22 @@ class Embeddings:
         query, q = token
         if q is None:
             return self.search(query, limit)
+        if not self._text_fast_path([query]):  # hybrid=True: the dense candidates from q, the BM25 half on the host
+            return self._hybrid(q, [query], int(limit), host_results=True)[0]
         scores, out_ids = self._index.search_host(q, int(limit), normalize=self.normalize)
         return self._format(scores, out_ids)[0]
 
-    def _hybrid(self, q: torch.Tensor, texts: List[str], limit: int) -> List[list]:
+    def _hybrid(self, q: torch.Tensor, texts: List[str], limit: int, host_results: bool = False) -> List[list]:
         """txtai's hybrid search [recalled, see sparse.py]: 10 x limit candidates from each half, per-id convex combination
-        ``weights * dense + (1 - weights) * bm25`` (BM25 normalised to 0..1), best ``limit``."""
+        ``weights * dense + (1 - weights) * bm25`` (BM25 normalised to 0..1), best ``limit``.  ``host_results``: ``q`` is the device output
+        of the encoder's host entry and the dense candidates come through the index's host-result entry (one question: one kernel)."""
         cand = min(10 * limit, 1024, max(self.n, 1))
-        scores, ids = self._searcher.search(q, cand)
-        torch.cuda.current_stream(q.device).synchronize()
-        ds, di = scores.cpu().numpy(), ids.cpu().numpy()
+        if host_results:
+            ds, di = self._index.search_host(q, cand, normalize=self.normalize)
+        else:
+            scores, ids = self._searcher.search(q, cand)
+            torch.cuda.current_stream(q.device).synchronize()
+            ds, di = scores.cpu().numpy(), ids.cpu().numpy()
         out_s = np.full((len(texts), limit), -np.inf, dtype=np.float32)
         out_i = np.full((len(texts), limit), -1, dtype=np.int64)
         for b, text in enumerate(texts):
