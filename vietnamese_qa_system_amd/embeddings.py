@@ -415,7 +415,10 @@ class Embeddings:
         ``weights * dense + (1 - weights) * bm25`` (BM25 normalised to 0..1), best ``limit``.  ``host_results``: ``q`` is the device output
         of the encoder's host entry and the dense candidates come through the index's host-result entry (one question: one kernel)."""
         cand = min(10 * limit, 1024, max(self.n, 1))
+        sparse_all = None
         if host_results:
+            # the encoder forward that produces q is still running on the device: the BM25 half is computed under it, the wait comes after
+            sparse_all = [[(int(self._row_ids[r]), s) for r, s in self._sparse.search(text, cand)] for text in texts]
             ds, di = self._index.search_host(q, cand, normalize=self.normalize)
         else:
             scores, ids = self._searcher.search(q, cand)
@@ -425,7 +428,7 @@ class Embeddings:
         out_i = np.full((len(texts), limit), -1, dtype=np.int64)
         for b, text in enumerate(texts):
             dense = [(int(i), float(s)) for i, s in zip(di[b], ds[b]) if i >= 0 and s > 0]  # txtai drops dense scores <= 0
-            sparse = [(int(self._row_ids[r]), s) for r, s in self._sparse.search(text, cand)]
+            sparse = sparse_all[b] if sparse_all is not None else [(int(self._row_ids[r]), s) for r, s in self._sparse.search(text, cand)]
             for j, (uid, sc) in enumerate(combine(dense, sparse, limit, self.weights, self._sparse.normalize)):
                 out_i[b, j], out_s[b, j] = uid, sc
         return self._format(out_s, out_i)
