@@ -1,4 +1,4 @@
-"""Differential fuzz of the one-launch search (csrc/tiny_search.hip) against the general launches: random shard sizes (1 ... 131 072 rows,
+"""Differential fuzz of the one-launch search (csrc/tiny_search.hip) against the general launches: random shard sizes (1 ... 262 144 rows,
 clustered around the workgroup and tile edges), row lengths (any d, not only multiples of 8), storage types, id vectors, question counts
 and k inside its limits, raw / normalised fp32 and fp16 questions, host and device resident, duplicated rows.  Every case must return
 the general path's scores, ids and positions bit for bit.  GPU box:  python scripts/fuzz_one_launch.py [cases] [seed]"""
@@ -10,11 +10,11 @@ from vietnamese_qa_system_amd.index import DeviceIndex
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 edges = [1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1000, 4095, 4096, 5000, 16383, 16384, 16385, 16447, 16448, 16449,
-         50000, 65535, 65536, 131071, 131072]
+         50000, 65535, 65536, 131071, 131072, 131073, 200000, 262143, 262144]
 bad = 0
 t0 = time.time()
 for c in range(cases):
-    n = int(rng.choice(edges)) if rng.random() < 0.6 else int(rng.integers(1, 131073))
+    n = int(rng.choice(edges)) if rng.random() < 0.6 else int(rng.integers(1, 262145))
     d = int(rng.choice([8, 24, 64, 100, 128, 200, 384, 768, 1024])) if rng.random() < 0.7 else int(rng.integers(1, 400))
     if n * d > 60_000_000:
         d = max(1, 60_000_000 // n)

@@ -253,9 +253,9 @@ def test_host_latency_path_returns_the_batch_paths_bits(native_lib, dtype, n, op
 
 @pytest.mark.parametrize("dtype", ["fp16", "fp32"])
 @pytest.mark.parametrize("n,d,with_ids", [(1, 768, False), (63, 64, True), (257, 100, False), (5000, 768, True), (16384, 768, False),
-                                          (16385, 256, True), (40000, 768, False), (131072, 128, False)])
+                                          (16385, 256, True), (40000, 768, False), (131072, 128, False), (131073, 64, True), (262144, 96, False)])
 def test_one_launch_search_returns_the_general_paths_bits(native_lib, n, d, with_ids, dtype):
-    """K4 (csrc/tiny_search.hip): on an fp16 or fp32 shard of <= 131 072 rows, vqa_index_search_host with <= 16 questions, k <= 16 and questions x k <= 64 is ONE
+    """K4 (csrc/tiny_search.hip): on an fp16 or fp32 shard of <= 262 144 rows, vqa_index_search_host with <= 16 questions, k <= 16 and questions x k <= 64 is ONE
     kernel -- normalise, score, select, merge.  Same scores / ids / positions, bit for bit, as the general launches on a handle with
     options.one_launch = 0, for raw fp32 questions (normalised by the call or not) and fp16 questions; rows stored twice tie and come
     back in position order; fewer rows than k: padding; 50 calls in a row (the ticket returns to zero) agree; and == the oracle."""

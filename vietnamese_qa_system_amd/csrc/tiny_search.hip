@@ -4,7 +4,7 @@
 // (inference_pipeline/db_utils/heavy_ranker.py:97-101).  At that size the general search
 // (normalise -> query staging -> seed scan -> threshold merge -> main scan -> list merge: six dependent launches, capi.hip) is all
 // launch latency: 0.05 ms of device time for a few MB of rows.  This kernel does the whole call in one launch.  Every workgroup
-// (W waves of RG row groups of 16: 64 rows of a shard of up to 16 384 rows, else 128)
+// (W waves of RG row groups of 16: 64 rows of a shard of up to 16 384 rows, 128 up to 131 072, else 256)
 //   (1) L2-normalises the raw fp32 questions and converts them to the storage type -- the arithmetic of normalize_convert_kernel
 //       followed by the staging conversion (convert.hip), bit for bit --,
 //   (2) scores its rows against them on the exact scan's MFMA (fp16: one v_mfma_f32_16x16x32_f16 per K-block; fp32: four
@@ -15,7 +15,7 @@
 //   (3) keeps its k best (score, position) keys per question (k rounds of a wave maximum),
 //   (4) publishes them and takes a ticket; the LAST workgroup to arrive merges all lists and writes scores, external ids and
 //       positions -- straight into the caller's pinned memory.
-// Limits (vqa_tiny_search_applies): fp16 / fp32 storage, <= 16 questions, k <= 16, questions x k <= 64, <= 131 072 rows.
+// Limits (vqa_tiny_search_applies): fp16 / fp32 storage, <= 16 questions, k <= 16, questions x k <= 64, <= 262 144 rows.
 #include <string.h>
 
 #include <type_traits>
@@ -34,7 +34,8 @@ constexpr int kTinyMaxResults = 64;  // questions x results per call
 constexpr int kTinyChunk = 12;  // K-blocks whose fragments a wave keeps in flight together (fp16, RG = 2: 96 registers; all 24 of a 768-element row at once: measured equal)
 constexpr int kTinyMaxUnits = 1024;
 constexpr int kTinyArgBytes = 3584;  // of questions inside the launch packet (4 KB of kernel arguments at most)
-constexpr int kTinyMaxRows = 131072;
+constexpr int kTinyMaxRows = 262144;
+constexpr int kTinyMidRows = 131072;   // up to here: workgroups of 128 rows; beyond: 256 (the list merge takes <= 1024 workgroups)
 constexpr int kTinySmallRows = 16384;  // up to here: workgroups of 64 rows (a 5000-row shard on 79 CUs instead of 40)
 
 // the k largest of the keys a wave holds (PER per lane; real keys are distinct, 0 = empty), largest first
@@ -298,7 +299,7 @@ bool vqa_tiny_search_applies(int32_t dtype, int64_t n, int32_t d_pad, int32_t B,
     // (B k <= 64: every selection round is a wave-wide maximum, a question's rounds run in ONE wave, and past that the general path's
     // block-wide selections are level or ahead -- 16 questions x 16 results: 122-194 us here, 120-170 us there)
     return (dtype == VQA_F16 || dtype == VQA_F32) && n >= 1 && n <= kTinyMaxRows && B >= 1 && B <= kTinyQ && k >= 1 && k <= kTinyK &&
-           B * k <= kTinyMaxResults && lds_bytes(d_pad * (dtype == VQA_F16 ? 2 : 4), d_pad, 128, kTinyQ) <= kTinyLdsMax;
+           B * k <= kTinyMaxResults && lds_bytes(d_pad * (dtype == VQA_F16 ? 2 : 4), d_pad, 256, kTinyQ) <= kTinyLdsMax;
 }
 
 size_t vqa_tiny_search_workspace_bytes() { return (size_t)kTinyMaxUnits * kTinyQ * kTinyK * sizeof(vqa_key) + 64; }
@@ -339,9 +340,11 @@ int vqa_launch_tiny_search(const void* rows_tiled, int32_t dtype, int64_t n, int
     if (dtype == VQA_F16) {
         // (64 rows as 2 waves x 32; more than 4 questions: twice the waves to share their normalisation and selection rounds)
         if (small && nq <= 4) return launch<2, 2, VQA_F16>(p, qa, d_pad, stream);
-        return launch<4, 2, VQA_F16>(p, qa, d_pad, stream);
+        if (n <= kTinyMidRows) return launch<4, 2, VQA_F16>(p, qa, d_pad, stream);
+        return launch<8, 2, VQA_F16>(p, qa, d_pad, stream);
     }
     // fp32: four MFMAs per K-block of 16 elements at 1/16 of the fp16 rate per element -- 16 rows per wave keep a wave's matrix time at 2.6 us (768 columns)
     if (small) return launch<4, 1, VQA_F32>(p, qa, d_pad, stream);
-    return launch<8, 1, VQA_F32>(p, qa, d_pad, stream);
+    if (n <= kTinyMidRows) return launch<8, 1, VQA_F32>(p, qa, d_pad, stream);
+    return launch<8, 2, VQA_F32>(p, qa, d_pad, stream);
 }
