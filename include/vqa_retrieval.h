@@ -119,7 +119,7 @@ typedef struct vqa_index_options {
     int32_t rescore_copy;         /* with VQA_INDEX_RESCORE_ROWS: [-1] take the copy only if an eighth of the device's memory stays free
                                    * behind it, 1: whenever the allocation succeeds */
     int32_t poison_workspace;     /* [-1: no] 0..255: fill every workspace with this byte at create (tests: nothing may read what no launch wrote) */
-    int32_t one_launch;           /* [1] vqa_index_search_host on an fp16 / fp32 shard of <= 262 144 rows with <= 16 questions, k <= 16 and questions x k <= 64 runs the whole
+    int32_t one_launch;           /* [1] vqa_index_search_host on an fp16 / fp32 shard of <= 262 144 rows with <= 16 questions, k <= 32 and questions x k <= 64 runs the whole
                                    * search -- normalise, score, select, merge -- as ONE kernel (csrc/tiny_search.hip; the reference's call:
                                    * one question, limit 1, a few thousand documents); 0: the general launches (same bits; A/B switch) */
 } vqa_index_options;

@@ -29,7 +29,7 @@ for c in range(cases):
     one = DeviceIndex(x, ids=ids, id_base=1, dtype=dtype, device=0)
     gen = DeviceIndex(x, ids=ids, id_base=1, dtype=dtype, device=0, options={"one_launch": 0})
     for _ in range(4):
-        k = int(rng.integers(1, 17))
+        k = int(rng.integers(1, 33))
         b = int(rng.integers(1, min(16, 64 // k) + 1))
         q = rng.standard_normal((b, d)).astype(np.float32)
         if rng.random() < 0.3:

@@ -255,7 +255,7 @@ def test_host_latency_path_returns_the_batch_paths_bits(native_lib, dtype, n, op
 @pytest.mark.parametrize("n,d,with_ids", [(1, 768, False), (63, 64, True), (257, 100, False), (5000, 768, True), (16384, 768, False),
                                           (16385, 256, True), (40000, 768, False), (131072, 128, False), (131073, 64, True), (262144, 96, False)])
 def test_one_launch_search_returns_the_general_paths_bits(native_lib, n, d, with_ids, dtype):
-    """K4 (csrc/tiny_search.hip): on an fp16 or fp32 shard of <= 262 144 rows, vqa_index_search_host with <= 16 questions, k <= 16 and questions x k <= 64 is ONE
+    """K4 (csrc/tiny_search.hip): on an fp16 or fp32 shard of <= 262 144 rows, vqa_index_search_host with <= 16 questions, k <= 32 and questions x k <= 64 is ONE
     kernel -- normalise, score, select, merge.  Same scores / ids / positions, bit for bit, as the general launches on a handle with
     options.one_launch = 0, for raw fp32 questions (normalised by the call or not) and fp16 questions; rows stored twice tie and come
     back in position order; fewer rows than k: padding; 50 calls in a row (the ticket returns to zero) agree; and == the oracle."""
@@ -271,7 +271,7 @@ def test_one_launch_search_returns_the_general_paths_bits(native_lib, n, d, with
     kw = dict(dtype=dtype, device=0)
     one = DeviceIndex(x, ids=ids, id_base=1, **kw)
     gen = DeviceIndex(x, ids=ids, id_base=1, options={"one_launch": 0}, **kw)
-    for b, k in ((1, 1), (1, 3), (1, 16), (4, 16), (16, 4), (5, 12), (8, 8), (2, 5), (16, 16)):  # (the last one: past questions x k <= 64, the general launches)
+    for b, k in ((1, 1), (1, 3), (1, 16), (4, 16), (16, 4), (5, 12), (8, 8), (2, 5), (1, 17), (1, 32), (2, 32), (3, 20), (16, 16)):  # (the last one: past questions x k <= 64, the general launches)
         for norm in (True, False):
             a = one.search_host(q[:b], k, normalize=norm, return_positions=True)
             g = gen.search_host(q[:b], k, normalize=norm, return_positions=True)

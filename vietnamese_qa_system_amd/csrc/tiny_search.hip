@@ -15,7 +15,7 @@
 //   (3) keeps its k best (score, position) keys per question (k rounds of a wave maximum),
 //   (4) publishes them and takes a ticket; the LAST workgroup to arrive merges all lists and writes scores, external ids and
 //       positions -- straight into the caller's pinned memory.
-// Limits (vqa_tiny_search_applies): fp16 / fp32 storage, <= 16 questions, k <= 16, questions x k <= 64, <= 262 144 rows.
+// Limits (vqa_tiny_search_applies): fp16 / fp32 storage, <= 16 questions, k <= 32, questions x k <= 64, <= 262 144 rows.
 #include <string.h>
 
 #include <type_traits>
@@ -29,7 +29,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int frag_t __attribute__((ext_vector_type(4)));  // 16 bytes of one row: 8 fp16 | 4 fp32
 
 constexpr int kTinyQ = 16;      // questions per call (one MFMA column group)
-constexpr int kTinyK = 16;      // results per question
+constexpr int kTinyK = 32;      // results per question
 constexpr int kTinyMaxResults = 64;  // questions x results per call
 constexpr int kTinyChunk = 12;  // K-blocks whose fragments a wave keeps in flight together (fp16, RG = 2: 96 registers; all 24 of a 768-element row at once: measured equal)
 constexpr int kTinyMaxUnits = 1024;
@@ -68,7 +68,7 @@ struct TinyArgs {
     int q_in_args, q_is_f16, normalize, nq, k;
     const long long* ids;
     long long id_base;
-    vqa_key* partial;  // [16 questions][16 slots][kTinyMaxUnits]
+    vqa_key* partial;  // [questions x k <= 64 lists][kTinyMaxUnits]: list qi k + r holds every workgroup's r-th best key of question qi
     unsigned* ticket;
     float* out_scores;
     long long* out_ids;
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(64 * W) void tiny_search_kernel(const TinyArgs p, c
         vqa_key mine[PER];
 #pragma unroll
         for (int i = 0; i < PER; ++i) mine[i] = keys[qi * RU + lane + 64 * i];
-        vqa_key* dst = p.partial + (size_t)qi * kTinyK * kTinyMaxUnits + unit;
+        vqa_key* dst = p.partial + (size_t)qi * k * kTinyMaxUnits + unit;  // list qi k + r of the call's <= 64
         wave_topk<PER>(mine, k, [&](int r, vqa_key best) {  // (device-scope stores: past this XCD's L2, which the others do not see)
             if (lane == 0) __hip_atomic_store(dst + (size_t)r * kTinyMaxUnits, best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         });
@@ -218,9 +218,9 @@ __global__ __launch_bounds__(64 * W) void tiny_search_kernel(const TinyArgs p, c
     if (tid == 0) *p.ticket = 0u;  // for the next call on this handle (stream order)
     // Two levels, one wave per question.  A key of the overall top k belongs to a workgroup whose BEST key is one of the k largest
     // best keys (otherwise k keys of other workgroups beat it): select those k workgroups from the <= 1024 best keys (16 per lane, one
-    // round of loads), then the answer from their k lists (k * k <= 256 keys, 4 per lane).
+    // round of loads), then the answer from their k lists (k * k keys: 4 per lane up to k = 16, else 16).
     for (int qi = wave; qi < nq; qi += W) {
-        const vqa_key* mine_q = p.partial + (size_t)qi * kTinyK * kTinyMaxUnits;
+        const vqa_key* mine_q = p.partial + (size_t)qi * k * kTinyMaxUnits;
         auto emit = [&](int r, vqa_key best) {
             if (lane != 0) return;
             const size_t o = (size_t)qi * k + r;
@@ -247,13 +247,18 @@ __global__ __launch_bounds__(64 * W) void tiny_search_kernel(const TinyArgs p, c
             if (lane == 0) sel[wave][r] = best ? (int)(vqa_key_pos(best) / RU) : -1;
         });
         __builtin_amdgcn_wave_barrier();
-        vqa_key mine[4];
+        auto second_level = [&](auto per) {
+            constexpr int PER2 = decltype(per)::value;
+            vqa_key mine[PER2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = lane + 64 * i, u = e < k * k ? sel[wave][e / k] : -1;
-            mine[i] = u >= 0 ? __hip_atomic_load(mine_q + (size_t)(e % k) * kTinyMaxUnits + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        }
-        wave_topk<4>(mine, k, emit);
+            for (int i = 0; i < PER2; ++i) {
+                const int e = lane + 64 * i, u = e < k * k ? sel[wave][e / k] : -1;
+                mine[i] = u >= 0 ? __hip_atomic_load(mine_q + (size_t)(e % k) * kTinyMaxUnits + u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            }
+            wave_topk<PER2>(mine, k, emit);
+        };
+        if (k <= 16) second_level(std::integral_constant<int, 4>{});
+        else second_level(std::integral_constant<int, 16>{});
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -274,7 +279,7 @@ size_t lds_bytes(int32_t row_bytes, int32_t d_pad, int rows_per_wg, int nq) {
     const size_t keys = (size_t)kTinyQ * rows_per_wg * sizeof(vqa_key), raw = (size_t)nq * d_pad * 4;
     return (size_t)kTinyQ * (row_bytes + 16) + (keys > raw ? keys : raw);
 }
-constexpr size_t kTinyLdsMax = 160 * 1024 - 1024;  // (the kernel's static LDS: a flag and the merge's selections)
+constexpr size_t kTinyLdsMax = 160 * 1024 - 2048;  // (the kernel's static LDS: a flag and the merge's selections)
 
 template <int W, int RG, int DT>
 int launch(const TinyArgs& p, const TinyQArg& qa, int32_t d_pad, hipStream_t stream) {
@@ -302,9 +307,9 @@ bool vqa_tiny_search_applies(int32_t dtype, int64_t n, int32_t d_pad, int32_t B,
            B * k <= kTinyMaxResults && lds_bytes(d_pad * (dtype == VQA_F16 ? 2 : 4), d_pad, 256, kTinyQ) <= kTinyLdsMax;
 }
 
-size_t vqa_tiny_search_workspace_bytes() { return (size_t)kTinyMaxUnits * kTinyQ * kTinyK * sizeof(vqa_key) + 64; }
+size_t vqa_tiny_search_workspace_bytes() { return (size_t)kTinyMaxUnits * kTinyMaxResults * sizeof(vqa_key) + 64; }
 
-// workspace: [16][16][kTinyMaxUnits] keys, then the ticket (zero before the first call; the kernel leaves it zero).  q: the questions
+// workspace: [64 lists][kTinyMaxUnits] keys, then the ticket (zero before the first call; the kernel leaves it zero).  q: the questions
 // as the device sees them; q_host: the same bytes in host memory or nullptr (questions that live on the device); q_stage: device memory for
 // them (host questions larger than the launch packet's share are copied there by a kernel in front)
 int vqa_launch_tiny_search(const void* rows_tiled, int32_t dtype, int64_t n, int32_t d, int32_t d_pad, const void* q, const void* q_host, void* q_stage,
@@ -332,7 +337,7 @@ int vqa_launch_tiny_search(const void* rows_tiled, int32_t dtype, int64_t n, int
     p.ids = reinterpret_cast<const long long*>(ids);
     p.id_base = id_base;
     p.partial = static_cast<vqa_key*>(workspace);
-    p.ticket = reinterpret_cast<unsigned*>(p.partial + (size_t)kTinyMaxUnits * kTinyQ * kTinyK);
+    p.ticket = reinterpret_cast<unsigned*>(p.partial + (size_t)kTinyMaxUnits * kTinyMaxResults);
     p.out_scores = out_scores;
     p.out_ids = reinterpret_cast<long long*>(out_ids);
     p.out_pos = reinterpret_cast<long long*>(out_pos);

@@ -282,7 +282,7 @@ int vqa_launch_rescore(const unsigned long long* regions, const unsigned* counts
 // rows [first, first + count) of a tiled shard -> its row-major copy (rows of row_bytes = padded row length in bytes)
 int vqa_launch_rows_to_rowmajor(const void* tiled, int64_t first, int64_t count, int32_t row_bytes, void* out, hipStream_t stream);
 
-// K4 (tiny_search.hip): the whole search of a small fp16 / fp32 shard for <= 16 questions and k <= 16 in ONE launch -- the latency form of
+// K4 (tiny_search.hip): the whole search of a small fp16 / fp32 shard for <= 16 questions and k <= 32 (questions x k <= 64) in ONE launch -- the latency form of
 // vqa_index_search_host.  `workspace`: vqa_tiny_search_workspace_bytes() of device memory, zeroed once; results go to out_* (device
 // pointers, here: the handle's mapped pinned buffer).  Same bits as the general path (tests/test_gpu_embeddings.py).
 bool vqa_tiny_search_applies(int32_t dtype, int64_t n, int32_t d_pad, int32_t B, int32_t k);
