@@ -1322,6 +1322,17 @@ __global__ __launch_bounds__(64 * WV) void gemm_tiny_kernel(const _Float16* __re
     }
 }
 
+// token ids and masks of vqa_encoder_forward_host: pinned host memory -> the device arrays a replayed graph reads
+__global__ __launch_bounds__(256) void stage_tokens_kernel(const int* __restrict__ ids, const int* __restrict__ mask, int T,
+                                                           int* __restrict__ ids_out, int* __restrict__ mask_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < T) {
+        const int a = ids[i], b = mask[i];
+        ids_out[i] = a;
+        mask_out[i] = b;
+    }
+}
+
 // ---- attention: one workgroup per (sequence, head); K and V of the head in LDS (fp32), one wave per query row ------
 __global__ __launch_bounds__(256) void attention_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ mask,
                                                         int L, int H, int heads, _Float16* __restrict__ ctx) {
@@ -2571,8 +2582,10 @@ static int forward_locked(vqa_encoder* e, const int32_t* input_ids, const int32_
         return encoder_launch(e, input_ids, attn_mask, B, L, 0, pooling, normalize, out, s);
     }
     const size_t H = e->cfg.hidden;
-    VQA_HIP_CHECK(hipMemcpyAsync(e->g_ids, input_ids, (size_t)T * 4, hipMemcpyDefault, s));
-    VQA_HIP_CHECK(hipMemcpyAsync(e->g_mask, attn_mask, (size_t)T * 4, hipMemcpyDefault, s));
+    // the call's ids and masks -> the graph's input arrays: ONE small kernel (device pointers, or the pinned device-mapped buffer of
+    // vqa_encoder_forward_host, read over the bus); two copy operations of a few hundred bytes took ~25 us of the stream's time
+    hipLaunchKernelGGL(stage_tokens_kernel, dim3((T + 255) / 256), dim3(256), 0, s, input_ids, attn_mask, T, e->g_ids, e->g_mask);
+    VQA_HIP_CHECK(hipGetLastError());
     if (!gr->exec) {
         hipGraph_t graph = nullptr;
         VQA_HIP_CHECK(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
