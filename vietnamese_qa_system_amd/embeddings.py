@@ -325,11 +325,20 @@ class Embeddings:
         # library's latency entry -- one call, no torch tensor on the way in or out
         if isinstance(queries, np.ndarray) and queries.dtype == np.float64:
             queries = queries.astype(np.float32)
-        if (isinstance(queries, np.ndarray) and queries.ndim == 2 and queries.dtype in (np.float32, np.float16) and
+        if (isinstance(queries, torch.Tensor) and queries.dim() == 2 and queries.dtype in (torch.float32, torch.float16) and
                 0 < queries.shape[0] <= HOST_PATH_MAX_QUERIES and not self._searcher.collective):
+            # a few vectors as a tensor: on this device as they are (the entry takes device pointers too), host tensors as arrays
+            if queries.is_cuda and queries.device.index == self.device:
+                queries = queries.contiguous()
+            elif not queries.is_cuda:
+                queries = queries.numpy()
+        if (isinstance(queries, (np.ndarray, torch.Tensor)) and queries.ndim == 2 and queries.dtype in (np.float32, np.float16, torch.float32, torch.float16) and
+                0 < queries.shape[0] <= HOST_PATH_MAX_QUERIES and not self._searcher.collective and
+                (isinstance(queries, np.ndarray) or (queries.is_cuda and queries.device.index == self.device))):
             if queries.shape[1] != self.d:
                 raise ValueError(f"query dimension {queries.shape[1]} != index dimension {self.d}")
-            scores, ids = self._index.search_host(queries, limit, normalize=self.normalize and queries.dtype == np.float32)
+            is_f32 = queries.dtype in (np.float32, torch.float32)
+            scores, ids = self._index.search_host(queries, limit, normalize=self.normalize and is_f32)
             return self._format(scores, ids)
         # a few text questions against one shard, encoder built here (TextEncoder over QuestionEncoder): tokenizer -> ONE library call for
         # the forward (host ids in, device vectors out) -> ONE for the search (device vectors in, host results out)
