@@ -354,6 +354,11 @@ class Embeddings:
         texts = list(queries) if not isinstance(queries, (np.ndarray, torch.Tensor)) and len(queries) and isinstance(queries[0], str) else None
         if self.hybrid and self._sparse is not None and texts is not None and 0.0 < self.weights < 1.0:
             return self._hybrid(q, texts, limit)
+        if 0 < q.shape[0] <= HOST_PATH_MAX_QUERIES and not self._searcher.collective:
+            # a few questions through a caller-supplied encoder (any callable): its device vectors, already normalised above, through the
+            # host-result entry -- no torch tensor for the results, no copy operation
+            scores, ids = self._index.search_host(q, limit, normalize=False)
+            return self._format(scores, ids)
         scores, ids = self._searcher.search(q, limit)
         torch.cuda.current_stream(q.device).synchronize()
         return self._format(scores.cpu().numpy(), ids.cpu().numpy())
