@@ -80,6 +80,29 @@ def test_docstore_import_of_reference_shape(tmp_path):
     assert docstore.fetch_docs(db, [9, 5]) == {5: "năm", 9: "chín"}
 
 
+def test_fetch_docs_keeps_its_connection_and_follows_the_file(tmp_path):
+    """The doc-text join runs once per search: it keeps one sqlite connection per (file, thread) and reopens when the file was
+    written to, replaced or removed and re-created (what `Embeddings.save` over an old directory does)."""
+    import os
+    import threading
+    db = str(tmp_path / "documents.db")
+    docstore.write_documents(db, [{"id": i + 1, "text": f"doc {i}", "source": "s"} for i in range(100)])
+    assert docstore.fetch_docs(db, [5]) == {5: "doc 4"}
+    conn = docstore._read_connection(db)
+    assert docstore._read_connection(db) is conn and docstore.fetch_docs(db, [7, 8]) == {7: "doc 6", 8: "doc 7"}
+    docstore.write_documents(db, [{"id": 500, "text": "moi", "source": "s"}])           # written to: the new row is seen
+    assert docstore.fetch_docs(db, [500, 5]) == {5: "doc 4", 500: "moi"}
+    os.remove(db)
+    docstore.write_documents(db, [{"id": 5, "text": "khac", "source": "s"}])            # re-created: the old rows are gone
+    assert docstore.fetch_docs(db, [500, 5]) == {5: "khac"}
+    seen = {}
+    t = threading.Thread(target=lambda: seen.update(docstore.fetch_docs(db, [5])))      # another thread: a connection of its own
+    t.start()
+    t.join()
+    assert seen == {5: "khac"}
+    assert docstore.fetch_docs(db, []) == {} and docstore.fetch_docs(db, [-1]) == {}
+
+
 def test_agreement_rule():
     # heavy_ranker.py:110: same id AND score sum > 0.4 (strict)
     assert heavy_ranker.agreement(7, 0.25, 7, 0.16)

@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import os
 import sqlite3
+import threading
 from typing import Any, Iterable, List, Sequence, Union
 
 DOCUMENTS_FIELDS = "(id INTEGER PRIMARY KEY AUTOINCREMENT, doc TEXT, source TEXT)"  # setup_db.py:14
@@ -95,6 +96,32 @@ def insert_data(database_path: str, table_name: str, data: List[dict], verbose: 
         connection.close()
 
 
+# fetch_docs keeps its connection: opening one costs 120 us, the statement 10 -- and the join runs once per search
+# (``heavy_ranker.py:102-108`` runs it once per hit).  One connection per (file, thread), dropped when the file changes.
+_read_connections: dict = {}
+
+
+def _read_connection(database_path: str) -> sqlite3.Connection:
+    st = os.stat(database_path)
+    signature = (st.st_ino, st.st_mtime_ns, st.st_size)
+    key = (os.path.abspath(database_path), threading.get_ident())
+    hit = _read_connections.get(key)
+    if hit is not None and hit[1] == signature:
+        return hit[0]
+    if hit is not None:
+        hit[0].close()
+    if len(_read_connections) >= 32:  # (a process that walks over many files or threads: start over)
+        for conn, _ in _read_connections.values():
+            try:
+                conn.close()
+            except sqlite3.Error:
+                pass
+        _read_connections.clear()
+    connection = connect_database(database_path)
+    _read_connections[key] = (connection, signature)
+    return connection
+
+
 def fetch_docs(database_path: str, ids: Sequence[int], table: str = "documents", column: str = "doc") -> dict:
     """Batched doc-text join: ``{id: text}`` for every id of a result batch, one statement per 900 ids
     (the per-hit loop of ``heavy_ranker.py:102-108`` collapsed)."""
@@ -102,16 +129,15 @@ def fetch_docs(database_path: str, ids: Sequence[int], table: str = "documents",
     uniq = sorted({int(i) for i in ids if int(i) >= 0})
     if not uniq:
         return out
-    connection = connect_database(database_path)
+    cursor = _read_connection(database_path).cursor()
     try:
-        cursor = connection.cursor()
         for c0 in range(0, len(uniq), 900):
             chunk = uniq[c0:c0 + 900]
             marks = ",".join("?" * len(chunk))
             cursor.execute(f"SELECT id, {column} FROM {table} WHERE id IN ({marks})", chunk)
             out.update({int(r[0]): r[1] for r in cursor.fetchall()})
     finally:
-        connection.close()
+        cursor.close()
     return out
 
 
