@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VQA_VERSION 112 /* 0.1.12: vqa_index_options.one_launch (vqa_index_search_host of a small fp16 shard is one kernel); 0.1.11: vqa_encoder_forward_host, device queries in vqa_index_search_host; 0.1.10: vqa_index_search_host; 0.1.9: vqa_index_options / vqa_index_create_ex, vqa_encoder_options / vqa_encoder_create_ex (no environment variable is read any more), vqa_launch_info.levels; 0.1.8: vqa_encoder_forward_hidden; 0.1.7: vqa_index_get_sketch_split; 0.1.6: vqa_index_sketch_stats, vqa_index_get_sketch_tile; 0.1.5: vqa_index_sketch_state; 0.1.4: VQA_INDEX_RESCORE_ROWS, vqa_index_device_bytes; 0.1.3: VQA_INDEX_SKETCH */
+#define VQA_VERSION 113 /* 0.1.13: vqa_index_options.sketch_regq (csrc/scan_regq.hip); 0.1.12: vqa_index_options.one_launch (vqa_index_search_host of a small fp16 shard is one kernel); 0.1.11: vqa_encoder_forward_host, device queries in vqa_index_search_host; 0.1.10: vqa_index_search_host; 0.1.9: vqa_index_options / vqa_index_create_ex, vqa_encoder_options / vqa_encoder_create_ex (no environment variable is read any more), vqa_launch_info.levels; 0.1.8: vqa_encoder_forward_hidden; 0.1.7: vqa_index_get_sketch_split; 0.1.6: vqa_index_sketch_stats, vqa_index_get_sketch_tile; 0.1.5: vqa_index_sketch_state; 0.1.4: VQA_INDEX_RESCORE_ROWS, vqa_index_device_bytes; 0.1.3: VQA_INDEX_SKETCH */
 
 /* error codes */
 #define VQA_OK 0
@@ -122,6 +122,9 @@ typedef struct vqa_index_options {
     int32_t one_launch;           /* [1] vqa_index_search_host on an fp16 / fp32 shard of <= 262 144 rows with <= 16 questions, k <= 32 and questions x k <= 64 runs the whole
                                    * search -- normalise, score, select, merge -- as ONE kernel (csrc/tiny_search.hip; the reference's call:
                                    * one question, limit 1, a few thousand documents); 0: the general launches (same bits; A/B switch) */
+    int32_t sketch_regq;          /* [1] int8 sketch scans of rows of 768 / 384 elements run the register-resident-query kernel (csrc/scan_regq.hip:
+                                   * the query tile is loaded once per launch instead of once per corpus tile); 0: score_topk.hip's slot loop
+                                   * (same candidate pairs, same results; A/B switch) */
 } vqa_index_options;
 void vqa_index_options_init(vqa_index_options* opt);
 /* vqa_index_create with explicit options (`flags` travel inside them); opt == NULL: the defaults */

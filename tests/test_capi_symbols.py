@@ -26,7 +26,7 @@ def test_python_binding_lists_every_symbol(native_lib):
     from vietnamese_qa_system_amd import _native
     assert sorted(_native.EXPORTS) == declared_symbols()
     lib = _native.load()
-    assert lib.vqa_version() == _native.VQA_VERSION == 112
+    assert lib.vqa_version() == _native.VQA_VERSION == 113
     assert isinstance(lib.vqa_last_error(), bytes)
 
 

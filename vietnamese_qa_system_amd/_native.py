@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VQA_LIB") or os.path.join(_HERE, "lib", "libvqa_retrieval.so")  # VQA_LIB: dev override
 
-VQA_VERSION = 112  # include/vqa_retrieval.h: the ABI these bindings were written against
+VQA_VERSION = 113  # include/vqa_retrieval.h: the ABI these bindings were written against
 VQA_F32, VQA_F16, VQA_FP8_E4M3 = 0, 1, 2
 VQA_INDEX_HAS_IDS = 1
 VQA_INDEX_SKETCH = 2
@@ -52,7 +52,8 @@ class IndexOptions(ctypes.Structure):
         "two_pass", "wide_k", "seed_mult", "seed_div", "stage_min_tiles", "stage_pct", "f16_loop", "sketch_cascade", "sketch_rotate",
         "sketch_center", "sketch_split", "sketch_per_row", "sketch_ring_stages", "sketch_mid_k", "sketch_mid_min_tiles", "sketch_mid_pct",
         "sketch_pre_k", "sketch_cooldown")] + [("sketch_profit", ctypes.c_float), ("rescore_copy", ctypes.c_int32),
-                                               ("poison_workspace", ctypes.c_int32), ("one_launch", ctypes.c_int32)]
+                                               ("poison_workspace", ctypes.c_int32), ("one_launch", ctypes.c_int32),
+                                               ("sketch_regq", ctypes.c_int32)]
 
 
 class EncoderOptions(ctypes.Structure):

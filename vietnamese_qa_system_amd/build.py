@@ -87,14 +87,20 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
-def build_variant(tag: str, defines: list[str]) -> str:
-    """Dev helper: a second copy of the library with extra -D flags (timing ablations), lib/libvqa_retrieval_<tag>.so."""
+def build_variant(tag: str, defines: list[str], only: tuple[str, ...] = ()) -> str:
+    """Dev helper: a second copy of the library with extra -D flags (timing ablations), lib/libvqa_retrieval_<tag>.so.
+    ``only``: source basenames the flags apply to; the other objects are the default build's (built first if stale)."""
     os.makedirs(OBJ_DIR, exist_ok=True)
     # a "define" that starts with '-' is passed to hipcc as it is (compiler-flag experiments)
     extra = []
     for d in defines:
         extra += d.split() if d.startswith("-") else [f"-D{d}"]
-    objs = [_compile(src, tuple(extra), "_" + tag) for src in sources()]
+    if only:
+        build()
+        objs = [_compile(src, tuple(extra), "_" + tag) if os.path.basename(src) in only
+                else os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o") for src in sources()]
+    else:
+        objs = [_compile(src, tuple(extra), "_" + tag) for src in sources()]
     out = os.path.join(LIB_DIR, f"libvqa_retrieval_{tag}.so")
     r = subprocess.run([HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", out, *objs], capture_output=True, text=True,
                        env=_clean_env())

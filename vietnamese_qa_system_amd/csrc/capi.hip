@@ -132,6 +132,7 @@ struct vqa_index {
     bool mu_set = false;
     bool center = true;                     // options.sketch_center = 0: no centring (needs the rotated form)
     bool rotate = true;                     // the sketch is cut from rotated rows (convert.hip: sketch_rotate); options.sketch_rotate = 0: from the rows as they are
+    bool sketch_regq = true;                // options.sketch_regq: the register-resident-query scan kernel where it applies
     bool sketch_sx5 = true;                 // the sketch scan's X ring: five stages; options.sketch_ring_stages = 6: six (A-B switch: measured equal)
     int mid_k = 16, mid_pct = 200;          // a second cascade stage of mid_pct % of the first one's tiles for k >= mid_k (options.sketch_mid_k, 0: never; options.sketch_mid_pct)
     int pre_k = 48;                         // a leading quarter of the first stage as a stage of its own for k >= pre_k (options.sketch_pre_k, 0: never)
@@ -395,6 +396,7 @@ extern "C" void vqa_index_options_init(vqa_index_options* o) {
     o->rescore_copy = -1;
     o->poison_workspace = -1;
     o->one_launch = 1;
+    o->sketch_regq = 1;
 }
 
 // -DVQA_DEV variant libraries only (scripts/: ab_loops.py, probes): the rounds-1-4 environment switches laid over the options
@@ -423,6 +425,7 @@ static void dev_env_overlay(vqa_index_options* o) {
     if (const char* v = vqa_dev_env("VQA_SKETCH_PROFIT")) o->sketch_profit = (float)atof(v);
     geti("VQA_RESCORE_COPY", &o->rescore_copy);
     geti("VQA_ONE_LAUNCH", &o->one_launch);
+    geti("VQA_SKETCH_REGQ", &o->sketch_regq);
     if (const char* v = vqa_dev_env("VQA_POISON_WORKSPACE")) o->poison_workspace = (int)strtol(v, nullptr, 0) & 0xFF;
     if (const char* v = vqa_dev_env("VQA_SKETCH")) {
         if (v[0] == '0') o->flags &= ~(uint32_t)VQA_INDEX_SKETCH;
@@ -580,6 +583,7 @@ extern "C" int vqa_index_create_ex(vqa_index** out, int device, int64_t n, int32
             ix->mid_min_tiles = o.sketch_mid_min_tiles;
             ix->pre_k = o.sketch_pre_k;
             ix->sketch_sx5 = o.sketch_ring_stages != 6;
+            ix->sketch_regq = o.sketch_regq != 0;
             ix->rotate = o.sketch_rotate != 0;
             ix->center = o.sketch_center != 0;
             ix->center = ix->center && ix->rotate;
@@ -961,6 +965,7 @@ static int sketch_scan_rescore(vqa_index* ix, const LaunchPlan& p, const float* 
     b.sketch = &sk;
     b.first_stage = tile_end < p.tiles;  // (its own kernel symbol in a trace)
     b.loop = ix->sketch_sx5 ? 1 : 0;
+    b.regq = ix->sketch_regq;
     timed = timed && ix->timing;
     if (timed && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
     rc = vqa_launch_score_topk(VQA_I8_SKETCH, b, stream);

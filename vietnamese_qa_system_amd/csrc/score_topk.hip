@@ -740,6 +740,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
     // (query << 32 | row position) and are scored exactly afterwards (rescore_kernel, merge_topk.hip).  No list, no
     // compaction, no workgroup barrier.
     auto sketch_epilogue = [&](const f32x4 (&acc)[8][4], uint32_t row0, int ti) __attribute__((always_inline)) {
+        if constexpr (bool(VQA_ABLATE & 8)) return;
         const float4 tmax = sk_tm[ti];
         const float a_hi = tmax.x, b_lo = tmax.y, inv_sx = tmax.z, c_w = tmax.w;
         if constexpr (kBeta) {
@@ -974,8 +975,11 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         uint32_t dst = ring_lds + lw * 4096;
         int n_issued = 0, src_kt = 0;
         auto issue = [&]() __attribute__((always_inline)) {
-            if constexpr (kQ0) glds16x4<false>(src, voff, dst);
-            else glds16x4<VQA_XNT != 0>(src, voff, dst);
+            if constexpr (kQ0) {
+                if constexpr (!(VQA_ABLATE & 33)) glds16x4<false>(src, voff, dst);
+            } else {
+                if constexpr (!(VQA_ABLATE & 1)) glds16x4<VQA_XNT != 0>(src, voff, dst);
+            }
             ++n_issued;
             if (n_issued < total) {  // past the end the cursor stays on the last block
                 src += kOperandBytes;
@@ -992,6 +996,19 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         const int b_off = SX * kOperandBytes + wn * 64 * kRowBytes + frag_off;      // inside a Q stage
         int rx = 0, rq = 0;  // stages of the K-step this group reads next
         frag_t fa[8], fb[4];
+#if VQA_ABLATE & 2
+        for (int i = 0; i < 8; ++i) fa[i] = frag_t{(uint32_t)lane * 2654435761u + i, 0x3c003c00u + lane, 0x12345678u * (i + 1), 0x0badcafeu ^ lane};
+        for (int i = 0; i < 4; ++i) fb[i] = frag_t{(uint32_t)lane * 40503u + i, 0x38003800u + lane, 0x87654321u * (i + 1), 0x0defacedu ^ lane};
+#endif
+#if VQA_ABLATE & 2
+#define VQA_SLOT_READ()                                                                                            \
+    do {                                                                                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) asm volatile("" : "+v"(fb[i_]));                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) asm volatile("" : "+v"(fa[i_]));                          \
+        if (++rx == SX) rx = 0;                                                                                    \
+        if (++rq == SQ) rq = 0;                                                                                    \
+    } while (0)
+#else
 #define VQA_SLOT_READ()                                                                                            \
     do {                                                                                                           \
         const char* xbuf_ = smem + rx * kOperandBytes;                                                             \
@@ -1003,6 +1020,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
         if (++rx == SX) rx = 0;                                                                                    \
         if (++rq == SQ) rq = 0;                                                                                    \
     } while (0)
+#endif
 #ifdef VQA_SLOT_SETPRIO
 #define VQA_SLOT_PRIO(P) __builtin_amdgcn_s_setprio(P)
 #else
@@ -1015,7 +1033,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
                      "+v"(fa[7]));                                                                                 \
         VQA_SB();                                                                                                  \
         VQA_SLOT_PRIO(1);                                                                                          \
-        mma_block<DT, (M0), (M1)>(acc, fa, fb);                                                                    \
+        VQA_MMA_RANGE(fa, fb, M0, M1);                                                                             \
         _Pragma("unroll") for (int mi_ = (M0); mi_ < (M1); ++mi_)                                                  \
             asm volatile("" ::"v"(acc[mi_][0]), "v"(acc[mi_][1]), "v"(acc[mi_][2]), "v"(acc[mi_][3]));             \
         VQA_SLOT_PRIO(0);                                                                                          \
@@ -1071,7 +1089,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
             VQA_STAMP(2);                                                                                            \
         }                                                                                                            \
         VQA_STAMP(3);                                                                                                \
-        block_barrier();                                                                                             \
+        VQA_LOOP_BARRIER();                                                                                          \
         VQA_STAMP(4);                                                                                                \
         if constexpr (kQ0) {                                                                                         \
             VQA_SLOT_MMA(kEarly, 8);                                                                                 \
@@ -1098,7 +1116,7 @@ __global__ __launch_bounds__(kThreads) void score_topk_kernel(const void* __rest
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                       \
             if constexpr (!LAST) VQA_SLOT_MMA(0, kEarly);                                                            \
         }                                                                                                            \
-        block_barrier();                                                                                             \
+        VQA_LOOP_BARRIER();                                                                                          \
         VQA_STAMP(7);                                                                                                \
         VQA_STAMP_FLUSH(KT_IDX);                                                                                     \
     } while (0)
@@ -1388,6 +1406,7 @@ int vqa_launch_score_topk(int dtype, const ScoreTopkArgs& a, hipStream_t stream)
                     "score_topk: incomplete sketch arguments");
         VQA_REQUIRE(!a.sketch->beta || (a.sketch->tile_c && a.d_pad / kRowBytes >= 6),
                     "score_topk: the per-row form needs the tiles' max |beta| and rows of at least six K-steps");
+        if (a.regq && vqa_sketch_regq_applies(a)) return vqa_launch_sketch_regq(a, stream);
         return launch_sketch(a, a.d_pad / kRowBytes, vqa_score_topk_lds_bytes(dtype, a.k), stream);
     }
     VQA_REQUIRE(dtype == VQA_F16 || dtype == VQA_FP8_E4M3 || dtype == VQA_F32, "score_topk: storage type %d", dtype);

@@ -161,11 +161,15 @@ struct ScoreTopkArgs {
     int32_t loop = 0;           // fp16: 0 = anti-phase slot loop, 1 = K-step-pair stagger loop (the fp8 structure); sketch scan: 1 = five
                                 // X ring stages instead of six
     const SketchScanArgs* sketch = nullptr;  // not null: MODE 2 over the int8 sketch (x = sketch rows, q = sketch of the query tile)
+    bool regq = true;           // sketch scans: the register-resident-query kernel (scan_regq.hip) where it applies
     bool seed_only = false;  // MODE 0: writes seeds_per_tile sub-maxima per query and tile to `partial` as [query][tile - tile_begin][.]
     int32_t seeds_per_tile = 2;  // 2 (one per 128-row half) or 8 (one per 32-row group: shards of a few tiles, where 2 per tile
                                  // are fewer than k values and leave the thresholds at -inf)
 };
 int vqa_launch_score_topk(int dtype, const ScoreTopkArgs& a, hipStream_t stream);
+// scan_regq.hip: the sketch scan with the query operand resident in registers (rows of 768 / 384 one-byte elements, no per-row betas)
+bool vqa_sketch_regq_applies(const ScoreTopkArgs& a);
+int vqa_launch_sketch_regq(const ScoreTopkArgs& a, hipStream_t stream);
 int vqa_score_topk_lds_bytes(int dtype, int k);
 int vqa_score_topk_max_k(int dtype);
 int vqa_score_topk_seeds_per_tile();
