@@ -244,6 +244,9 @@ def main():
     ap.add_argument("--no-other", action="store_true", help="skip the other_configs legs (fp8, fp32 + encoder, configs[0] API latency)")
     args = ap.parse_args()
 
+    # RCCL's intra-node transport needs dmabuf IPC on this driver (hipIpcGetMemHandle fails in the legacy mode): set before torch is
+    # imported / anything touches the GPU, for EVERY way this file is started -- bare, self-spawned or under an external launcher
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if args.gpus > 1 and not launched:
         # a bare `python bench.py --gpus N`: this process becomes the launcher of its own N ranks (a CHILD torch.distributed.run
@@ -355,7 +358,34 @@ def main():
         allmed = [torch.zeros_like(med) for _ in range(world)]
         dist.all_gather(allmed, med)
         allmed = torch.stack(allmed).cpu().numpy()  # [rank, phase]
+        # proof of N ranks on N devices that does not depend on NCCL_DEBUG: every rank contributes (rank, local device index, the
+        # device's uuid bytes) through the job's own backend
+        props = torch.cuda.get_device_properties(device)
+        uuid_hex = "".join(ch for ch in str(getattr(props, "uuid", "")) if ch in "0123456789abcdefABCDEF")[-32:].rjust(32, "0")
+        uuid_bytes = bytes.fromhex(uuid_hex)
+        ident = torch.tensor([rank, dev_index, *uuid_bytes], dtype=torch.int64, device=device)
+        idents = [torch.zeros_like(ident) for _ in range(world)]
+        dist.all_gather(idents, ident)
+        idents = [[int(v) for v in t.cpu().tolist()] for t in idents]
+        rank_devices = [{"rank": t[0], "device_index": t[1], "device_uuid": bytes(t[2:18]).hex()} for t in idents]
+        try:
+            rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception:  # noqa: BLE001 -- diagnostics only
+            rccl_version = None
+        one_gpu = None
+        p80 = os.path.join(ROOT, "profiles", "r05_80M_one_gpu.json")
+        if os.path.exists(p80):
+            with open(p80) as f:
+                j80 = json.load(f)
+            one_gpu = {"file": "profiles/r05_80M_one_gpu.json", "rows": 80_000_000,
+                       "ms_per_batch_sketch_path": j80["default_path_int8_sketch_scan_plus_exact_rescoring"]["ms_per_batch"],
+                       "ms_per_batch_exact_scan": j80["exact_fp16_scan_VQA_SKETCH_0"]["ms_per_batch"],
+                       "note": "the WHOLE 80M x 768 fp16 corpus of configs[3] on ONE MI355X (256 queries, top-10): the strong-scaling denominator; "
+                               "this job's ms_per_step at N = 8 x 10M rows is the numerator's inverse"}
         multi = {"backend": backend + (" (RCCL)" if backend == "nccl" else " (ranks share a device: plumbing run, VQA_BENCH_SHARE_GPU=1)"),
+                 "rccl_version": rccl_version, "hsa_enable_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                 "ranks": rank_devices, "distinct_devices": len({(t["device_index"], t["device_uuid"]) for t in rank_devices}),
+                 "corpus_80M_on_one_gpu": one_gpu,
                  "world_size": world, "device_count": torch.cuda.device_count(), "gpus_flag": args.gpus,
                  "devices": sorted({(r % torch.cuda.device_count()) if share else r for r in range(world)}),
                  "collectives_per_step": (searcher.collectives - c0) / ps,
@@ -402,7 +432,8 @@ def main():
         mode = {"fp16": 1, "fp8": 2, "fp32": 0}[args.dtype]
         sketch = bool(info.sketch_scan)
         esize = {"fp16": 2, "fp8": 1, "fp32": 4}[args.dtype]
-        kname = "score_topk_kernel<2, 3, 0, 1>" if sketch else f"score_topk_kernel<1, {mode}, 0, 0>"
+        kname = ((f"sketch_scan_regq_kernel<{(d + 127) // 128 * 2}, 0>" if info.scan_kernel == 1 else "score_topk_kernel<2, 3, 0, 1>") if sketch
+                 else f"score_topk_kernel<1, {mode}, 0, 0>")
         if sketch:  # the PMC bytes of THAT launch (profiles/traffic.json keeps the exact main launch's under the plain key)
             traffic = None
             if os.path.exists(tpath):

@@ -242,6 +242,8 @@ typedef struct vqa_launch_info {
                                * element, flops_per_launch the same multiply-adds (int8 x int8 -> int32) */
     int32_t levels;           /* scans of disjoint row ranges one pass consists of: 1 = one launch over every row; 2 = first stage + main
                                * launch; sketch cascade: 2 .. 4 (leading quarter | first stage | second stage | the rest) */
+    int32_t scan_kernel;      /* which kernel the sketch scans run: 0 = csrc/score_topk.hip (MODE 2, the slot loop; also every exact scan),
+                               * 1 = csrc/scan_regq.hip (query tile resident in registers: rows of 768 / 384 sketch elements, no per-row form) */
 } vqa_launch_info;
 int vqa_index_launch_info(const vqa_index* index, int32_t B, int32_t k, vqa_launch_info* out);
 int vqa_index_set_timing(vqa_index* index, int32_t enabled); /* 0: off (recorded pairs are kept until get_timing), 1: on, from scratch,

@@ -238,6 +238,7 @@ def main():
     dist.barrier()
     with open(os.path.join(args.out, f"rank{rank}.json"), "w") as f:
         json.dump({"rank": rank, "world": world, "backend": args.backend, "device": dev_index, "checks": checks,
+                   "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                    "collectives": emb._searcher.collectives}, f)
     dist.destroy_process_group()
 

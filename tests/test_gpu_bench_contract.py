@@ -60,8 +60,9 @@ def test_bench_two_ranks_started_by_bench_itself(native_lib):
     torch.distributed.run child before touching the GPU, relays rank 0's one JSON line and the exit code.  On the 1-GPU box
     VQA_BENCH_SHARE_GPU=1 puts both ranks on cuda:0 over gloo.  The row-sharded searcher, the all-gather, the merge, the
     max-over-ranks timing, the per-phase event times and the end-to-end leg on every rank all run."""
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(VQA_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # (HSA_ENABLE_IPC_MODE_LEGACY is NOT preset: bench.py sets it for itself and its ranks before anything touches the GPU)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")}
+    env.update(VQA_BENCH_SHARE_GPU="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--docs-per-gpu",
                           "200000", "--steps", "4", "--warmup", "2", "--verify-queries", "4", "--e2e-steps", "3"],
                          capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
@@ -74,6 +75,8 @@ def test_bench_two_ranks_started_by_bench_itself(native_lib):
     assert r["roofline"]["launches"] == 1 and r["end_to_end"]["value"] > 0
     mg = r["multi_gpu"]
     assert mg["world_size"] == 2 and mg["backend"].startswith("gloo") and mg["device_count"] >= 1 and mg["collectives_per_step"] == 1
+    assert mg["hsa_enable_ipc_mode_legacy"] == "0" and [t["rank"] for t in mg["ranks"]] == [0, 1] and mg["distinct_devices"] == 1
+    assert mg["corpus_80M_on_one_gpu"]["ms_per_batch_sketch_path"] > 0
     pr = mg["per_rank_ms_per_step"]
     assert len(pr["by_rank"]) == 2 and pr["min"] <= pr["max"] and abs(pr["max"] - r["ms_per_step"]) < 1e-3
     for phase in ("local_search_ms", "gather_wait_ms", "merge_ms"):
@@ -96,7 +99,9 @@ def test_bench_eight_ranks_sharing_the_device(native_lib):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    env = dict(os.environ, VQA_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    # an EXTERNAL launcher, as the driver's, and no HSA_ENABLE_IPC_MODE_LEGACY in its environment: bench.py's own first lines set it
+    env = {k: v for k, v in os.environ.items() if k != "HSA_ENABLE_IPC_MODE_LEGACY"}
+    env.update(VQA_BENCH_SHARE_GPU="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
                           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--docs-per-gpu",
                           "200000", "--steps", "4", "--warmup", "2", "--verify-queries", "4", "--e2e-steps", "2"],
@@ -107,6 +112,7 @@ def test_bench_eight_ranks_sharing_the_device(native_lib):
     r = json.loads(lines[0])
     assert r["n_gpus"] == 8 and r["config"]["docs_total"] == 1600000 and r["scaling"] == "weak"
     assert r["config"]["parallelism"] == "row-shard x8" and r["recall_at_10"] == 1.0 and "cpu_baseline" not in r
+    assert r["multi_gpu"]["hsa_enable_ipc_mode_legacy"] == "0" and len(r["multi_gpu"]["ranks"]) == 8
     assert r["roofline"]["launches"] == 1 and r["end_to_end"]["value"] > 0
     assert r["pipelined"]["value"] > 0 and r["pipelined"]["batches"] >= 2
     mg = r["multi_gpu"]

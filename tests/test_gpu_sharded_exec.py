@@ -31,10 +31,14 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def _run(tmp_path, extra, world=2, env_extra=None):
+def _run(tmp_path, extra, world=2, env_extra=None, preset_ipc=True):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "sharded_worker.py"), "--out", str(tmp_path), *extra]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT, **(env_extra or {}))
+    env = dict(os.environ, PYTHONPATH=ROOT, **(env_extra or {}))
+    if preset_ipc:
+        env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    else:
+        env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-4000:] + "\n" + r.stderr[-6000:])
     recs = []
@@ -54,6 +58,13 @@ def test_two_ranks_sharing_one_device(native_lib, tmp_path):
 def test_eight_ranks_sharing_one_device(native_lib, tmp_path):
     """BASELINE configs[3] / configs[4] run 8 ranks: the product program at that world size (one device, gloo)."""
     _run(tmp_path, ["--backend", "gloo", "--share"], world=8)
+
+
+def test_one_rank_over_rccl_without_the_ipc_variable_preset(native_lib, tmp_path):
+    """An external `torch.distributed.run` whose environment does not carry HSA_ENABLE_IPC_MODE_LEGACY: importing the
+    package under a launcher sets it to 0 before the first GPU call, and the RCCL group of one rank runs every collective of the path."""
+    recs = _run(tmp_path, ["--backend", "nccl"], world=1, env_extra={"VQA_ALWAYS_GATHER": "1"}, preset_ipc=False)
+    assert recs[0]["backend"] == "nccl" and recs[0]["collectives"] >= 10 and recs[0]["ipc_mode_legacy"] == "0"
 
 
 def test_one_rank_over_rccl(native_lib, tmp_path):

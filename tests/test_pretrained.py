@@ -182,3 +182,88 @@ def test_minilm_shaped_directory_in_the_old_sentence_transformers_layout(native_
     ref = E.encode({k: v.astype(np.float32) for k, v in w.items()}, cfg, ids[:6], mask[:6], pooling="cls")
     assert np.abs(got[:6] - ref).max() < 8.5e-4  # tests/test_gpu_encoder.py BOUNDS["minilm", 2]
     enc.close()
+
+
+# ---- hub names, offline (heavy_ranker.py:80,83 pass "sentence-transformers/..." names) ------------------------
+def _fake_hub_cache(root, golden_dir, name="sentence-transformers/paraphrase-multilingual-MiniLM-L12-v2", revision="abc123", refs=True):
+    """<root>/models--org--name/snapshots/<revision>/ = a copy of the tiny golden model directory, as huggingface_hub lays it out."""
+    import shutil
+    hub = os.path.join(root, "models--" + name.replace("/", "--"))
+    snap = os.path.join(hub, "snapshots", revision)
+    shutil.copytree(os.path.join(golden_dir, "hf_tiny_roberta_st"), snap)
+    if refs:
+        os.makedirs(os.path.join(hub, "refs"))
+        with open(os.path.join(hub, "refs", "main"), "w") as f:
+            f.write(revision)
+    return snap
+
+
+def test_hub_name_resolves_from_the_local_cache(golden_dir, tmp_path, monkeypatch):
+    name = "sentence-transformers/paraphrase-multilingual-MiniLM-L12-v2"
+    for var in ("SENTENCE_TRANSFORMERS_HOME", "HF_HUB_CACHE", "HUGGINGFACE_HUB_CACHE", "TRANSFORMERS_CACHE", "HF_HOME", "XDG_CACHE_HOME"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv("HOME", str(tmp_path / "home"))
+    assert P.resolve_model_path(name) is None  # nothing cached: the caller raises its clear error
+    assert P.resolve_model_path(str(tmp_path / "no" / "such" / "dir")) is None and P.resolve_model_path(None) is None
+    assert P.resolve_model_path(f"{golden_dir}/hf_tiny_roberta_st") == f"{golden_dir}/hf_tiny_roberta_st"  # a directory is itself
+    # $HF_HOME/hub, revision named by refs/main (an older snapshot beside it is not taken)
+    hub = tmp_path / "hf_home" / "hub"
+    _fake_hub_cache(str(hub), golden_dir, name, "old000", refs=False)
+    snap = _fake_hub_cache_second = os.path.join(str(hub), "models--" + name.replace("/", "--"), "snapshots", "new111")
+    import shutil
+    shutil.copytree(os.path.join(golden_dir, "hf_tiny_roberta_st"), snap)
+    os.makedirs(os.path.join(str(hub), "models--" + name.replace("/", "--"), "refs"))
+    with open(os.path.join(str(hub), "models--" + name.replace("/", "--"), "refs", "main"), "w") as f:
+        f.write("new111")
+    monkeypatch.setenv("HF_HOME", str(tmp_path / "hf_home"))
+    assert P.resolve_model_path(name) == snap
+    # a bare name is tried under the sentence-transformers organisation, as that library does
+    assert P.resolve_model_path("paraphrase-multilingual-MiniLM-L12-v2") == snap
+    # the default location ~/.cache/huggingface/hub and sentence-transformers' older flat layout
+    monkeypatch.delenv("HF_HOME")
+    default = _fake_hub_cache(str(tmp_path / "home" / ".cache" / "huggingface" / "hub"), golden_dir, "org/model-x")
+    assert P.resolve_model_path("org/model-x") == default
+    flat = tmp_path / "st_home" / "sentence-transformers_all-tiny"
+    shutil.copytree(os.path.join(golden_dir, "hf_tiny_roberta_st"), flat)
+    monkeypatch.setenv("SENTENCE_TRANSFORMERS_HOME", str(tmp_path / "st_home"))
+    assert P.resolve_model_path("sentence-transformers/all-tiny") == str(flat)
+    # what loads from there is the model
+    w, cfg, pooling, normalize = P.load_pretrained(P.resolve_model_path(name) or snap)
+    assert cfg == TINY and pooling == "mean"
+
+
+def test_a_hub_name_that_is_not_cached_is_a_clear_error(monkeypatch, tmp_path):
+    """No GPU needed: the text path fails before any device work when the name resolves to nothing."""
+    for var in ("SENTENCE_TRANSFORMERS_HOME", "HF_HUB_CACHE", "HUGGINGFACE_HUB_CACHE", "TRANSFORMERS_CACHE", "HF_HOME", "XDG_CACHE_HOME"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv("HOME", str(tmp_path))
+    from vietnamese_qa_system_amd.embeddings import Embeddings
+    emb = Embeddings.__new__(Embeddings)
+    emb.encoder, emb.path = None, "sentence-transformers/paraphrase-multilingual-mpnet-base-v2"
+    with pytest.raises(RuntimeError, match="already in the local Hugging Face cache"):
+        emb._encode(["câu hỏi"])
+
+
+@pytest.mark.gpu
+def test_embeddings_with_the_references_hub_name(native_lib, golden_dir, tmp_path, monkeypatch):
+    """heavy_ranker.py:78-80 verbatim -- Embeddings(hybrid=..., content=True, path="sentence-transformers/...") -- with the model in a
+    local hub cache: index(texts), search(text) run through the HIP encoder built from the cached snapshot."""
+    from vietnamese_qa_system_amd import Embeddings
+    name = "sentence-transformers/paraphrase-multilingual-MiniLM-L12-v2"
+    for var in ("SENTENCE_TRANSFORMERS_HOME", "HF_HUB_CACHE", "HUGGINGFACE_HUB_CACHE", "TRANSFORMERS_CACHE", "XDG_CACHE_HOME"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv("HF_HOME", str(tmp_path / "hf"))
+    _fake_hub_cache(str(tmp_path / "hf" / "hub"), golden_dir, name)
+    g, _ = _npz_weights(golden_dir, "enc_tiny.npz")
+    ids, mask = g["input_ids"], g["attention_mask"]
+    table = {f"text {i}": (ids[i], mask[i]) for i in range(ids.shape[0])}
+
+    def tokenizer(texts):
+        return np.stack([table[t][0] for t in texts]), np.stack([table[t][1] for t in texts])
+
+    emb = Embeddings(content=True, path=name, tokenizer=tokenizer, max_tokens=64, min_score=None)
+    emb.index([{"id": 10 + i, "text": f"text {i}", "source": "s"} for i in range(4)])
+    for i in range(4):
+        hit = emb.search(f"text {i}", 1)[0]
+        assert hit["id"] == 10 + i and hit["text"] == f"text {i}" and abs(hit["score"] - 1.0) < 2e-3
+    assert emb.path == name  # what save() records is what the caller passed

@@ -4,6 +4,7 @@
 everything below it (L2-normalise, fp16 index in HBM, fused MFMA scoring + top-k, shard merge, question encoder)
 runs in ``libvqa_retrieval.so`` (hand-written HIP, gfx950).  There is no CPU fallback.
 """
+from .sharded import ensure_multi_process_gpu_env as _ensure_env  # noqa: F401  (first: sets HSA_ENABLE_IPC_MODE_LEGACY=0 under a distributed launcher)
 from .embeddings import Embeddings  # noqa: F401
 from .index import DeviceIndex, merge_topk  # noqa: F401
 from .sharded import ShardedSearcher, shard_bounds, sharded_index_searcher  # noqa: F401

@@ -43,7 +43,7 @@ class LaunchInfo(ctypes.Structure):
                 ("rows_per_tile", ctypes.c_int32), ("rows_per_launch", ctypes.c_int64),
                 ("bytes_per_launch", ctypes.c_int64), ("flops_per_launch", ctypes.c_int64),
                 ("seed_grid", ctypes.c_int32), ("seed_tiles", ctypes.c_int32), ("first_stage_rows", ctypes.c_int64),
-                ("sketch_scan", ctypes.c_int32), ("levels", ctypes.c_int32)]
+                ("sketch_scan", ctypes.c_int32), ("levels", ctypes.c_int32), ("scan_kernel", ctypes.c_int32)]
 
 
 class IndexOptions(ctypes.Structure):

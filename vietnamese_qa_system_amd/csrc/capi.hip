@@ -841,6 +841,17 @@ extern "C" int vqa_index_launch_info(const vqa_index* ix, int32_t B, int32_t k, 
     out->flops_per_launch = 2 * (int64_t)VQA_QUERY_TILE * out->rows_per_launch * (int64_t)ix->d;
     out->seed_grid = p.grid0;
     out->seed_tiles = p.seed_tiles;
+    out->scan_kernel = 0;
+    if (out->sketch_scan && ix->sketch_regq && !ix->per_row) {  // the rule of vqa_sketch_regq_applies for this shard's scans
+        ScoreTopkArgs a;
+        SketchScanArgs sk;
+        a.sketch = &sk;
+        a.d_pad = ix->d_pad8;
+        a.tile_begin = 0;
+        a.tile_end = p.tiles;
+        a.grid = p.grid1;
+        out->scan_kernel = vqa_sketch_regq_applies(a) ? 1 : 0;
+    }
     return VQA_OK;
 }
 

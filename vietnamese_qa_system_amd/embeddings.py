@@ -120,10 +120,17 @@ class Embeddings:
             out.append(d)
         return out
 
+    def _model_dir(self) -> Optional[str]:
+        """``path=`` as a local directory: the directory itself, or the hub name's snapshot in the local Hugging Face /
+        sentence-transformers cache (``pretrained.resolve_model_path``: the reference passes hub names, ``heavy_ranker.py:80,83``)."""
+        from .pretrained import resolve_model_path
+        return resolve_model_path(self.path) if self.path else None
+
     def _encoder_from_path(self):
         """``path=<local model directory>`` -> ``TextEncoder`` over the HIP encoder (built once, on first use)."""
         from .encoder import QuestionEncoder, TextEncoder
-        enc = QuestionEncoder.from_pretrained(self.path, device=self.device, max_tokens=self.max_tokens)
+        model_dir = self._model_dir()
+        enc = QuestionEncoder.from_pretrained(model_dir, device=self.device, max_tokens=self.max_tokens)
         self._auto_encoder_path = self.path  # (load() of an index built with another model drops this encoder)
         tok = self.tokenizer
         if tok is None:
@@ -131,7 +138,7 @@ class Embeddings:
                 from transformers import AutoTokenizer  # host-side tokenisation only; the forward is ours
             except ImportError as e:  # pragma: no cover
                 raise RuntimeError("no tokenizer= was given and transformers is not importable for AutoTokenizer") from e
-            hf_tok = AutoTokenizer.from_pretrained(self.path)
+            hf_tok = AutoTokenizer.from_pretrained(model_dir)
             cap = max(8, min(128, int(enc.config["max_pos"]) - 2 - int(enc.config["pad_id"])))
 
             def tok(texts):
@@ -143,12 +150,12 @@ class Embeddings:
         return TextEncoder(tok, enc, pooling=self.pooling, normalize=self.normalize or bool(enc.normalize))
 
     def _encode(self, texts: List[str]) -> torch.Tensor:
-        if self.encoder is None and self.path and os.path.isdir(str(self.path)):
+        if self.encoder is None and self._model_dir():
             self.encoder = self._encoder_from_path()
         if self.encoder is None:
             raise RuntimeError("this Embeddings object has no text encoder: pass encoder= (see encoder.TextEncoder), a path= that is "
-                               f"a local model directory (path={self.path!r} is not one: hub names cannot be fetched here), "
-                               "or index/search with vectors")
+                               f"a local model directory or a hub name already in the local Hugging Face cache (path={self.path!r} is "
+                               "neither: nothing can be downloaded here), or index/search with vectors")
         v = self.encoder(texts)
         if not isinstance(v, torch.Tensor) or v.dim() != 2 or v.shape[0] != len(texts):
             raise ValueError("encoder must return a [len(texts), d] tensor")
@@ -371,7 +378,7 @@ class Embeddings:
             return False
         if not hybrid_ok and self.hybrid and self._sparse is not None and 0.0 < self.weights < 1.0:
             return False
-        if self.encoder is None and self.path and os.path.isdir(str(self.path)):
+        if self.encoder is None and self._model_dir():
             self.encoder = self._encoder_from_path()
         enc = self.encoder
         return isinstance(enc, TextEncoder) and isinstance(enc.encoder, QuestionEncoder) and enc.encoder.device == self.device

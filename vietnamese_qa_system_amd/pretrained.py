@@ -172,3 +172,66 @@ def load_pretrained(model_dir: str) -> Tuple[Dict[str, np.ndarray], dict, Option
         raise KeyError(f"{tdir}: found {len(weights)} encoder tensors, a {cfg['layers']}-layer model has {need} "
                        f"(first names seen: {sorted(raw)[:4]})")
     return weights, cfg, pooling, normalize
+
+
+# ---- hub names, offline -------------------------------------------------------------------------------------------------------
+def _hub_cache_roots():
+    """Directories a Hugging Face / sentence-transformers install keeps downloaded models in, most specific first."""
+    env, home = os.environ, os.path.expanduser("~")
+    roots = []
+    for var in ("SENTENCE_TRANSFORMERS_HOME", "HF_HUB_CACHE", "HUGGINGFACE_HUB_CACHE", "TRANSFORMERS_CACHE"):
+        if env.get(var):
+            roots.append(env[var])
+    if env.get("HF_HOME"):
+        roots.append(os.path.join(env["HF_HOME"], "hub"))
+    xdg = env.get("XDG_CACHE_HOME") or os.path.join(home, ".cache")
+    roots += [os.path.join(xdg, "huggingface", "hub"), os.path.join(xdg, "torch", "sentence_transformers")]
+    seen, out = set(), []
+    for r in roots:
+        if r and r not in seen:
+            seen.add(r)
+            out.append(r)
+    return out
+
+
+def resolve_model_path(path) -> Optional[str]:
+    """``path=`` of the reference's constructor -> a local model directory, or None.
+
+    ``heavy_ranker.py:80,83`` pass HUB NAMES (``"sentence-transformers/paraphrase-multilingual-MiniLM-L12-v2"``).  There is no network
+    here, but a model that was downloaded once sits in the local cache; this looks where the hub client and sentence-transformers
+    put it, without importing either:
+
+      <root>/models--{org}--{name}/snapshots/<revision>/config.json     huggingface_hub (``$HF_HUB_CACHE``, ``$HF_HOME/hub``,
+                                                                        ``~/.cache/huggingface/hub``, ``$SENTENCE_TRANSFORMERS_HOME``);
+                                                                        the revision ``refs/main`` names, else the newest snapshot
+      <root>/{org}_{name}/config.json                                   sentence-transformers <= 2.2 (``~/.cache/torch/sentence_transformers``)
+
+    A directory is returned as it is.  A bare name (no ``/``) is tried under the ``sentence-transformers`` organisation too, as that
+    library does."""
+    if path is None:
+        return None
+    p = str(path)
+    if os.path.isdir(p):
+        return p
+    if not p or p.startswith((".", os.sep)) or p.count("/") > 1 or "\\" in p:
+        return None  # a file-system path that does not exist, not a hub name
+    names = [p] if "/" in p else [p, "sentence-transformers/" + p]
+    for name in names:
+        org, _, model = name.rpartition("/")
+        for root in _hub_cache_roots():
+            hub = os.path.join(root, "models--" + (org + "--" if org else "") + model)
+            snaps = os.path.join(hub, "snapshots")
+            if os.path.isdir(snaps):
+                cands = []
+                ref = os.path.join(hub, "refs", "main")
+                if os.path.isfile(ref):
+                    with open(ref) as f:
+                        cands.append(os.path.join(snaps, f.read().strip()))
+                cands += sorted((os.path.join(snaps, d) for d in os.listdir(snaps)), key=lambda d: -os.path.getmtime(d))
+                for c in cands:
+                    if os.path.isfile(os.path.join(c, "config.json")):
+                        return c
+            flat = os.path.join(root, (org + "_" if org else "") + model)
+            if os.path.isfile(os.path.join(flat, "config.json")):
+                return flat
+    return None

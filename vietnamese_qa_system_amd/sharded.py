@@ -15,8 +15,20 @@ from __future__ import annotations
 import os
 from typing import Callable, Optional, Tuple
 
-import torch
-import torch.distributed as dist
+
+def ensure_multi_process_gpu_env() -> None:
+    """A multi-rank job on this driver needs dmabuf IPC (``HSA_ENABLE_IPC_MODE_LEGACY=0``): in the legacy mode RCCL's intra-node
+    transport fails with ``hipIpcGetMemHandle: invalid argument``.  The variable is read when the HSA runtime initialises, so it is
+    set here -- at import, before this process has made a GPU call -- whenever a distributed launcher started this process
+    (RANK / WORLD_SIZE in the environment) and the caller has not decided otherwise.  (bench.py does the same for itself; an already initialised GPU is left alone.)"""
+    if "WORLD_SIZE" in os.environ and "RANK" in os.environ:  # started by a distributed launcher (any world size: a group of one rank runs the same RCCL calls)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+ensure_multi_process_gpu_env()
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
