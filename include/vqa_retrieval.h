@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VQA_VERSION 113 /* 0.1.13: vqa_index_options.sketch_regq (csrc/scan_regq.hip); 0.1.12: vqa_index_options.one_launch (vqa_index_search_host of a small fp16 shard is one kernel); 0.1.11: vqa_encoder_forward_host, device queries in vqa_index_search_host; 0.1.10: vqa_index_search_host; 0.1.9: vqa_index_options / vqa_index_create_ex, vqa_encoder_options / vqa_encoder_create_ex (no environment variable is read any more), vqa_launch_info.levels; 0.1.8: vqa_encoder_forward_hidden; 0.1.7: vqa_index_get_sketch_split; 0.1.6: vqa_index_sketch_stats, vqa_index_get_sketch_tile; 0.1.5: vqa_index_sketch_state; 0.1.4: VQA_INDEX_RESCORE_ROWS, vqa_index_device_bytes; 0.1.3: VQA_INDEX_SKETCH */
+#define VQA_VERSION 113 /* 0.1.13: vqa_index_options.sketch_regq (csrc/scan_regq.hip), .final_rescore, vqa_launch_info.scan_kernel, vqa_index_sketch_pause; 0.1.12: vqa_index_options.one_launch (vqa_index_search_host of a small fp16 shard is one kernel); 0.1.11: vqa_encoder_forward_host, device queries in vqa_index_search_host; 0.1.10: vqa_index_search_host; 0.1.9: vqa_index_options / vqa_index_create_ex, vqa_encoder_options / vqa_encoder_create_ex (no environment variable is read any more), vqa_launch_info.levels; 0.1.8: vqa_encoder_forward_hidden; 0.1.7: vqa_index_get_sketch_split; 0.1.6: vqa_index_sketch_stats, vqa_index_get_sketch_tile; 0.1.5: vqa_index_sketch_state; 0.1.4: VQA_INDEX_RESCORE_ROWS, vqa_index_device_bytes; 0.1.3: VQA_INDEX_SKETCH */
 
 /* error codes */
 #define VQA_OK 0
@@ -116,8 +116,9 @@ typedef struct vqa_index_options {
     int32_t sketch_cooldown;      /* [64] base length of the pause after an overflow, in searches (0: no pause) */
     float sketch_profit;          /* [-1: by type -- 0.75 fp16, 4 fp32] factor f of the profitability rule (pause when a query tile scores
                                    * more than f n - 4e5 pairs exactly); 0: never */
-    int32_t rescore_copy;         /* with VQA_INDEX_RESCORE_ROWS: [-1] take the copy only if an eighth of the device's memory stays free
-                                   * behind it, 1: whenever the allocation succeeds */
+    int32_t rescore_copy;         /* [-1] with VQA_INDEX_RESCORE_ROWS: take the copy only if an eighth of the device's memory stays free
+                                   * behind it; 1: ask for the copy (sets the flag) and take it whenever the allocation succeeds;
+                                   * 0: no copy, whatever the flag says */
     int32_t poison_workspace;     /* [-1: no] 0..255: fill every workspace with this byte at create (tests: nothing may read what no launch wrote) */
     int32_t one_launch;           /* [1] vqa_index_search_host on an fp16 / fp32 shard of <= 262 144 rows with <= 16 questions, k <= 32 and questions x k <= 64 runs the whole
                                    * search -- normalise, score, select, merge -- as ONE kernel (csrc/tiny_search.hip; the reference's call:
@@ -125,6 +126,11 @@ typedef struct vqa_index_options {
     int32_t sketch_regq;          /* [1] int8 sketch scans of rows of 768 / 384 elements run the register-resident-query kernel (csrc/scan_regq.hip:
                                    * the query tile is loaded once per launch instead of once per corpus tile); 0: score_topk.hip's slot loop
                                    * (same candidate pairs, same results; A/B switch) */
+    int32_t final_rescore;        /* [1] fp16 / fp32 shards of the size at which a sketch search exists for the type (16 / 8 tiles of 256 rows per
+                                   * compute unit: 1.05M / 0.52M rows; or stage_min_tiles when given): every EXACT path (sketch paused or off,
+                                   * overflow fallback) ends by scoring its rows in the sketch path's re-scoring arithmetic and re-ranking them,
+                                   * so both paths return the same bits (k <= 10: over the scan's k + 2 best rows; rows that tie with the k-th
+                                   * beyond those two can still differ); 0: the MFMA sums as they are */
 } vqa_index_options;
 void vqa_index_options_init(vqa_index_options* opt);
 /* vqa_index_create with explicit options (`flags` travel inside them); opt == NULL: the defaults */
@@ -164,6 +170,11 @@ int64_t vqa_index_device_bytes(const vqa_index* index);
  * time -- captured outside a pause: the sketch search with its gated fallback (an overflow inside a replay takes the fallback,
  * correct results, and no pause ever starts because no host code runs); captured inside a pause: the exact scan. */
 int32_t vqa_index_sketch_state(const vqa_index* index);
+/* Pause the sketch of this handle for (at least) its next `searches` searches (they take the exact scan; 0 ends a pause at once).  What the
+ * handle does by itself after an overflow, at the caller's request: for data the caller knows the bound cannot prune, and for tests /
+ * benchmarks that want the exact path of the SAME handle (since 0.1.13 both paths return the same bits on the shards that have both:
+ * vqa_index_options.final_rescore).  VQA_EINVAL for a shard without a sketch.  Not thread-safe against a concurrent search. */
+int vqa_index_sketch_pause(vqa_index* index, int32_t searches);
 /* Diagnostics of the sketch search; both SYNCHRONISE the device (never call them between the searches of a timed loop).
  * vqa_index_sketch_stats: what the last search of this handle left in its candidate buffers -- out[8] = { candidate pairs of the last
  * sketch scan (of a cascade: its second, main scan) of the call's last query tile, the fullest workgroup region of that scan, pairs

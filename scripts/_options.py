@@ -6,7 +6,7 @@ ENV_TO_OPTION = {"VQA_STAGE_MIN": "stage_min_tiles", "VQA_STAGE_PCT": "stage_pct
                  "VQA_SKETCH_PRE_K": "sketch_pre_k", "VQA_POISON_WORKSPACE": "poison_workspace", "VQA_ONE_LAUNCH": "one_launch", "VQA_SKETCH_CENTER": "sketch_center",
                  "VQA_SKETCH_PER_ROW": "sketch_per_row", "VQA_SKETCH_ROTATE": "sketch_rotate", "VQA_SKETCH_COOLDOWN": "sketch_cooldown",
                  "VQA_SKETCH_PROFIT": "sketch_profit", "VQA_SKETCH_SPLIT": "sketch_split", "VQA_SKETCH_SX": "sketch_ring_stages",
-                 "VQA_F16_LOOP": "f16_loop", "VQA_SKETCH_REGQ": "sketch_regq", "VQA_RESCORE_COPY": "rescore_copy"}
+                 "VQA_F16_LOOP": "f16_loop", "VQA_SKETCH_REGQ": "sketch_regq", "VQA_FINAL_RESCORE": "final_rescore", "VQA_RESCORE_COPY": "rescore_copy"}
 
 
 def options(kv) -> dict:

@@ -31,10 +31,10 @@ __device__ __forceinline__ void grid_barrier(unsigned* counter, unsigned phase) 
             const unsigned members = leaf + 1 < leaves ? kLeaf : G - leaf * kLeaf;
             const unsigned old = __hip_atomic_fetch_add(counter + 32 * (1 + leaf), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (old + 1 == (phase + 1) * members) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (phase + 1) * leaves) __builtin_amdgcn_s_sleep(1);
+            for (unsigned spin = 0; spin < (1u << 22) && __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (phase + 1) * leaves; ++spin) __builtin_amdgcn_s_sleep(1);
         } else {
             __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (phase + 1) * G) __builtin_amdgcn_s_sleep(1);
+            for (unsigned spin = 0; spin < (1u << 22) && __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (phase + 1) * G; ++spin) __builtin_amdgcn_s_sleep(1);
         }
     }
     __syncthreads();
@@ -85,6 +85,7 @@ static void run(const char* name, int G, int wbytes) {
     const int units = 4096;  // 64 KB of activations
     hipMalloc(&counter, 8192); hipMalloc(&sink, 64);
     if (DATA == 2) { hipExtMallocWithFlags((void**)&x, units * 16, hipDeviceMallocFinegrained); hipExtMallocWithFlags((void**)&y, units * 16, hipDeviceMallocFinegrained); }
+    else if (DATA == 3) { hipExtMallocWithFlags((void**)&x, units * 16, hipDeviceMallocUncached); hipExtMallocWithFlags((void**)&y, units * 16, hipDeviceMallocUncached); }
     else { hipMalloc(&x, units * 16); hipMalloc(&y, units * 16); } hipMalloc(&w, (size_t)16 * (wbytes ? wbytes : 16));
     hipMemset(x, 0, units * 16); hipMemset(y, 0, units * 16); hipMemset(w, 1, (size_t)16 * (wbytes ? wbytes : 16));
     const int P = 500;
@@ -116,6 +117,8 @@ int main() {
         run<1, 1, 0>("coherent load + store + fenced barrier", G, 0);
         run<0, 1, 0>("... + weights read inside the phase", G, 4 << 20);
         run<0, 1, 1>("... + weights requested before the barrier wait", G, 4 << 20);
+        run<0, 3, 0>("UNCACHED buffers, plain load + store + fence-free barrier", G, 0);
+        run<0, 3, 1>("UNCACHED buffers, plain accesses, weights prefetched", G, 4 << 20);
         run<2, 0, 0>("barrier only, fence-free tree", G, 0);
         run<2, 1, 0>("coherent load + store + tree barrier", G, 0);
         run<2, 1, 0>("... + weights read inside the phase", G, 4 << 20);

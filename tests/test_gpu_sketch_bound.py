@@ -568,7 +568,9 @@ def test_a_search_that_scores_too_many_pairs_pauses_the_sketch_without_overflowi
         s2, _, p2 = ske.search(q, k, return_positions=True)  # inside the pause: the exact scan
         torch.cuda.synchronize()
         if want_pause:
-            assert torch.equal(s2, s0) and torch.equal(p2, p0)
+            # (both exact scans end in the re-scoring arithmetic: the same bits -- tests/test_gpu_determinism.py; against the SKETCH search the
+            # 11 000 near-duplicates per query are more near-ties of the k-th row than the k + 2 rows an exact scan re-ranks can cover)
+            assert torch.equal(s2, s0) and torch.equal(p2, p0) and (s2 - s1).abs().max().item() < 1e-6
         else:
             assert torch.equal(s2, s1) and torch.equal(p2, p1)
         ske.close()

@@ -133,7 +133,7 @@ def test_embeddings_loads_the_model_named_by_path(native_lib, golden_dir):
     got = encb.forward(gb["input_ids"], gb["attention_mask"], pooling="mean", normalize=False).cpu().numpy()
     assert np.abs(got - gb["mean_pooled"]).max() < 1.2e-2  # BOUNDS["tiny_raw"]
     encb.close()
-    with pytest.raises(RuntimeError, match="hub names"):
+    with pytest.raises(RuntimeError, match="local Hugging Face cache"):  # (not in any local cache either: tests above plant one)
         Embeddings(path="sentence-transformers/paraphrase-multilingual-MiniLM-L12-v2").index([{"id": 1, "text": "q"}])
 
 

@@ -28,7 +28,7 @@ DTYPE_BYTES = {VQA_F32: 4, VQA_F16: 2, VQA_FP8_E4M3: 1}
 # every symbol include/vqa_retrieval.h declares (tests/test_capi_symbols.py checks the two lists agree)
 EXPORTS = (
     "vqa_version", "vqa_last_error", "vqa_index_create", "vqa_index_options_init", "vqa_index_create_ex", "vqa_index_set_rows", "vqa_index_get_rows", "vqa_index_destroy", "vqa_index_size", "vqa_index_dim",
-    "vqa_index_dtype", "vqa_index_device_bytes", "vqa_index_sketch_state", "vqa_index_sketch_stats", "vqa_index_get_sketch_tile", "vqa_index_get_sketch_split", "vqa_index_search", "vqa_index_search_host", "vqa_merge_topk", "vqa_index_launch_info", "vqa_index_set_timing",
+    "vqa_index_dtype", "vqa_index_device_bytes", "vqa_index_sketch_state", "vqa_index_sketch_pause", "vqa_index_sketch_stats", "vqa_index_get_sketch_tile", "vqa_index_get_sketch_split", "vqa_index_search", "vqa_index_search_host", "vqa_merge_topk", "vqa_index_launch_info", "vqa_index_set_timing",
     "vqa_index_get_timing", "vqa_encoder_create", "vqa_encoder_options_init", "vqa_encoder_create_ex",
     "vqa_encoder_destroy", "vqa_encoder_forward", "vqa_encoder_forward_host", "vqa_encoder_forward_hidden", "vqa_normalize_convert",
 )
@@ -53,7 +53,7 @@ class IndexOptions(ctypes.Structure):
         "sketch_center", "sketch_split", "sketch_per_row", "sketch_ring_stages", "sketch_mid_k", "sketch_mid_min_tiles", "sketch_mid_pct",
         "sketch_pre_k", "sketch_cooldown")] + [("sketch_profit", ctypes.c_float), ("rescore_copy", ctypes.c_int32),
                                                ("poison_workspace", ctypes.c_int32), ("one_launch", ctypes.c_int32),
-                                               ("sketch_regq", ctypes.c_int32)]
+                                               ("sketch_regq", ctypes.c_int32), ("final_rescore", ctypes.c_int32)]
 
 
 class EncoderOptions(ctypes.Structure):
@@ -126,6 +126,8 @@ def load() -> ctypes.CDLL:
     lib.vqa_index_device_bytes.restype = c.c_int64
     lib.vqa_index_sketch_state.argtypes = [c.c_void_p]
     lib.vqa_index_sketch_state.restype = c.c_int32
+    lib.vqa_index_sketch_pause.argtypes = [c.c_void_p, c.c_int32]
+    lib.vqa_index_sketch_pause.restype = c.c_int
     lib.vqa_index_sketch_stats.argtypes = [c.c_void_p, c.POINTER(c.c_int64)]
     lib.vqa_index_get_sketch_tile.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p]
     lib.vqa_index_get_sketch_split.argtypes = [c.c_void_p, c.c_int64, c.c_void_p, c.c_void_p, c.c_void_p, c.c_void_p]

@@ -92,6 +92,13 @@ struct vqa_index {
     float* thr_seed = nullptr;   // [256] the cascade's theta0 (k-th largest exact seed, MFMA arithmetic): kept for its exact fallback
     vqa_key* upper = nullptr;    // [256] last key returned per query (continuation passes of a search with k > 12)
     int* wide_flag = nullptr;    // 1 = the one-pass large-k result could not be verified: the gated continuation passes run
+    // the exact paths' final re-scoring on large fp16 / fp32 shards (sketch.hip final_rescore_kernel): where the merge of an exact scan leaves its
+    // rows before they are scored by the re-scoring arithmetic and re-ranked into the caller's arrays
+    float* fin_scores = nullptr;   // [256][VQA_MAX_K_TOTAL]
+    int64_t* fin_ids = nullptr;    // [256][VQA_MAX_K_TOTAL]
+    int64_t* fin_pos = nullptr;    // [256][VQA_MAX_K_TOTAL]
+    bool final_fma = true;         // options.final_rescore
+    int fin_min_tiles = 0;         // ... from this many tiles per workgroup on (0: never)
     bool wide = true;            // options.wide_k = 0 disables the one-pass large-k attempt
     // int8 sketch of a large fp16 shard (VQA_INDEX_SKETCH): the rigorous pruning pre-pass of the main launch (score_topk.hip MODE 2)
     bool sketch = false;
@@ -222,6 +229,9 @@ extern "C" void vqa_index_destroy(vqa_index* ix) {
     if (ix->thr_seed) (void)hipFree(ix->thr_seed);
     if (ix->upper) (void)hipFree(ix->upper);
     if (ix->wide_flag) (void)hipFree(ix->wide_flag);
+    if (ix->fin_scores) (void)hipFree(ix->fin_scores);
+    if (ix->fin_ids) (void)hipFree(ix->fin_ids);
+    if (ix->fin_pos) (void)hipFree(ix->fin_pos);
     for (hipEvent_t e : ix->ev) (void)hipEventDestroy(e);
     delete ix;
 }
@@ -397,6 +407,7 @@ extern "C" void vqa_index_options_init(vqa_index_options* o) {
     o->poison_workspace = -1;
     o->one_launch = 1;
     o->sketch_regq = 1;
+    o->final_rescore = 1;
 }
 
 // -DVQA_DEV variant libraries only (scripts/: ab_loops.py, probes): the rounds-1-4 environment switches laid over the options
@@ -426,6 +437,7 @@ static void dev_env_overlay(vqa_index_options* o) {
     geti("VQA_RESCORE_COPY", &o->rescore_copy);
     geti("VQA_ONE_LAUNCH", &o->one_launch);
     geti("VQA_SKETCH_REGQ", &o->sketch_regq);
+    geti("VQA_FINAL_RESCORE", &o->final_rescore);
     if (const char* v = vqa_dev_env("VQA_POISON_WORKSPACE")) o->poison_workspace = (int)strtol(v, nullptr, 0) & 0xFF;
     if (const char* v = vqa_dev_env("VQA_SKETCH")) {
         if (v[0] == '0') o->flags &= ~(uint32_t)VQA_INDEX_SKETCH;
@@ -453,7 +465,8 @@ extern "C" int vqa_index_create_ex(vqa_index** out, int device, int64_t n, int32
         o.struct_size = (uint32_t)sizeof(o);
     }
     dev_env_overlay(&o);
-    const uint32_t flags = o.flags;
+    // rescore_copy = 0: no row-major copy whatever the flag says (rounds 1-4 meaning of VQA_RESCORE_COPY=0); 1: the flag + no free-memory rule
+    const uint32_t flags = o.rescore_copy == 0 ? (o.flags & ~(uint32_t)VQA_INDEX_RESCORE_ROWS) : o.rescore_copy == 1 ? (o.flags | VQA_INDEX_RESCORE_ROWS) : o.flags;
     VQA_REQUIRE(o.seed_mult >= 1 && o.seed_mult <= 4, "vqa_index_create_ex: seed_mult=%d outside [1, 4]", o.seed_mult);
     VQA_REQUIRE(o.seed_div >= 0, "vqa_index_create_ex: seed_div=%d", o.seed_div);
     VQA_REQUIRE(o.stage_pct >= 1 && o.stage_pct <= 50, "vqa_index_create_ex: stage_pct=%d outside [1, 50]", o.stage_pct);
@@ -501,6 +514,9 @@ extern "C" int vqa_index_create_ex(vqa_index** out, int device, int64_t n, int32
     ix->seed_mult = o.seed_mult;
     const bool stage_given = o.stage_min_tiles >= 0;  // (tests, A/B runs: a plan forced at a size production would not pick it at)
     ix->stage_min_tiles = stage_given ? o.stage_min_tiles : kPlan.stage_min_plain;
+    // shard size (tiles per workgroup) from which a shard of this type CAN have two answer paths -- where a sketch index of the type starts its
+    // sketch search: from there on every exact path ends in the re-scoring arithmetic (final_rescore_applies), with or without a sketch
+    ix->fin_min_tiles = stage_given ? o.stage_min_tiles : dtype == VQA_F32 ? kPlan.stage_min_f32_sketch : kPlan.stage_min_f16_sketch;
     ix->stage_pct = o.stage_pct;
     ix->f16_loop = o.f16_loop;
     const int eb = elem_bytes(dtype);
@@ -538,11 +554,16 @@ extern "C" int vqa_index_create_ex(vqa_index** out, int device, int64_t n, int32
             hipMalloc((void**)&ix->thr0, VQA_QUERY_TILE * sizeof(float)) != hipSuccess ||
             hipMalloc((void**)&ix->thr_seed, VQA_QUERY_TILE * sizeof(float)) != hipSuccess ||
             hipMalloc((void**)&ix->upper, VQA_QUERY_TILE * sizeof(vqa_key)) != hipSuccess ||
-            hipMalloc((void**)&ix->wide_flag, sizeof(int)) != hipSuccess) {
+            hipMalloc((void**)&ix->wide_flag, sizeof(int)) != hipSuccess ||
+            ((dtype == VQA_F16 || dtype == VQA_F32) &&
+             (hipMalloc((void**)&ix->fin_scores, (size_t)VQA_QUERY_TILE * VQA_MAX_K_TOTAL * 4) != hipSuccess ||
+              hipMalloc((void**)&ix->fin_ids, (size_t)VQA_QUERY_TILE * VQA_MAX_K_TOTAL * 8) != hipSuccess ||
+              hipMalloc((void**)&ix->fin_pos, (size_t)VQA_QUERY_TILE * VQA_MAX_K_TOTAL * 8) != hipSuccess))) {
             vqa_set_error("vqa_index_create: workspace allocation failed");
             rc = VQA_ENOMEM;
             break;
         }
+        ix->final_fma = o.final_rescore != 0;
         // int8 sketch: fp16 shards only, and only where a workgroup's tile maxima fit the scan's LDS
         // (and only for shards large enough for the two-stage search, whose main launch the sketch scan replaces)
         // fp32 shards: the exact scan runs at 1/16 of the fp16 matrix rate, the sketch scan at the same int8 rate: the
@@ -738,6 +759,18 @@ extern "C" int32_t vqa_index_sketch_state(const vqa_index* ix) {
     return ix->sketch_cooldown;
 }
 
+extern "C" int vqa_index_sketch_pause(vqa_index* ix, int32_t searches) {
+    VQA_REQUIRE(ix, "vqa_index_sketch_pause: index is null");
+    VQA_REQUIRE(ix->sketch, "vqa_index_sketch_pause: the shard keeps no sketch");
+    VQA_REQUIRE(searches >= 0, "vqa_index_sketch_pause: searches=%d", searches);
+    HandleBusy busy(ix->busy);
+    VQA_REQUIRE(busy.ok, "vqa_index_sketch_pause: this index handle is in use by another host thread");
+    ix->sketch_cooldown = searches > 0 ? searches + 1 : 0;  // (a search decrements the counter BEFORE it looks at it)
+    ix->pause_min_k = 0;                        // every k
+    ix->sketch_seq_ignore = ix->sketch_seq;     // reports of searches already queued say nothing about this pause
+    return VQA_OK;
+}
+
 extern "C" int64_t vqa_index_device_bytes(const vqa_index* ix) {
     if (!ix) return -1;
     int64_t b = (int64_t)ix->rows_bytes + (ix->ids ? ix->n * 8 : 0);
@@ -819,6 +852,13 @@ static LaunchPlan plan_launch(const vqa_index* ix, int k = 0) {
         }
     }
     return p;
+}
+
+// the exact paths of this shard end in the re-scoring arithmetic (sketch.hip final_rescore_kernel): fp16 / fp32 shards of the size at which
+// a sketch search can exist beside the exact scan (whether or not THIS handle keeps a sketch: `sketch=False` answers in the same bits)
+static bool final_rescore_applies(const vqa_index* ix, const LaunchPlan& p) {
+    return ix->final_fma && ix->fin_pos && (ix->dtype == VQA_F16 || ix->dtype == VQA_F32) && ix->scale == 1.0f && ix->fin_min_tiles > 0 &&
+           (long long)p.tiles >= (long long)ix->fin_min_tiles * ix->max_grid;
 }
 
 static bool sketch_active(const vqa_index* ix, const LaunchPlan& p, int k) {
@@ -1031,7 +1071,9 @@ extern "C" int vqa_index_search_host(vqa_index* ix, const void* q_host, int32_t 
     const size_t q_off = 0, s_off = (qbytes + 63) / 64 * 64, i_off = s_off + (nres * 4 + 63) / 64 * 64, p_off = i_off + nres * 8;
     const size_t need = p_off + nres * 8;
     // one launch for the whole call where K4 applies (tiny_search.hip); `timing` handles time the scan kernel of the general path
-    const bool one_launch = ix->one_launch && !ix->timing && !ix->sketch && ix->scale == 1.0f && vqa_tiny_search_applies(ix->dtype, ix->n, ix->d_pad, B, k);
+    // (a shard on the two-stage plan -- only tests bring that down to this size -- answers in the re-scoring arithmetic: the general launches)
+    const bool one_launch = ix->one_launch && !ix->timing && !ix->sketch && ix->scale == 1.0f && vqa_tiny_search_applies(ix->dtype, ix->n, ix->d_pad, B, k) &&
+                            !final_rescore_applies(ix, plan_launch(ix, k));
     if (one_launch && !ix->tiny_ws) {
         const size_t ws = vqa_tiny_search_workspace_bytes();
         if (hipMalloc(&ix->tiny_ws, ws) != hipSuccess) {
@@ -1110,6 +1152,10 @@ extern "C" int vqa_index_search_host(vqa_index* ix, const void* q_host, int32_t 
     }
     if (st != hipSuccess) {
         vqa_set_error("vqa_index_search_host: waiting for the search failed: %s", hipGetErrorString(st));
+        // a one-launch search that died between its ticket and the ticket's reset would leave the NEXT call's last workgroup undetected
+        // (stale pinned results returned as VQA_OK): the workspace starts from zero again (best effort: the device may be gone)
+        if (one_launch && ix->tiny_ws) (void)hipMemset(ix->tiny_ws, 0, vqa_tiny_search_workspace_bytes());
+        (void)hipGetLastError();
         return VQA_EHIP;
     }
     memcpy(out_scores, h + s_off, nres * 4);
@@ -1210,6 +1256,12 @@ static int search_impl(vqa_index* ix, const void* q, int32_t q_dtype, int32_t B,
         // the device and raises wide_flag.  The exact continuation passes below are then launched GATED on the flag: they
         // return at once when the one-pass result stands (no host round trip), and overwrite it when it does not.
         const int* gate = nullptr;
+        // Large fp16 / fp32 shards (the size at which a sketch search can exist for the type): every exact path ends by scoring its rows in
+        // the re-scoring kernel's arithmetic and re-ranking them (sketch.hip final_rescore_kernel), so that the exact scan -- during a
+        // pause of the sketch, behind an overflow, with the sketch off -- returns the bits the sketch path returns.  One pass (k <= 10):
+        // the scan keeps k + 2 rows per query, so rows the MFMA order ranks just below the k-th compete too.
+        const bool fin = final_rescore_applies(ix, p);
+        int64_t* const wide_pos = fin && k > max_k ? (op ? op : ix->fin_pos) : op;  // k > 12: the passes' rows, re-scored in place at the end
         MergeSketchTail cascade_report;  // (set by the cascade: the report its fallback's first merge carries)
         if (any_sketch && ix->cascade) {
             // A sketch shard, k <= 64, as a cascade of bounds -- no exact scan of a first stage at all:
@@ -1269,10 +1321,15 @@ static int search_impl(vqa_index* ix, const void* q, int32_t q_dtype, int32_t B,
                 a.gate = ix->sketch_flag;
                 rc = vqa_launch_score_topk(ix->dtype, a, stream);
                 if (rc != VQA_OK) return rc;
-                rc = vqa_launch_merge_partials(ix->partial, p.grid1, k, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr,
+                int64_t* fpos = fin ? (op ? op : ix->fin_pos) : op;  // (the final re-scoring reads the rows' positions)
+                rc = vqa_launch_merge_partials(ix->partial, p.grid1, k, nq, k, ix->ids, ix->id_base, os, oi, fpos, nullptr,
                                                1.0f / (ix->scale * ix->scale), k, 0, nullptr, true, ix->sketch_flag, stream, 0, nullptr, 1,
                                                &cascade_report);
                 if (rc != VQA_OK) return rc;
+                // the fallback's rows in the sketch path's arithmetic (gated like the fallback itself)
+                if (fin && (rc = vqa_launch_final_rescore(fpos, k, nq, k, k, ix->rows, nullptr, ix->q_stage, nullptr, ix->dtype, ix->d_pad, ix->ids,
+                                                          ix->id_base, os, oi, op, k, ix->sketch_flag, stream)) != VQA_OK)
+                    return rc;
                 continue;
             }
             gate = ix->sketch_flag;  // larger k: the gated exact passes below
@@ -1288,7 +1345,7 @@ static int search_impl(vqa_index* ix, const void* q, int32_t q_dtype, int32_t B,
             a.seed_only = false;
             rc = vqa_launch_score_topk(ix->dtype, a, stream);
             if (rc != VQA_OK) return rc;
-            rc = vqa_launch_merge_partials(ix->partial, p.grid1, max_k, nq, k, ix->ids, ix->id_base, os, oi, op, nullptr,
+            rc = vqa_launch_merge_partials(ix->partial, p.grid1, max_k, nq, k, ix->ids, ix->id_base, os, oi, wide_pos, nullptr,
                                            1.0f / (ix->scale * ix->scale), k, 0, ix->upper, true, nullptr, stream);
             if (rc != VQA_OK) return rc;
             rc = vqa_launch_verify_wide(ix->partial, p.grid1, max_k, nq, ix->upper, ix->wide_flag, stream);
@@ -1297,8 +1354,9 @@ static int search_impl(vqa_index* ix, const void* q, int32_t q_dtype, int32_t B,
         }
         // Exact passes: k <= 12 needs one; larger k ceil(k / 12), each admitting only keys strictly below the last key already
         // returned (keys are distinct, so the continuation is exact); every pass is a full scan of the shard.
+        const int kx = fin && k + 2 <= max_k && !use_sketch && ix->n >= k + 2 ? 2 : 0;  // margin rows of a one-pass exact search
         for (int done = 0; done < k; done += max_k) {
-            const int kk = k - done < max_k ? k - done : max_k;
+            const int kk = (k - done < max_k ? k - done : max_k) + kx;
             const vqa_key* upper = done > 0 ? ix->upper : nullptr;
             ScoreTopkArgs a = exact_launch_args(ix, nq, kk);
             a.upper = upper;
@@ -1358,12 +1416,23 @@ static int search_impl(vqa_index* ix, const void* q, int32_t q_dtype, int32_t B,
             if (rc != VQA_OK) return rc;
             if (time_it && (rc = timing_event(ix, stream)) != VQA_OK) return rc;
             const bool report_here = cascade_fallback && done == 0;  // (k > 12 behind a cascade: the first gated pass's merge reports)
-            rc = vqa_launch_merge_partials(ix->partial, lists, kk, nq, kk, ix->ids, ix->id_base, os, oi, op, nullptr,
-                                           1.0f / (ix->scale * ix->scale), k, done, done + kk < k ? ix->upper : nullptr, true,
+            const bool one_pass_fin = fin && k <= max_k && !use_sketch;  // its k + kx rows go to the scratch arrays, the re-scoring writes the caller's
+            rc = vqa_launch_merge_partials(ix->partial, lists, kk, nq, kk, ix->ids, ix->id_base, one_pass_fin ? ix->fin_scores : os,
+                                           one_pass_fin ? ix->fin_ids : oi, one_pass_fin ? ix->fin_pos : wide_pos, nullptr,
+                                           1.0f / (ix->scale * ix->scale), one_pass_fin ? kk : k, done, done + kk < k ? ix->upper : nullptr, true,
                                            staged && use_sketch ? ix->sketch_flag : gate, stream, 0, nullptr, 1,
                                            report_here ? &cascade_report : nullptr);
             if (rc != VQA_OK) return rc;
+            if (one_pass_fin && (rc = vqa_launch_final_rescore(ix->fin_pos, kk, nq, kk, k, ix->rows, nullptr, ix->q_stage, nullptr, ix->dtype, ix->d_pad,
+                                                               ix->ids, ix->id_base, os, oi, op, k, gate, stream)) != VQA_OK)
+                return rc;
         }
+        // k > 12: the passes' k rows (the verified one-pass attempt's, or the gated continuation passes') re-scored and re-ranked in place;
+        // behind a cascade the passes only ran if its flag is up, and so does this
+        if (fin && k > max_k && !use_sketch &&
+            (rc = vqa_launch_final_rescore(wide_pos, k, nq, k, k, ix->rows, nullptr, ix->q_stage, nullptr, ix->dtype, ix->d_pad, ix->ids, ix->id_base,
+                                           os, oi, op, k, gate == ix->sketch_flag ? gate : nullptr, stream)) != VQA_OK)
+            return rc;
     }
     // the overflow flags of this call (its last tile's, the OR over the earlier ones, the call's number) -> the pinned mirror a later
     // call's cool-down bookkeeping reads

@@ -1803,6 +1803,20 @@ int upload_folded(const float* src, int N, int K, const float* gamma, const floa
 
 constexpr int kTokenPad = 256;  // activation buffers are padded to this many rows (the tallest tile)
 
+// The FFN1 epilogue's GELU table of this device, built once per device at encoder create (built lazily inside the first launch of a
+// shape it sat on the NULL stream with a synchronise -- inside a caller's stream capture that invalidates the capture).
+int ensure_gelu_table() {
+    static VqaPerDeviceOnce once;
+    return once.run([&](int) -> int {
+        if (VQA_GELU_TABLE) {
+            hipLaunchKernelGGL(gelu_table_kernel, dim3(kGeluN / 256), dim3(256), 0, nullptr);
+            VQA_HIP_CHECK(hipGetLastError());
+            VQA_HIP_CHECK(hipStreamSynchronize(nullptr));
+        }
+        return VQA_OK;
+    });
+}
+
 template <int EPI, int BM, int BN, int WM, int WN, int BK, int FOLD = 0, int ONEBAR = 0, int TIL = 0>
 int launch_tile(const _Float16* A, const _Float16* W, const float* bias, const _Float16* R, _Float16* C, int M, int N, int K,
                 int num_cu, hipStream_t s, const FoldArgs& fa = FoldArgs{}) {
@@ -1811,12 +1825,7 @@ int launch_tile(const _Float16* A, const _Float16* W, const float* bias, const _
     int rc = once.run([&](int) -> int {
         VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<EPI, BM, BN, WM, WN, BK, FOLD, ONEBAR, TIL>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, G::kLds));
-        if (EPI == 1 && VQA_GELU_TABLE) {  // the device's GELU table (a first call of a shape is never inside a graph capture)
-            hipLaunchKernelGGL(gelu_table_kernel, dim3(kGeluN / 256), dim3(256), 0, nullptr);
-            VQA_HIP_CHECK(hipGetLastError());
-            VQA_HIP_CHECK(hipStreamSynchronize(nullptr));
-        }
-        return VQA_OK;
+        return VQA_OK;  // (the device's GELU table is built by vqa_encoder_create_ex: ensure_gelu_table)
     });
     if (rc != VQA_OK) return rc;
     const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM, tiles = tiles_n * tiles_m;
@@ -2022,6 +2031,7 @@ extern "C" int vqa_dev_gemm(const void* A, const void* W, const float* bias, con
     const _Float16 *a = (const _Float16*)A, *w = (const _Float16*)W, *r = (const _Float16*)R;
     _Float16* c = (_Float16*)C;
     hipStream_t s = (hipStream_t)stream;
+    if (int grc = ensure_gelu_table(); grc != VQA_OK) return grc;
     hipDeviceProp_t prop;
     int dev = 0;
     VQA_HIP_CHECK(hipGetDevice(&dev));
@@ -2123,6 +2133,7 @@ extern "C" int vqa_encoder_create_ex(vqa_encoder** out, int device, const vqa_en
     }
     VQA_REQUIRE(device >= 0 && device < ndev, "vqa_encoder_create: device %d of %d", device, ndev);
     DevGuard guard(device);
+    if (int grc = ensure_gelu_table(); grc != VQA_OK) return grc;
     vqa_encoder* e = new (std::nothrow) vqa_encoder();
     if (!e) {
         vqa_set_error("vqa_encoder_create: host allocation failed");

@@ -136,6 +136,76 @@ __global__ __launch_bounds__(256) void rescore_kernel(const unsigned long long* 
     }
 }
 
+// ---- the exact paths' last step on a large shard: the rows they selected, scored again in THIS file's arithmetic and re-ranked.
+// A shard large enough for the sketch search has two ways to answer a search -- the sketch cascade (scores = rescore_kernel's fma chain)
+// and the exact scan (scores = MFMA sums; during a pause, behind an overflow, for sketch = off) -- and which one runs can depend on an
+// asynchronous report (include/vqa_retrieval.h: vqa_index_sketch_state).  MFMA sums and the fma chain differ in the last bits, so the
+// two paths could return near-tied rows in another order ("two paths, last-bit different, chosen asynchronously").  Here the
+// exact scan's `kin` best rows per query (kin = k + 2 where the scan's lists have room: rows the MFMA order ranks just below the k-th
+// are candidates too) get the fma-chain score -- the same loads, the same fma order, the same butterfly as rescore_kernel -- and the
+// `kout` best by (that score descending, position ascending) are the result: the same bits the sketch path returns for the same rows.
+// One workgroup per query: a half wave per candidate row, then rank by counting over the <= 1024 keys in LDS.
+template <typename T, bool RM>
+__global__ __launch_bounds__(256) void final_rescore_kernel(const long long* __restrict__ pos_in, int in_stride, int nq, int kin, int kout,
+                                                            const T* __restrict__ X, const T* __restrict__ Q, int KT,
+                                                            const long long* __restrict__ ids, long long id_base,
+                                                            float* __restrict__ out_scores, long long* __restrict__ out_ids,
+                                                            long long* __restrict__ out_pos, int out_stride, const int* __restrict__ gate) {
+    if (gate && *gate == 0) return;
+    constexpr int EPU = 16 / (int)sizeof(T);
+    typedef T unit_t __attribute__((ext_vector_type(EPU)));
+    __shared__ vqa_key keys[VQA_MAX_K_TOTAL];
+    __shared__ long long posv[VQA_MAX_K_TOTAL];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, hl = lane & 31, half = tid >> 5;  // 8 half waves
+    const int units = KT * 4;
+    for (int i = half; i < kin; i += 8) {
+        const long long pos = pos_in[(size_t)q * in_stride + i];
+        float acc = 0.f;
+        if (pos >= 0)
+            for (int u = hl; u < units; u += 32) {
+                const unit_t xw = *reinterpret_cast<const unit_t*>(X + (RM ? (size_t)pos * units + u : unit_of(pos, u, KT)) * EPU);
+                const unit_t qw = *reinterpret_cast<const unit_t*>(Q + (RM ? (size_t)q * units + u : unit_of(q, u, KT)) * EPU);
+#pragma unroll
+                for (int e = 0; e < EPU; ++e) acc = __builtin_fmaf((float)xw[e], (float)qw[e], acc);
+            }
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);  // inside the half wave
+        if (hl == 0) {
+            keys[i] = pos >= 0 ? vqa_make_key(acc, (uint32_t)pos) : 0ull;
+            posv[i] = pos;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < kin; i += 256) {
+        const vqa_key mine = keys[i];
+        if (mine == 0ull) continue;
+        int rank = 0;
+        for (int j = 0; j < kin; ++j) rank += keys[j] > mine ? 1 : 0;  // keys of real rows are distinct (the position is part of the key)
+        if (rank < kout) {
+            const size_t o = (size_t)q * out_stride + rank;
+            const long long pos = posv[i];
+            out_scores[o] = vqa_key_score(mine);
+            out_ids[o] = ids ? ids[pos] : id_base + pos;
+            if (out_pos) out_pos[o] = pos;
+        }
+    }
+    // fewer real rows than kout: padding behind them, as the merges write it
+    __shared__ int nreal;
+    if (tid == 0) nreal = 0;
+    __syncthreads();
+    int mine_real = 0;
+    for (int i = tid; i < kin; i += 256) mine_real += keys[i] != 0ull ? 1 : 0;
+    if (mine_real) atomicAdd(&nreal, mine_real);
+    __syncthreads();
+    for (int r = nreal + tid; r < kout; r += 256) {
+        const size_t o = (size_t)q * out_stride + r;
+        out_scores[o] = -INFINITY;
+        out_ids[o] = -1;
+        if (out_pos) out_pos[o] = -1;
+    }
+}
+
 // rows [first, first + count) of the tiled shard -> the row-major re-scoring copy (rows of KT * 64 bytes, zero padded as stored);
 // one wave per row, 16 bytes per lane and step
 __global__ __launch_bounds__(256) void rows_to_rowmajor_kernel(const uint4* __restrict__ tiled, long long first, long long count, int KT,
@@ -241,6 +311,29 @@ int vqa_launch_rescore(const unsigned long long* regions, const unsigned* counts
     }
 #undef VQA_RESCORE
 #undef VQA_RESCORE_UM
+    VQA_HIP_CHECK(hipGetLastError());
+    return VQA_OK;
+}
+
+int vqa_launch_final_rescore(const int64_t* pos_in, int in_stride, int nq, int kin, int kout, const void* x, const void* x_rowmajor,
+                             const void* q, const void* q_rowmajor, int32_t dtype, int32_t d_pad, const int64_t* ids, int64_t id_base,
+                             float* out_scores, int64_t* out_ids, int64_t* out_pos, int out_stride, const int* gate, hipStream_t stream) {
+    VQA_REQUIRE(dtype == VQA_F16 || dtype == VQA_F32, "final_rescore: storage type %d", dtype);
+    VQA_REQUIRE(kin >= kout && kin <= VQA_MAX_K_TOTAL && kout >= 1, "final_rescore: kin=%d kout=%d", kin, kout);
+    const bool rm = x_rowmajor && q_rowmajor;
+#define VQA_FINAL(T, RMV, XP, QP, KTV)                                                                                                  \
+    hipLaunchKernelGGL((final_rescore_kernel<T, RMV>), dim3(nq), dim3(256), 0, stream, reinterpret_cast<const long long*>(pos_in), in_stride, \
+                       nq, kin, kout, reinterpret_cast<const T*>(XP), reinterpret_cast<const T*>(QP), KTV,                                \
+                       reinterpret_cast<const long long*>(ids), (long long)id_base, out_scores, reinterpret_cast<long long*>(out_ids),     \
+                       reinterpret_cast<long long*>(out_pos), out_stride, gate)
+    if (dtype == VQA_F16) {
+        if (rm) VQA_FINAL(_Float16, true, x_rowmajor, q_rowmajor, d_pad / 32);
+        else VQA_FINAL(_Float16, false, x, q, d_pad / 32);
+    } else {
+        if (rm) VQA_FINAL(float, true, x_rowmajor, q_rowmajor, d_pad / 16);
+        else VQA_FINAL(float, false, x, q, d_pad / 16);
+    }
+#undef VQA_FINAL
     VQA_HIP_CHECK(hipGetLastError());
     return VQA_OK;
 }

@@ -210,6 +210,16 @@ __global__ __launch_bounds__(64 * W) void tiny_search_kernel(const TinyArgs p, c
     // ---- (4) ticket; the last workgroup merges.  The lists are written and read with device-scope accesses and every wave waits for its
     // stores before the barrier in front of the ticket, so no fence is needed: a device-scope release / acquire pair writes back and
     // invalidates the XCD's whole L2, once per workgroup -- 103 us instead of 40 at 131 072 rows.
+    // What this relies on (gfx942 / gfx950 only; outside the HIP memory model, so the file refuses other targets below): a relaxed
+    // agent-scope atomic store / load of 8 bytes is emitted as `global_store_dwordx2 ... sc1` / `global_load_dwordx2 ... sc1`; an sc1
+    // store writes THROUGH this XCD's L2 to the memory side before it retires from vmcnt, and an sc1 load never hits a stale line of
+    // the reader's L2 -- the "every store sc1 and drained with s_waitcnt vmcnt(0) before the counter, every load sc1" hand-off that
+    // /opt/skills/guides/MI355X_MICROARCH.md lists under Correctness boundaries as valid in place of the release / acquire pair.  The
+    // ticket itself is a device-scope atomic at the memory side.  (A launch that aborts between its ticket and the reset below would
+    // leave the ticket non-zero: the host side clears the workspace after any failed call, capi.hip.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "tiny_search.hip: the fence-free hand-off is only argued for gfx942 / gfx950"
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) last_flag = atomicAdd(p.ticket, 1u) == (unsigned)(units - 1) ? 1u : 0u;

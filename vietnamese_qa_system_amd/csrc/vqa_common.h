@@ -283,6 +283,11 @@ int vqa_launch_rescore(const unsigned long long* regions, const unsigned* counts
                        int nq, int k, const void* x, const void* x_rowmajor /* or nullptr: the tiled rows x are read */, const void* q,
                        const void* q_rowmajor /* the staged query tile, row-major (read with x_rowmajor) */, int32_t dtype, int32_t d_pad,
                        vqa_key* cand_keys, unsigned* cand_cnt, int capq, int* overflow, hipStream_t stream);
+// the exact scan's kin best rows per query (positions, -1 = none) scored again by rescore_kernel's fma chain and re-ranked: kout results
+// (scores, external ids, positions) -- the bits the sketch path returns for the same rows (sketch.hip)
+int vqa_launch_final_rescore(const int64_t* pos_in, int in_stride, int nq, int kin, int kout, const void* x, const void* x_rowmajor,
+                             const void* q, const void* q_rowmajor, int32_t dtype, int32_t d_pad, const int64_t* ids, int64_t id_base,
+                             float* out_scores, int64_t* out_ids, int64_t* out_pos, int out_stride, const int* gate, hipStream_t stream);
 // rows [first, first + count) of a tiled shard -> its row-major copy (rows of row_bytes = padded row length in bytes)
 int vqa_launch_rows_to_rowmajor(const void* tiled, int64_t first, int64_t count, int32_t row_bytes, void* out, hipStream_t stream);
 

@@ -97,28 +97,33 @@ def insert_data(database_path: str, table_name: str, data: List[dict], verbose: 
 
 
 # fetch_docs keeps its connection: opening one costs 120 us, the statement 10 -- and the join runs once per search
-# (``heavy_ranker.py:102-108`` runs it once per hit).  One connection per (file, thread), dropped when the file changes.
-_read_connections: dict = {}
+# (``heavy_ranker.py:102-108`` runs it once per hit).  One connection per (file, thread), dropped when the file changes.  The cache is
+# THREAD-LOCAL (a module-wide dict was mutated without a lock and its flush closed other threads' connections, which sqlite3
+# refuses): a thread only ever sees, closes and evicts connections it opened itself, and they go away with the thread.
+_read_local = threading.local()
 
 
 def _read_connection(database_path: str) -> sqlite3.Connection:
+    if not os.path.isfile(database_path):
+        connect_database(database_path)  # (raises the module's own "no such database" assertion, as before the cache existed)
     st = os.stat(database_path)
     signature = (st.st_ino, st.st_mtime_ns, st.st_size)
-    key = (os.path.abspath(database_path), threading.get_ident())
-    hit = _read_connections.get(key)
+    cache = getattr(_read_local, "connections", None)
+    if cache is None:
+        cache = _read_local.connections = {}
+    key = os.path.abspath(database_path)
+    hit = cache.get(key)
     if hit is not None and hit[1] == signature:
         return hit[0]
     if hit is not None:
         hit[0].close()
-    if len(_read_connections) >= 32:  # (a process that walks over many files or threads: start over)
-        for conn, _ in _read_connections.values():
-            try:
-                conn.close()
-            except sqlite3.Error:
-                pass
-        _read_connections.clear()
+        del cache[key]
+    if len(cache) >= 8:  # (a thread that walks over many files: start over -- its own connections only)
+        for conn, _ in cache.values():
+            conn.close()
+        cache.clear()
     connection = connect_database(database_path)
-    _read_connections[key] = (connection, signature)
+    cache[key] = (connection, signature)
     return connection
 
 

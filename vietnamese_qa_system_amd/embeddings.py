@@ -412,13 +412,20 @@ class Embeddings:
         """First half of ``search(query, limit)`` for a caller that asks SEVERAL retrievers the same question (``heavy_ranker.py:98-100``
         asks two, one after the other): the question's encoder forward is enqueued on the current stream and the call returns at once,
         so the forwards of two models -- each far too small to fill the device -- run side by side when the caller gives every
-        retriever a stream of its own (``heavy_ranker.rank_query``).  ``search_end`` completes the call.  Not part of txtai."""
+        retriever a stream of its own (``heavy_ranker.rank_query``).  ``search_end`` completes the call.  Not part of txtai.
+
+        ONE question may be outstanding per object: the returned token's vector lives in this object's single staging buffer, so a second
+        ``search_begin`` before the first token's ``search_end`` is refused (it would overwrite the first question's vector: ADVICE r5)."""
         if self._index is None:
             raise RuntimeError("the index is empty: call index()/load() first")
         if not isinstance(query, str):
             raise ValueError("search_begin() takes one text question")
+        if getattr(self, "_begun", None) is not None:
+            raise RuntimeError("search_begin(): the previous question of this Embeddings object has not been completed by search_end()")
         q = self._encode_texts_fast([query]) if self._text_fast_path([query], hybrid_ok=True) else None
-        return (query, q)
+        token = (query, q)
+        self._begun = token if q is not None else None  # (a question off the fast path holds no buffer)
+        return token
 
     def search_end(self, token, limit: int = 3) -> list:
         """Second half: the search of the vector ``search_begin`` left on the device (waits for it), or the whole ``search`` when the
@@ -426,6 +433,9 @@ class Embeddings:
         query, q = token
         if q is None:
             return self.search(query, limit)
+        if getattr(self, "_begun", None) is not token:
+            raise RuntimeError("search_end(): this token is not the outstanding question of this Embeddings object")
+        self._begun = None
         if not self._text_fast_path([query]):  # hybrid=True: the dense candidates from q, the BM25 half on the host
             return self._hybrid(q, [query], int(limit), host_results=True)[0]
         scores, out_ids = self._index.search_host(q, int(limit), normalize=self.normalize)

@@ -91,6 +91,11 @@ class DeviceIndex:
         # row-major copy of the rows for the sketch search's exact re-scoring (VQA_INDEX_RESCORE_ROWS: +100 % of the rows' memory,
         # re-scoring 3x faster, bit-equal results; kept only where the library keeps a sketch).  Default: shards whose rows take
         # up to RESCORE_COPY_MAX_BYTES (an 80M x 768 fp16 shard on one device does without); VQA_RESCORE_COPY=0 / 1 overrides.
+        # (the argument wins over options["rescore_copy"]; True / 1 forces the copy past the library's free-memory rule, False / 0 forbids it)
+        if rescore_copy is None and int(opts.get("rescore_copy", -1)) in (0, 1):
+            rescore_copy = bool(opts["rescore_copy"])
+        elif rescore_copy is not None:
+            opts["rescore_copy"] = 1 if rescore_copy else 0
         if rescore_copy is None:
             rescore_copy = int(n) * int(d) * N.DTYPE_BYTES[self.dtype] <= RESCORE_COPY_MAX_BYTES
         if rescore_copy and (flags & N.VQA_INDEX_SKETCH):
@@ -278,6 +283,11 @@ class DeviceIndex:
     def sketch_state(self) -> int:
         """-1: no sketch; 0: searches take the sketch search; n > 0: an overflow sent the next n searches to the exact scan."""
         return int(self._lib.vqa_index_sketch_state(self._handle))
+
+    def sketch_pause(self, searches: int) -> None:
+        """The next ``searches`` searches of this handle take the exact scan (0 ends a pause); same bits as the sketch search on the
+        shards that have both paths (``include/vqa_retrieval.h``: vqa_index_sketch_pause, options.final_rescore)."""
+        N.check(self._lib.vqa_index_sketch_pause(self._handle, int(searches)), "vqa_index_sketch_pause")
 
     def sketch_stats(self) -> dict:
         """Diagnostics of the last sketch search of this handle (synchronises the device; ``include/vqa_retrieval.h``)."""
