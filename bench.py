@@ -144,6 +144,23 @@ def measure_copy(torch, device, nbytes=1 << 30, reps=10):
     return round(2 * nbytes / (ms * 1e-3) / 1e9, 1)
 
 
+def measure_read_stream(torch, device, nbytes=8 << 30):
+    """GB/s of a READ-ONLY stream on this box with the scan kernels' own loads (LDS-DMA nt into an LDS ring, one persistent workgroup per
+    CU; csrc/diag.hip, the library's measurement entry): the ceiling the scans' roofline fractions can be read against here
+    (torch's read + write copy is not that ceiling)."""
+    import ctypes
+    from vietnamese_qa_system_amd import _native as N
+    lib = N.load()
+    buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    buf.fill_(0x5A)
+    torch.cuda.synchronize(device)
+    out = ctypes.c_double()
+    N.check(lib.vqa_measure_read_stream(ctypes.c_void_p(buf.data_ptr()), nbytes, 5, ctypes.byref(out), None), "vqa_measure_read_stream")
+    del buf
+    torch.cuda.empty_cache()
+    return round(out.value, 1)
+
+
 def cpu_model() -> str:
     try:
         with open("/proc/cpuinfo") as f:
@@ -416,6 +433,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         piped = float(t.item())
     copy_gbs = measure_copy(torch, device) if rank == 0 else None
+    read_gbs = measure_read_stream(torch, device) if rank == 0 else None
 
     result = None
     if rank == 0:
@@ -434,11 +452,17 @@ def main():
         esize = {"fp16": 2, "fp8": 1, "fp32": 4}[args.dtype]
         kname = ((f"sketch_scan_regq_kernel<{(d + 127) // 128 * 2}, 0>" if info.scan_kernel == 1 else "score_topk_kernel<2, 3, 0, 1>") if sketch
                  else f"score_topk_kernel<1, {mode}, 0, 0>")
-        if sketch:  # the PMC bytes of THAT launch (profiles/traffic.json keeps the exact main launch's under the plain key)
-            traffic = None
-            if os.path.exists(tpath):
-                with open(tpath) as f:
-                    traffic = json.load(f).get(f"{n}x{d}_{dt}_b{b}_k{k}_sketch")
+        traffic_key = f"{n}x{d}_{dt}_b{b}_k{k}" + ("_sketch" if sketch else "")
+        traffic_note = None
+        if os.path.exists(tpath):  # the PMC bytes of THAT launch (profiles/traffic.json: an earlier rocprofv3 run of this repository, not this run)
+            with open(tpath) as f:
+                tj = json.load(f)
+            traffic = tj.get(traffic_key)
+            rec_kernel = tj.get("_kernel_" + traffic_key)
+            if traffic is not None and rec_kernel is not None and kname.split("<")[0] not in str(rec_kernel):
+                traffic, traffic_note = None, f"profiles/traffic.json holds the bytes of {rec_kernel}, not of this run's dominant kernel: dropped"
+            elif traffic is not None:
+                traffic_note = f"PMC bytes per launch recorded by an earlier profiling run ({tj.get('_source_' + traffic_key)}, kernel {rec_kernel}); not measured by this run"
         result = {
             "metric": "queries_per_sec", "value": round(qps, 1), "unit": "queries/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
@@ -453,7 +477,7 @@ def main():
             "step_ms": percentiles(np, step_ms),
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1) if achieved else None,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None,
-                         "traffic": traffic, "kernel_ms": round(kern_ms, 4), "launches": launches,
+                         "traffic": traffic, "traffic_source": traffic_note, "kernel_ms": round(kern_ms, 4), "launches": launches,
                          "kernel_events": f"HIP events on the launch's stream around every {KERNEL_EVENT_EVERY}th timed step's dominant launch",
                          "step_ms_of_event_steps": round(float(np.median(step_ms[::KERNEL_EVENT_EVERY])), 4),
                          "bytes_per_launch": info.bytes_per_launch, "flops_per_launch": info.flops_per_launch,
@@ -486,7 +510,11 @@ def main():
                          **step_bytes(info, sketch_stats, n, d, esize, b, float(np.median(step_ms))),
                          # the ceiling this box's HBM really gives a plain stream: a 1 GiB device-to-device copy (torch's copy
                          # kernel), bytes read + written over its event time, in this process
-                         "hbm_copy_measured_gbs": copy_gbs},
+                         "hbm_copy_measured_gbs": copy_gbs,
+                         # ... and a READ-ONLY stream with the scan's own loads and nothing else (csrc/diag.hip): the box's ceiling for a scan;
+                         # frac_of_measured_read_stream = the dominant launch against it
+                         "hbm_read_stream_measured_gbs": read_gbs,
+                         "frac_of_measured_read_stream": round(achieved / read_gbs, 4) if achieved and read_gbs else None},
             **({"multi_gpu": multi} if multi is not None else {}),
             "pipelined": {"batches": S, "calls": reps, "ms_per_batch": round(piped / (reps * S) * 1e3, 4),
                           "value": round(b * S * reps / piped, 1), "unit": "queries/s",

@@ -261,6 +261,10 @@ int vqa_index_set_timing(vqa_index* index, int32_t enabled); /* 0: off (recorded
                                                                * 2: on, keeping the pairs recorded so far (an event record between two
                                                                * launches costs the stream a few microseconds: bench.py samples) */
 int vqa_index_get_timing(vqa_index* index, double* kernel_ms_sum, int64_t* launches);
+/* Measurement helper (no search path uses it): GB/s of a read-only stream over `bytes` of device memory with the scan kernels' own loads
+ * (LDS-DMA nt into an LDS ring, one persistent workgroup per compute unit) and nothing else -- the ceiling of THIS device the scans'
+ * bandwidth fractions can be read against (csrc/diag.hip; fastest of `reps` launches behind two warm-ups; synchronises the stream). */
+int vqa_measure_read_stream(const void* device_buffer, int64_t bytes, int32_t reps, double* out_gbs, void* hip_stream);
 
 /* ---- question encoder: replaces the transformer forward + pooling + L2-normalise inside txtai
  * (model chosen by `path=` at heavy_ranker.py:80,83; DPR form at src/test.py:84-86 `.pooler_output`).

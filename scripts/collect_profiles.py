@@ -15,7 +15,7 @@ with open(os.path.join(dst, f"{name}_kernel_stats.csv"), "w", newline="") as f:
 summ = json.load(open(os.path.join(src, "pmc_summary.json")))
 bench = summ.pop("bench", None)
 if summ.get("kernel") in (None, "", "void "):
-    summ["kernel"] = next((r[0][:120] for r in rows[1:] if re.search(r"score_topk_kernel<2, 3, 0, \d>|score_topk_kernel<1, \d, 0(, \d)?>|score_topk_kernelILi1ELi\dELi0E", r[0])), summ.get("kernel"))
+    summ["kernel"] = next((r[0][:120] for r in rows[1:] if re.search(r"sketch_scan_regq_kernel<\d+, 0>|score_topk_kernel<2, 3, 0, \d>|score_topk_kernel<1, \d, 0(, \d)?>|score_topk_kernelILi1ELi\dELi0E", r[0])), summ.get("kernel"))
 json.dump(summ, open(os.path.join(dst, f"{name}_pmc_summary.json"), "w"), indent=1)
 if bench:
     json.dump(bench, open(os.path.join(dst, f"{name}_bench.json"), "w"), indent=1)
@@ -26,6 +26,7 @@ if bench:
     if "hbm_traffic_bytes_per_launch" in summ:
         t[key] = int(round(summ["hbm_traffic_bytes_per_launch"]))
         t["_source_" + key] = f"profiles/{name}_pmc_summary.json"
+        t["_kernel_" + key] = summ.get("kernel")  # bench.py drops the figure when the dominant kernel is another one by now
         json.dump(t, open(tpath, "w"), indent=1)
     print(key, t.get(key))
 print("ok", name)

@@ -19,14 +19,17 @@ main_name = None
 # the dominant launch: the int8 sketch scan score_topk_kernel<2, 3, 0, 0> where a search has one, else the exact main launch
 # score_topk_kernel<1, DT, 0, L> (<1, DT, 1, L> is the first stage of a two-stage search, <0, ..> the seed pass)
 MAIN = r"score_topk_kernel<1, \d, 0(, \d)?>|score_topk_kernelILi1ELi\dELi0E"
-if any(re.search(r"score_topk_kernel<2, 3", r["Kernel_Name"]) for r in rows("pmc_fetch", "counter_collection.csv")):
+if any(re.search(r"sketch_scan_regq_kernel<", r["Kernel_Name"]) for r in rows("pmc_fetch", "counter_collection.csv")):
+    MAIN = r"sketch_scan_regq_kernel<\d+, 0>"  # (<KT, 1> is the same code under the early stages' symbol)
+    out["sketch_scan"] = True
+elif any(re.search(r"score_topk_kernel<2, 3", r["Kernel_Name"]) for r in rows("pmc_fetch", "counter_collection.csv")):
     MAIN = r"score_topk_kernel<2, 3, 0, \d>"
     out["sketch_scan"] = True
 for sub in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_lds"):
     agg = collections.defaultdict(list)
     for r in rows(sub, "counter_collection.csv"):
         if re.search(MAIN, r["Kernel_Name"]):
-            main_name = re.search(r"score_topk_kernel(<[^>]*>|IL\w*E)", r["Kernel_Name"]).group(0)
+            main_name = re.search(r"(score_topk_kernel|sketch_scan_regq_kernel)(<[^>]*>|IL\w*E)", r["Kernel_Name"]).group(0)
             agg[r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     for name, v in agg.items():
         v = v[3:] if len(v) > 6 else v  # drop the warm-up launches
@@ -38,7 +41,7 @@ out["kernel"] = main_name
 per = collections.defaultdict(lambda: collections.defaultdict(list))
 for sub, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     for r in rows(sub, "counter_collection.csv"):
-        m = re.search(r"(score_topk_kernel<[^>]*>|rescore_kernel|merge_partials_kernel|sketch_rows_kernel|tile_rows_kernel|sketch_qconst_kernel)", r["Kernel_Name"])
+        m = re.search(r"(score_topk_kernel<[^>]*>|sketch_scan_regq_kernel<[^>]*>|final_rescore_kernel|rescore_kernel|merge_partials_kernel|sketch_rows_kernel|tile_rows_kernel|sketch_qconst_kernel)", r["Kernel_Name"])
         if m and r["Counter_Name"] == ctr:
             per[m.group(1)][ctr].append(float(r["Counter_Value"]))
 out["per_kernel_hbm_bytes_per_launch"] = {

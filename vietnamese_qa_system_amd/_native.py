@@ -28,7 +28,7 @@ DTYPE_BYTES = {VQA_F32: 4, VQA_F16: 2, VQA_FP8_E4M3: 1}
 # every symbol include/vqa_retrieval.h declares (tests/test_capi_symbols.py checks the two lists agree)
 EXPORTS = (
     "vqa_version", "vqa_last_error", "vqa_index_create", "vqa_index_options_init", "vqa_index_create_ex", "vqa_index_set_rows", "vqa_index_get_rows", "vqa_index_destroy", "vqa_index_size", "vqa_index_dim",
-    "vqa_index_dtype", "vqa_index_device_bytes", "vqa_index_sketch_state", "vqa_index_sketch_pause", "vqa_index_sketch_stats", "vqa_index_get_sketch_tile", "vqa_index_get_sketch_split", "vqa_index_search", "vqa_index_search_host", "vqa_merge_topk", "vqa_index_launch_info", "vqa_index_set_timing",
+    "vqa_index_dtype", "vqa_index_device_bytes", "vqa_index_sketch_state", "vqa_index_sketch_pause", "vqa_index_sketch_stats", "vqa_index_get_sketch_tile", "vqa_index_get_sketch_split", "vqa_index_search", "vqa_index_search_host", "vqa_merge_topk", "vqa_index_launch_info", "vqa_measure_read_stream", "vqa_index_set_timing",
     "vqa_index_get_timing", "vqa_encoder_create", "vqa_encoder_options_init", "vqa_encoder_create_ex",
     "vqa_encoder_destroy", "vqa_encoder_forward", "vqa_encoder_forward_host", "vqa_encoder_forward_hidden", "vqa_normalize_convert",
 )
@@ -140,6 +140,7 @@ def load() -> ctypes.CDLL:
     lib.vqa_index_launch_info.argtypes = [c.c_void_p, c.c_int32, c.c_int32, c.POINTER(LaunchInfo)]
     lib.vqa_index_set_timing.argtypes = [c.c_void_p, c.c_int32]
     lib.vqa_index_get_timing.argtypes = [c.c_void_p, c.POINTER(c.c_double), c.POINTER(c.c_int64)]
+    lib.vqa_measure_read_stream.argtypes = [c.c_void_p, c.c_int64, c.c_int32, c.POINTER(c.c_double), c.c_void_p]
     lib.vqa_encoder_create.argtypes = [c.POINTER(c.c_void_p), c.c_int, c.POINTER(EncoderConfig),
                                        c.POINTER(EncoderWeights), c.c_int32]
     lib.vqa_encoder_destroy.argtypes = [c.c_void_p]
