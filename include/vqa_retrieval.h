@@ -308,6 +308,13 @@ typedef struct vqa_encoder_options {
     int32_t graphs;         /* [1] calls of <= 1024 positions replay a captured hipGraph */
     int32_t latency_path;   /* [1] calls of <= 64 positions (one question: heavy_ranker.py:97-101) on models whose hidden and FFN sizes are
                              * multiples of 384 (the reference's two models: hidden 384 / 768) run the latency form: five launches per layer, LayerNorms inside the GEMMs; 0: the general small-batch kernels */
+    int32_t persistent;     /* [0] 1: the two model shapes of the reference (hidden 768 / FFN 3072 and hidden 384 / FFN 1536, 12 heads) run a call of <= 64
+                             * positions as ONE cooperative launch: every phase of the latency form inside a persistent kernel, fence-free grid barriers
+                             * between the phases, activations in uncached device memory read with device-scope loads (csrc/encoder.hip
+                             * encoder_persist_kernel).  The same bits as the launches -- and, measured, 1.04 ms against their 0.44 (every workgroup of
+                             * every phase pulls the activations through the memory side instead of its XCD's L2: profiles/r06_persistent_forward.txt):
+                             * kept as the measured answer to "would one launch be faster", off by default */
+    int32_t persistent_grid; /* [0: FFN size / 32] resident workgroups of that kernel (A/B switch) */
 } vqa_encoder_options;
 void vqa_encoder_options_init(vqa_encoder_options* opt);
 int vqa_encoder_create_ex(vqa_encoder** out, int device, const vqa_encoder_config* cfg, const vqa_encoder_weights* w, int32_t max_tokens,

@@ -487,3 +487,37 @@ def test_latency_form_matches_the_general_kernels_and_the_oracle(native_lib, mon
     for j, n in enumerate((0, 1, 3)):
         for on in (1, 0):
             check_parity(f"latency form={on} b={b} l={l} hidden_states[{n}]", hid[on][j][real], refs[n][real], *BOUNDS["hidden_" + model])
+
+
+# ---- the one-launch forward (encoder_persist_kernel, round 6): the latency form's phases inside ONE cooperative launch, fence-free grid
+# barriers between them, activations in uncached memory.  The phase bodies are the launches' own, so the result is the launches' bit for bit
+# -- for any number of resident workgroups, repeated calls, both of the reference's model shapes (heavy_ranker.py:80,83).
+@pytest.mark.parametrize("model", ["phobert", "minilm"])
+@pytest.mark.parametrize("b,l", [(1, 32), (1, 7), (3, 9), (2, 32), (1, 64), (1, 40)])
+def test_one_launch_forward_returns_the_launches_bits(native_lib, b, l, model):
+    from vietnamese_qa_system_amd.encoder import QuestionEncoder
+    cfg = dict(E.PHOBERT_BASE if model == "phobert" else E.MINILM_L12, layers=4, vocab_size=8000)
+    w = E.synthetic_weights(cfg, seed=33, layers=4)
+    rng = np.random.default_rng(9)
+    for k_ in list(w):
+        if "LayerNorm.weight" in k_:
+            w[k_] = (1.0 + 0.3 * rng.standard_normal(w[k_].shape)).astype(np.float32)
+        elif "LayerNorm.bias" in k_:
+            w[k_] = (0.2 * rng.standard_normal(w[k_].shape)).astype(np.float32)
+    ids, mask = E.synthetic_tokens(cfg, b, l, seed=70 + b + l, min_len=min(5, l))
+    ids2, mask2 = E.synthetic_tokens(cfg, b, l, seed=71 + b + l, min_len=min(3, l))
+    ref_enc = QuestionEncoder(w, cfg, max_tokens=b * l, options={"persistent": 0})
+    want = {(j, p): ref_enc.forward(i_, m_, pooling=p).cpu().numpy() for j, (i_, m_) in enumerate(((ids, mask), (ids2, mask2))) for p in ("cls", "mean")}
+    ref_enc.close()
+    for grid in (0, 24, 144, 256):
+        enc = QuestionEncoder(w, cfg, max_tokens=b * l, options={"persistent": 1, "persistent_grid": grid})
+        assert enc.options.persistent == 1
+        for rep in range(3):  # the barrier counter runs on over the handle's launches
+            for j, (i_, m_) in enumerate(((ids, mask), (ids2, mask2))):
+                for p in ("cls", "mean"):
+                    got = enc.forward(i_, m_, pooling=p).cpu().numpy()
+                    assert np.array_equal(got, want[j, p]), (grid, rep, j, p, np.abs(got - want[j, p]).max())
+        enc.close()
+    ref = E.encode(w, cfg, ids, mask, pooling="mean")
+    d, cos, _ = parity(want[0, "mean"], ref)
+    assert 1 - cos <= 5.2e-6

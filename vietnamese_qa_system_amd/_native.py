@@ -59,7 +59,7 @@ class IndexOptions(ctypes.Structure):
 class EncoderOptions(ctypes.Structure):
     """``vqa_encoder_options``."""
     _fields_ = [("struct_size", ctypes.c_uint32), ("fold_layernorm", ctypes.c_int32), ("first_rows", ctypes.c_int32),
-                ("graphs", ctypes.c_int32), ("latency_path", ctypes.c_int32)]
+                ("graphs", ctypes.c_int32), ("latency_path", ctypes.c_int32), ("persistent", ctypes.c_int32), ("persistent_grid", ctypes.c_int32)]
 
 
 class EncoderConfig(ctypes.Structure):

@@ -173,15 +173,50 @@ __global__ __launch_bounds__(256) void pack_kernel(const int* __restrict__ mask,
     }
 }
 
-__global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ ids, int T, int L, int H, int pad_id, int vocab, int abs_pos,
-                                                       int* __restrict__ bad_ids, const int* __restrict__ cu,
-                                                       const int* __restrict__ row_seq, int B, const float* __restrict__ word,
-                                                       const float* __restrict__ pos,
-                                                       const float* __restrict__ type0, const float* __restrict__ g,
-                                                       const float* __restrict__ b, float eps, _Float16* __restrict__ out,
-                                                       float2* __restrict__ stats, int st_stride) {
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+// Loads of activations another workgroup of the SAME launch wrote (the persistent one-question forward): relaxed device-scope atomic
+// loads, i.e. `global_load ... sc1` -- never served from this CU's vector L1 or a stale L2 line (the hand-off form tiny_search.hip uses;
+// /opt/skills/guides/MI355X_MICROARCH.md, Correctness boundaries).  8 bytes per instruction; COH = false: the plain load.
+template <bool COH>
+__device__ __forceinline__ half8 act_load16(const _Float16* p) {
+    if constexpr (!COH) {
+        return *reinterpret_cast<const half8*>(p);
+    } else {
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        u64x2 v;
+        v[0] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v[1] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __builtin_bit_cast(half8, v);
+    }
+}
+template <bool COH, typename T8>  // an 8-byte value (4 halves, a float2)
+__device__ __forceinline__ T8 act_load8(const void* p) {
+    if constexpr (!COH) {
+        return *reinterpret_cast<const T8*>(p);
+    } else {
+        const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return __builtin_bit_cast(T8, v);
+    }
+}
+template <bool COH>
+__device__ __forceinline__ float act_load_half(const _Float16* p) {
+    if constexpr (!COH) {
+        return (float)*p;
+    } else {
+        const unsigned short v = __hip_atomic_load(reinterpret_cast<const unsigned short*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (float)__builtin_bit_cast(_Float16, v);
+    }
+}
+
+// (bodies take their block / thread index as arguments: the persistent one-question forward, encoder_persist_kernel, calls them per unit)
+__device__ __forceinline__ void embed_ln_body(const int* __restrict__ ids, int T, int L, int H, int pad_id, int vocab, int abs_pos,
+                                              int* __restrict__ bad_ids, const int* __restrict__ cu,
+                                              const int* __restrict__ row_seq, int B, const float* __restrict__ word,
+                                              const float* __restrict__ pos,
+                                              const float* __restrict__ type0, const float* __restrict__ g,
+                                              const float* __restrict__ b, float eps, _Float16* __restrict__ out,
+                                              float2* __restrict__ stats, int st_stride, int bx, int tid) {
+    const int lane = tid & 63;
+    const int t = bx * 4 + (tid >> 6);
     if (t >= T) return;
     int seq, l;
     if (cu) {  // packed rows: t = cu[seq] + l
@@ -226,24 +261,39 @@ __global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ i
     if (stats) row_raw_stats(x, H, lane, out + (size_t)t * H, stats, (size_t)st_stride, (size_t)t);
     else row_layer_norm(x, H, lane, g, b, eps, out + (size_t)t * H);
 }
+__global__ __launch_bounds__(256) void embed_ln_kernel(const int* __restrict__ ids, int T, int L, int H, int pad_id, int vocab, int abs_pos,
+                                                       int* __restrict__ bad_ids, const int* __restrict__ cu,
+                                                       const int* __restrict__ row_seq, int B, const float* __restrict__ word,
+                                                       const float* __restrict__ pos,
+                                                       const float* __restrict__ type0, const float* __restrict__ g,
+                                                       const float* __restrict__ b, float eps, _Float16* __restrict__ out,
+                                                       float2* __restrict__ stats, int st_stride) {
+    embed_ln_body(ids, T, L, H, pad_id, vocab, abs_pos, bad_ids, cu, row_seq, B, word, pos, type0, g, b, eps, out, stats, st_stride, (int)blockIdx.x,
+                  (int)threadIdx.x);
+}
 
 // LayerNorm alone: the residual add is fused into the epilogue of the GEMM that produced `a` (EPI 2).  (Two or four rows per
 // wave, all loaded before the first reduction, measured 1-2 % slower on the whole forward than one row per wave.)
-__global__ __launch_bounds__(256) void ln_kernel(const _Float16* __restrict__ a, int T, int H, const float* __restrict__ g,
-                                                 const float* __restrict__ b, float eps, _Float16* __restrict__ out) {
-    const int lane = threadIdx.x & 63;
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+template <bool COH = false>
+__device__ __forceinline__ void ln_body(const _Float16* __restrict__ a, int T, int H, const float* __restrict__ g,
+                                        const float* __restrict__ b, float eps, _Float16* __restrict__ out, int bx, int tid) {
+    const int lane = tid & 63;
+    const int t = bx * 4 + (tid >> 6);
     if (t >= T) return;
     float x[kChunks][8];
 #pragma unroll
     for (int i = 0; i < kChunks; ++i) {
         const int j0 = (lane + 64 * i) * 8;
         half8 va = half8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (j0 < H) va = *reinterpret_cast<const half8*>(a + (size_t)t * H + j0);
+        if (j0 < H) va = act_load16<COH>(a + (size_t)t * H + j0);
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[i][e] = (float)va[e];
     }
     row_layer_norm(x, H, lane, g, b, eps, out + (size_t)t * H);
+}
+__global__ __launch_bounds__(256) void ln_kernel(const _Float16* __restrict__ a, int T, int H, const float* __restrict__ g,
+                                                 const float* __restrict__ b, float eps, _Float16* __restrict__ out) {
+    ln_body(a, T, H, g, b, eps, out, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // erf GELU, 0.5 x (1 + erf(x / sqrt 2)), with erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the fp16
@@ -1188,17 +1238,24 @@ struct TinyArgs {
     float inv_k = 0.f, eps = 0.f;
 };
 
-template <int EPI, int MT, int FOLDIN, int NBC, int WV = 8>  // MT token tiles of 16; NBC K-blocks per chunk (all of a chunk's loads in flight together);
+template <int EPI, int MT, int FOLDIN, int NBC, int WV = 8, bool COH = false>  // MT token tiles of 16; NBC K-blocks per chunk (all of a chunk's loads in flight together);
                                                              // WV waves split K (8; 4 for K = 384, the MiniLM-L12 hidden size of heavy_ranker.py:80)
-__global__ __launch_bounds__(64 * WV) void gemm_tiny_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
-                                                        const float* __restrict__ bias, const _Float16* __restrict__ R,
-                                                        _Float16* __restrict__ C, int M, int N, int K, TinyArgs ta) {
+// (bx, by, tid: the unit and thread; threads of waves >= WV -- the persistent kernel's 512-thread workgroup running a four-wave form -- only
+// take part in the barrier)
+__device__ __forceinline__ void gemm_tiny_body(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+                                               const float* __restrict__ bias, const _Float16* __restrict__ R,
+                                               _Float16* __restrict__ C, int M, int N, int K, const TinyArgs& ta, int bx, int by, int tid,
+                                               const half8* wpre = nullptr /* this wave's weight fragments of its (single) chunk, loaded ahead */) {
     __shared__ f32x4 red[WV - 1][MT][64];
     __shared__ float2 sred[WV][MT][16];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
+    if (wave >= WV) {
+        __syncthreads();
+        return;
+    }
     const int c = lane & 15, g = lane >> 4;
-    const int n0 = blockIdx.x * 16;
-    const int m0 = blockIdx.y * (16 * MT);  // gridDim.y > 1: the token tiles are spread over workgroups (FFN2: 48 feature slices alone leave 208 CUs idle)
+    const int n0 = bx * 16;
+    const int m0 = by * (16 * MT);  // by > 0: the token tiles are spread over workgroups (FFN2: 48 feature slices alone leave 208 CUs idle)
     const int kq = K / WV;  // this wave's K range [wave kq, +kq): a multiple of 32 NBC
     const int kbase = wave * kq;
     const _Float16* wp = W + (size_t)(n0 + c) * K + kbase + 8 * g;
@@ -1237,19 +1294,19 @@ __global__ __launch_bounds__(64 * WV) void gemm_tiny_kernel(const _Float16* __re
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) {
                 const int m = m0 + mi * 16 + c < M ? m0 + mi * 16 + c : M - 1;
-                res[mi] = *reinterpret_cast<const half4*>(R + (size_t)m * N + n0 + 4 * g);
-                if (ta.g) st[mi] = ta.st_in[m];
+                res[mi] = act_load8<COH, half4>(R + (size_t)m * N + n0 + 4 * g);
+                if (ta.g) st[mi] = act_load8<COH, float2>(ta.st_in + m);
             }
         }
     }
     for (int k0 = 0; k0 < kq; k0 += 32 * NBC) {
         half8 wf[NBC], xf[NBC][MT];
 #pragma unroll
-        for (int j = 0; j < NBC; ++j) wf[j] = *reinterpret_cast<const half8*>(wp + k0 + 32 * j);
+        for (int j = 0; j < NBC; ++j) wf[j] = wpre ? wpre[j] : *reinterpret_cast<const half8*>(wp + k0 + 32 * j);
 #pragma unroll
         for (int j = 0; j < NBC; ++j)
 #pragma unroll
-            for (int mi = 0; mi < MT; ++mi) xf[j][mi] = *reinterpret_cast<const half8*>(ap[mi] + k0 + 32 * j);
+            for (int mi = 0; mi < MT; ++mi) xf[j][mi] = act_load16<COH>(ap[mi] + k0 + 32 * j);
         // every load of the chunk is issued before the first MFMA (left alone, hipcc interleaves them with the MFMAs to save registers:
         // a memory round trip per few K-blocks again)
         __builtin_amdgcn_sched_barrier(0);
@@ -1307,7 +1364,7 @@ __global__ __launch_bounds__(64 * WV) void gemm_tiny_kernel(const _Float16* __re
             const float mean = a1 * ta.inv_k;
             rstd = rsqrtf(fmaxf(a2 * ta.inv_k - mean * mean, 0.f) + ta.eps);
             mrs = mean * rstd;
-            if (ta.st_out && blockIdx.x == 0 && g == 0 && m < M) ta.st_out[m] = make_float2(mean, rstd);
+            if (ta.st_out && bx == 0 && g == 0 && m < M) ta.st_out[m] = make_float2(mean, rstd);
         }
         if (m >= M) continue;
         half4 o;
@@ -1320,6 +1377,12 @@ __global__ __launch_bounds__(64 * WV) void gemm_tiny_kernel(const _Float16* __re
         }
         *reinterpret_cast<half4*>(C + (size_t)m * N + n0 + 4 * g) = o;
     }
+}
+template <int EPI, int MT, int FOLDIN, int NBC, int WV = 8>
+__global__ __launch_bounds__(64 * WV) void gemm_tiny_kernel(const _Float16* __restrict__ A, const _Float16* __restrict__ W,
+                                                        const float* __restrict__ bias, const _Float16* __restrict__ R,
+                                                        _Float16* __restrict__ C, int M, int N, int K, TinyArgs ta) {
+    gemm_tiny_body<EPI, MT, FOLDIN, NBC, WV>(A, W, bias, R, C, M, N, K, ta, (int)blockIdx.x, (int)blockIdx.y, (int)threadIdx.x);
 }
 
 // token ids and masks of vqa_encoder_forward_host: pinned host memory -> the device arrays a replayed graph reads
@@ -1402,16 +1465,19 @@ typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 constexpr int kAttMaxBlocks = 8;  // L <= 256
 __host__ __device__ constexpr bool att_mfma_head_size(int dh) { return dh == 64 || dh == 32; }
 
-template <int NQB, int HPW, int DH>
-__global__ __launch_bounds__(64 * NQB * HPW) void attention_mfma_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ mask,
-                                                                         int Lmax, int H, int heads, const int* __restrict__ cu,
-                                                                         _Float16* __restrict__ ctx) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+template <int NQB, int HPW, int DH, bool COH = false>
+__device__ __forceinline__ void attention_mfma_body(const _Float16* __restrict__ qkv, const int* __restrict__ mask,
+                                                    int Lmax, int H, int heads, const int* __restrict__ cu,
+                                                    _Float16* __restrict__ ctx, int bx, int tid, char* smem) {
     constexpr int Lp = NQB * 32;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
+    if (wave >= NQB * HPW) {  // (a wider workgroup of the persistent kernel: the extra waves only take part in the barrier)
+        __syncthreads();
+        return;
+    }
     const int hw = wave / NQB, qb = wave - hw * NQB;  // head inside the workgroup, query block
     const int groups = heads / HPW;
-    const int seq = blockIdx.x / groups, head = (blockIdx.x - seq * groups) * HPW + hw;
+    const int seq = bx / groups, head = (bx - seq * groups) * HPW + hw;
     static_assert(DH == 64 || DH == 32, "head sizes of the matrix-core attention");
     constexpr int kRowB = DH * 2;      // bytes of a key row of the V image
     constexpr int kCh = DH / 8;        // 16-byte chunks per row
@@ -1431,12 +1497,12 @@ __global__ __launch_bounds__(64 * NQB * HPW) void attention_mfma_kernel(const _F
         const int i = tid - hw * 64 * NQB + t * 64 * NQB;
         const int key = i / kCh, ch = i % kCh;
         vreg[t] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (key < L) vreg[t] = *reinterpret_cast<const half8*>(base + (size_t)key * row_stride + 2 * H + ch * 8);
+        if (key < L) vreg[t] = act_load16<COH>(base + (size_t)key * row_stride + 2 * H + ch * 8);
     }
     const int qrow = qb * 32 + li < L ? qb * 32 + li : L - 1;  // padded query rows recompute the last row, never stored
     half8 qf[kVregs];
 #pragma unroll
-    for (int kk = 0; kk < kVregs; ++kk) qf[kk] = *reinterpret_cast<const half8*>(base + (size_t)qrow * row_stride + kk * 16 + h * 8);
+    for (int kk = 0; kk < kVregs; ++kk) qf[kk] = act_load16<COH>(base + (size_t)qrow * row_stride + kk * 16 + h * 8);
     f32x16 st[NQB];
     const float scale = rsqrtf((float)DH);
     float mx = -INFINITY;
@@ -1447,7 +1513,7 @@ __global__ __launch_bounds__(64 * NQB * HPW) void attention_mfma_kernel(const _F
         f32x16 acc = {};
 #pragma unroll
         for (int kk = 0; kk < kVregs; ++kk) {
-            const half8 kf = *reinterpret_cast<const half8*>(base + (size_t)krow * row_stride + H + kk * 16 + h * 8);
+            const half8 kf = act_load16<COH>(base + (size_t)krow * row_stride + H + kk * 16 + h * 8);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], acc, 0, 0, 0);
         }
         // key validity of this block as a wave-uniform bit mask (bit = key index inside the block)
@@ -1526,6 +1592,13 @@ __global__ __launch_bounds__(64 * NQB * HPW) void attention_mfma_kernel(const _F
                     half4{(_Float16)o[db][4 * g4], (_Float16)o[db][4 * g4 + 1], (_Float16)o[db][4 * g4 + 2], (_Float16)o[db][4 * g4 + 3]};
     }
 }
+template <int NQB, int HPW, int DH>
+__global__ __launch_bounds__(64 * NQB * HPW) void attention_mfma_kernel(const _Float16* __restrict__ qkv, const int* __restrict__ mask,
+                                                                         int Lmax, int H, int heads, const int* __restrict__ cu,
+                                                                         _Float16* __restrict__ ctx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    attention_mfma_body<NQB, HPW, DH>(qkv, mask, Lmax, H, heads, cu, ctx, (int)blockIdx.x, (int)threadIdx.x, smem);
+}
 
 // CLS pooling reads one row per sequence, and after the last layer's attention nothing mixes rows any more: the last layer's
 // out-projection, FFN and LayerNorms then run on the B first-token rows alone.  This gathers those rows of the attention
@@ -1581,13 +1654,14 @@ __global__ __launch_bounds__(256) void fold_weight_kernel(const float* __restric
 
 constexpr int kMaxPer = 32;  // hidden <= 2048 (pooling keeps element j = lane + 64 i per lane)
 
-__global__ __launch_bounds__(256) void pool_normalize_kernel(const _Float16* __restrict__ hidden, const int* __restrict__ mask,
-                                                             int B, int Lmax, int H, int pooling, int normalize,
-                                                             const int* __restrict__ cu, float* __restrict__ out,
-                                                             const float2* __restrict__ stats, int st_stride, int p,
-                                                             const float* __restrict__ g, const float* __restrict__ b, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int seq = blockIdx.x * 4 + (threadIdx.x >> 6);
+template <bool COH = false>
+__device__ __forceinline__ void pool_normalize_body(const _Float16* __restrict__ hidden, const int* __restrict__ mask,
+                                                    int B, int Lmax, int H, int pooling, int normalize,
+                                                    const int* __restrict__ cu, float* __restrict__ out,
+                                                    const float2* __restrict__ stats, int st_stride, int p,
+                                                    const float* __restrict__ g, const float* __restrict__ b, float eps, int bx, int tid) {
+    const int lane = tid & 63;
+    const int seq = bx * 4 + (tid >> 6);
     if (seq >= B) return;
     const size_t row0 = cu ? (size_t)cu[seq] : (size_t)seq * Lmax;
     const int L = cu ? cu[seq + 1] - cu[seq] : Lmax;
@@ -1603,7 +1677,7 @@ __global__ __launch_bounds__(256) void pool_normalize_kernel(const _Float16* __r
 #pragma unroll
         for (int i = 0; i < kMaxPer; ++i) {
             const int j = lane + 64 * i;
-            if (j < H) x[i] = ((float)hidden[row0 * H + j] - mean) * rstd;
+            if (j < H) x[i] = (act_load_half<COH>(hidden + row0 * H + j) - mean) * rstd;
         }
     } else {
         cnt = 0;
@@ -1614,7 +1688,7 @@ __global__ __launch_bounds__(256) void pool_normalize_kernel(const _Float16* __r
 #pragma unroll
             for (int i = 0; i < kMaxPer; ++i) {
                 const int j = lane + 64 * i;
-                if (j < H) x[i] += ((float)hidden[(row0 + l) * H + j] - mean) * rstd;
+                if (j < H) x[i] += (act_load_half<COH>(hidden + (row0 + l) * H + j) - mean) * rstd;
             }
         }
     }
@@ -1644,6 +1718,13 @@ __global__ __launch_bounds__(256) void pool_normalize_kernel(const _Float16* __r
         if (j < H) out[(size_t)seq * H + j] = x[i] / nrm;
     }
 }
+__global__ __launch_bounds__(256) void pool_normalize_kernel(const _Float16* __restrict__ hidden, const int* __restrict__ mask,
+                                                             int B, int Lmax, int H, int pooling, int normalize,
+                                                             const int* __restrict__ cu, float* __restrict__ out,
+                                                             const float2* __restrict__ stats, int st_stride, int p,
+                                                             const float* __restrict__ g, const float* __restrict__ b, float eps) {
+    pool_normalize_body(hidden, mask, B, Lmax, H, pooling, normalize, cu, out, stats, st_stride, p, g, b, eps, (int)blockIdx.x, (int)threadIdx.x);
+}
 
 // hidden states for a caller (vqa_encoder_forward_hidden = HF `output_hidden_states`): row t of the activation array (packed or padded)
 // -> fp32 row (seq, l) of out [B, L, H]; stats != nullptr: x holds raw rows whose LayerNorm is folded into the GEMMs, applied here.
@@ -1668,6 +1749,212 @@ __global__ __launch_bounds__(256) void export_hidden_kernel(const _Float16* __re
         if (stats) v = (v - mean) * rstd * g[j] + b[j];
         out[dst * H + j] = v;
     }
+}
+
+// ---- ONE launch for the whole one-question forward (round 6: the reference's own call, heavy_ranker.py:97-101 -- one question, limit 1).
+// The latency form above is 62 launches of ~5.8 us each (0.36-0.44 ms for 32 tokens), every one a chain of wave start -> one memory round
+// trip -> LDS reduction -> store -> kernel boundary (write-back + invalidate of the L2s).  Here the same phases -- embedding, and per layer
+// QKV (LayerNorm folded in) | attention | out-projection (+ normalised residual) | FFN1 (LayerNorm folded in, GELU) | FFN2 (+ normalised
+// residual), then the last LayerNorm and the pooling -- run inside ONE persistent kernel: G resident workgroups (cooperative launch), the
+// phases' units (16 output features x the token tiles; 4 heads of a sequence; 4 rows) dealt round-robin, a fence-free grid barrier between
+// phases.  The bodies are the launches' own (gemm_tiny_body, attention_mfma_body, ...): same arithmetic, same bits.
+// Coherence without fences (a device-scope release / acquire per workgroup writes back and invalidates an XCD's L2: 12-64 us per barrier,
+// scripts/probes/grid_barrier_probe.hip): every ACTIVATION buffer the phases hand to each other lives in UNCACHED device memory
+// (hipDeviceMallocUncached), so plain loads and stores go to the memory side and no L2 / L1 ever holds a stale line (probe: no stale read in
+// 4 x 500 phases at 48-256 workgroups, 2.9-5.1 us per phase with a 64 KB exchange); the per-CU vector L1 is invalidated by every wave behind
+// each barrier (it does cache uncached memory); weights and inputs are read-only and cached as usual.
+// The barrier: every wave drains its stores (s_waitcnt vmcnt(0)), the workgroup's barrier, ONE device-scope atomic add, one lane polls.
+// Spins are bounded: a workgroup that waits longer than ~50 ms raises `abort` and every workgroup leaves (the host reports the failure and
+// takes the launches instead) -- a stuck grid must never hang the device.
+struct PersistLayer {
+    const _Float16 *wqkv_f, *wo, *w1_f, *w2;
+    const float *bqkv_f, *cqkv, *bo, *b1_f, *c1, *b2, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+};
+struct PersistArgs {
+    const int *ids, *mask;
+    int B, L, T, H, F, heads, layers, pad_id, vocab, abs_pos;
+    int* bad_ids;
+    const float *word, *pos, *type0, *emb_g, *emb_b;
+    float eps;
+    const PersistLayer* lay;
+    _Float16 *x, *qkv, *ctx, *tmp, *ffn;  // uncached
+    float2 *tiny_x, *tiny_tmp;            // uncached
+    float2* st_scratch;                   // the embedding's slot statistics (written, never read here)
+    int st_stride;
+    int pooling, normalize;
+    float* out;
+    unsigned* counter;  // grid barrier: monotonic over the handle's launches
+    unsigned base;      // its value when this launch starts
+    unsigned* abort;    // raised by a workgroup whose wait ran out
+};
+
+// barriers of one forward: behind the embedding, five per layer, behind the last LayerNorm (the host advances its copy of the counter by
+// this many x the grid per launch)
+__host__ __device__ constexpr unsigned persist_barriers(int layers) { return 2u + 5u * (unsigned)layers; }
+
+__device__ __forceinline__ bool persist_barrier(const PersistArgs& a, unsigned phase, int tid) {
+    __shared__ unsigned ok;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores of the phase have reached the memory side
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned target = (phase + 1u) * gridDim.x;
+        __hip_atomic_fetch_add(a.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned good = 0u;
+        for (unsigned spin = 0; spin < (1u << 21); ++spin) {
+            if (__hip_atomic_load(a.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.base >= target) {
+                good = 1u;
+                break;
+            }
+            if ((spin & 255u) == 255u && __hip_atomic_load(a.abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (!good) __hip_atomic_store(a.abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        ok = good;
+    }
+    __syncthreads();
+    // Uncached memory bypasses the L2s, NOT this CU's vector L1: a workgroup that read a buffer in an earlier phase and was idle since can
+    // still hold those lines (seen at 256 workgroups with plain loads: the ones that only ever run FFN1 units re-read the previous layer's rows;
+    // `buffer_inv sc0` does not drop them, `buffer_inv sc1` does -- at 5.6 us per barrier).  The phases read activations with device-scope atomic
+    // loads instead (act_load16 / act_load8: `sc1`, never served from the L1).
+#ifndef VQA_PERSIST_INV
+#define VQA_PERSIST_INV 0  // dev: 1 / 2 = every wave invalidates the caches behind the barrier (5.6 us per barrier; the coherent loads make it unnecessary)
+#endif
+#if VQA_PERSIST_INV == 1
+    asm volatile("buffer_inv sc1" ::: "memory");
+#elif VQA_PERSIST_INV == 2
+    asm volatile("buffer_inv sc0 sc1" ::: "memory");
+#endif
+    return ok != 0u;
+}
+
+// this wave's weight fragments of unit `unit` of a gemm_tiny_body<.., NBC, WV> call (its whole K range is one chunk), requested AHEAD of
+// the grid barrier in front of that phase: weights do not depend on the phase before, so their memory round trip passes under the barrier
+template <int NBC, int WV>
+__device__ __forceinline__ void persist_prefetch(const _Float16* __restrict__ W, int K, int unit, int tid, half8 (&wf)[12]) {
+    const int lane = tid & 63, wave = tid >> 6;
+    if (wave >= WV) return;
+    const int c = lane & 15, g = lane >> 4;
+    const _Float16* wp = W + (size_t)(unit * 16 + c) * K + wave * (K / WV) + 8 * g;
+#pragma unroll
+    for (int j = 0; j < NBC; ++j) wf[j] = *reinterpret_cast<const half8*>(wp + 32 * j);
+#pragma unroll
+    for (int j = 0; j < NBC; ++j) asm volatile("" : "+v"(wf[j]));  // (requested here, not behind the barrier)
+}
+
+// MT: token tiles of 16 (T <= 16 MT); FOUR: hidden size 384 (K = 384: four waves split K, heads of 32); NQB: 32-token blocks per sequence
+template <int MT, bool FOUR, int NQB>
+__global__ __launch_bounds__(512) void encoder_persist_kernel(PersistArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int WVA = FOUR ? 4 : 8;       // waves that split K = H
+    constexpr int NBCB = FOUR ? 6 : 12;     // K-blocks per chunk of FFN2 (K = F: 1536 / 3072, eight waves)
+    constexpr int DH = FOUR ? 32 : 64;
+    constexpr int HPW = 4;
+    const int tid = threadIdx.x, G = gridDim.x, wg = blockIdx.x;
+    const int H = a.H, F = a.F, T = a.T;
+    const float inv_h = 1.0f / (float)H;
+    unsigned phase = 0;
+    half8 wnext[12];  // the next phase's weight fragments of this workgroup's first unit
+#pragma unroll
+    for (int j = 0; j < 12; ++j) wnext[j] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+#define VQA_PERSIST_BARRIER()                     \
+    do {                                          \
+        if (!persist_barrier(a, phase, tid)) return; \
+        ++phase;                                  \
+    } while (0)
+    // ---- embedding: raw rows (+ slot statistics nobody reads here); 4 rows per 256 threads, 8 per unit
+    for (int u = wg; u < (T + 7) / 8; u += G) embed_ln_body(a.ids, T, a.L, H, a.pad_id, a.vocab, a.abs_pos, a.bad_ids, nullptr, nullptr, a.B, a.word, a.pos, a.type0,
+                                                            a.emb_g, a.emb_b, a.eps, a.x, a.st_scratch, a.st_stride, 2 * u + (tid >> 8), tid & 255);
+    const float *pg = a.emb_g, *pb = a.emb_b;
+    for (int l = 0; l < a.layers; ++l) {
+        const PersistLayer& Ly = a.lay[l];
+        if (wg < 3 * H / 16) persist_prefetch<3, WVA>(Ly.wqkv_f, H, wg, tid, wnext);
+        VQA_PERSIST_BARRIER();
+        {   // QKV on the raw rows, LayerNorm folded in; leaves (mean, rstd) of every row
+            TinyArgs t;
+            t.cvec = Ly.cqkv;
+            t.st_out = a.tiny_x;
+            t.inv_k = inv_h;
+            t.eps = a.eps;
+            if (wg < 3 * H / 16) {  // this workgroup's first unit: its weights were requested in front of the barrier
+                const int u = wg;
+                gemm_tiny_body<0, MT, 1, 3, WVA, true>(a.x, Ly.wqkv_f, Ly.bqkv_f, nullptr, a.qkv, T, 3 * H, H, t, u, 0, tid, wnext);
+                __syncthreads();
+            }
+            for (int u = wg + G; u < 3 * H / 16; u += G) {
+                gemm_tiny_body<0, MT, 1, 3, WVA, true>(a.x, Ly.wqkv_f, Ly.bqkv_f, nullptr, a.qkv, T, 3 * H, H, t, u, 0, tid, nullptr);
+                __syncthreads();
+            }
+        }
+        VQA_PERSIST_BARRIER();
+        for (int u = wg; u < a.B * (a.heads / HPW); u += G) {
+            attention_mfma_body<NQB, HPW, DH, true>(a.qkv, a.mask, a.L, H, a.heads, nullptr, a.ctx, u, tid, smem);
+            __syncthreads();
+        }
+        if (wg < H / 16) persist_prefetch<3, WVA>(Ly.wo, H, wg, tid, wnext);
+        VQA_PERSIST_BARRIER();
+        {   // out-projection + LN_prev(x) as the residual -> tmp (raw)
+            TinyArgs t;
+            t.st_in = a.tiny_x;
+            t.g = pg;
+            t.b = pb;
+            if (wg < H / 16) {  // this workgroup's first unit: its weights were requested in front of the barrier
+                const int u = wg;
+                gemm_tiny_body<2, MT, 0, 3, WVA, true>(a.ctx, Ly.wo, Ly.bo, a.x, a.tmp, T, H, H, t, u, 0, tid, wnext);
+                __syncthreads();
+            }
+            for (int u = wg + G; u < H / 16; u += G) {
+                gemm_tiny_body<2, MT, 0, 3, WVA, true>(a.ctx, Ly.wo, Ly.bo, a.x, a.tmp, T, H, H, t, u, 0, tid, nullptr);
+                __syncthreads();
+            }
+        }
+        if (wg < F / 16) persist_prefetch<3, WVA>(Ly.w1_f, H, wg, tid, wnext);
+        VQA_PERSIST_BARRIER();
+        {   // FFN1 on tmp with LN1 folded in, GELU; leaves (mean, rstd) of tmp's rows
+            TinyArgs t;
+            t.cvec = Ly.c1;
+            t.st_out = a.tiny_tmp;
+            t.inv_k = inv_h;
+            t.eps = a.eps;
+            if (wg < F / 16) {  // this workgroup's first unit: its weights were requested in front of the barrier
+                const int u = wg;
+                gemm_tiny_body<1, MT, 1, 3, WVA, true>(a.tmp, Ly.w1_f, Ly.b1_f, nullptr, a.ffn, T, F, H, t, u, 0, tid, wnext);
+                __syncthreads();
+            }
+            for (int u = wg + G; u < F / 16; u += G) {
+                gemm_tiny_body<1, MT, 1, 3, WVA, true>(a.tmp, Ly.w1_f, Ly.b1_f, nullptr, a.ffn, T, F, H, t, u, 0, tid, nullptr);
+                __syncthreads();
+            }
+        }
+        const int nx = H / 16, my = (T + 15) / 16;
+        if (wg < nx * my) persist_prefetch<NBCB, 8>(Ly.w2, F, wg % nx, tid, wnext);
+        VQA_PERSIST_BARRIER();
+        {   // FFN2 + LN1(tmp) as the residual -> x (raw); one token tile per unit
+            TinyArgs t;
+            t.st_in = a.tiny_tmp;
+            t.g = Ly.ln1_g;
+            t.b = Ly.ln1_b;
+            if (wg < nx * my) {  // this workgroup's first unit: its weights were requested in front of the barrier
+                const int u = wg;
+                gemm_tiny_body<2, 1, 0, NBCB, 8, true>(a.ffn, Ly.w2, Ly.b2, a.tmp, a.x, T, H, F, t, u % nx, u / nx, tid, wnext);
+                __syncthreads();
+            }
+            for (int u = wg + G; u < nx * my; u += G) {
+                gemm_tiny_body<2, 1, 0, NBCB, 8, true>(a.ffn, Ly.w2, Ly.b2, a.tmp, a.x, T, H, F, t, u % nx, u / nx, tid, nullptr);
+                __syncthreads();
+            }
+        }
+        pg = Ly.ln2_g;
+        pb = Ly.ln2_b;
+    }
+    VQA_PERSIST_BARRIER();
+    // ---- the last LayerNorm (x raw -> tmp), then pooling + L2 normalisation
+    for (int u = wg; u < (T + 7) / 8; u += G) ln_body<true>(a.x, T, H, pg, pb, a.eps, a.tmp, 2 * u + (tid >> 8), tid & 255);
+    VQA_PERSIST_BARRIER();
+    for (int u = wg; u < (a.B + 7) / 8; u += G)
+        pool_normalize_body<true>(a.tmp, a.mask, a.B, a.L, H, a.pooling, a.normalize, nullptr, a.out, nullptr, 0, 0, nullptr, nullptr, a.eps, 2 * u + (tid >> 8), tid & 255);
+    if (phase != persist_barriers(a.layers) && wg == 0 && tid == 0)  // (the host's bookkeeping and this kernel disagree: never use the handle's counter again)
+        __hip_atomic_store(a.abort, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#undef VQA_PERSIST_BARRIER
 }
 
 }  // namespace
@@ -1714,6 +2001,19 @@ struct vqa_encoder {
     int32_t* stage_dev = nullptr;   // ... its device alias
     hipEvent_t stage_done = nullptr;  // recorded behind the launches of the last forward_host call: the staging buffer is free again
     bool stage_pending = false;
+    // the one-launch forward of one question (encoder_persist_kernel): activations in UNCACHED device memory, the layers' pointers as a
+    // device array, the grid barrier's counter and its host-side value, the abort flag (pinned, device-mapped)
+    struct Persist {
+        bool on = false;             // options.persistent and a model / device the kernel serves
+        int grid = 0;                // resident workgroups
+        _Float16 *x = nullptr, *qkv = nullptr, *ctx = nullptr, *tmp = nullptr, *ffn = nullptr;
+        float2 *tiny_x = nullptr, *tiny_tmp = nullptr;
+        PersistLayer* layers = nullptr;
+        unsigned* counter = nullptr;
+        unsigned base = 0;           // the counter's value when the next launch starts (phases x grid per completed launch)
+        unsigned* abort_host = nullptr;
+        unsigned* abort_dev = nullptr;
+    } persist;
     int* bad_ids_host = nullptr;  // pinned, device-mapped: set by embed_ln when a token id lies outside [0, vocab_size)
     int* bad_ids_dev = nullptr;
     std::atomic_flag busy = ATOMIC_FLAG_INIT;  // one forward at a time per handle (staging buffers and graphs are shared)
@@ -2080,6 +2380,10 @@ extern "C" void vqa_encoder_destroy(vqa_encoder* e) {
         if (gr.exec) (void)hipGraphExecDestroy(gr.exec);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     if (e->bad_ids_host) (void)hipHostFree(e->bad_ids_host);
+    if (e->persist.abort_host) (void)hipHostFree(e->persist.abort_host);
+    for (void* q : {(void*)e->persist.x, (void*)e->persist.qkv, (void*)e->persist.ctx, (void*)e->persist.tmp, (void*)e->persist.ffn, (void*)e->persist.tiny_x,
+                    (void*)e->persist.tiny_tmp, (void*)e->persist.layers, (void*)e->persist.counter})
+        if (q) (void)hipFree(q);
     if (e->stage_host) (void)hipHostFree(e->stage_host);
     if (e->stage_done) (void)hipEventDestroy(e->stage_done);
     delete e;
@@ -2092,6 +2396,8 @@ extern "C" void vqa_encoder_options_init(vqa_encoder_options* o) {
     o->first_rows = 1;
     o->graphs = 1;
     o->latency_path = 1;
+    o->persistent = 0;  // (built, bit-equal to the launches, and 2.2x SLOWER than them: profiles/r06_persistent_forward.txt)
+    o->persistent_grid = 0;
 }
 
 extern "C" int vqa_encoder_create(vqa_encoder** out, int device, const vqa_encoder_config* cfg, const vqa_encoder_weights* w,
@@ -2115,6 +2421,8 @@ extern "C" int vqa_encoder_create_ex(vqa_encoder** out, int device, const vqa_en
     if (const char* v = vqa_dev_env("VQA_ENC_FOLD")) o.fold_layernorm = atoi(v) != 0;
     if (const char* v = vqa_dev_env("VQA_ENCODER_GRAPH")) o.graphs = v[0] != '0';
     if (const char* v = vqa_dev_env("VQA_ENC_TINY")) o.latency_path = v[0] != '0';
+    if (const char* v = vqa_dev_env("VQA_ENC_PERSIST")) o.persistent = v[0] != '0';
+    if (const char* v = vqa_dev_env("VQA_ENC_PERSIST_GRID")) o.persistent_grid = atoi(v);
     VQA_REQUIRE(cfg && w && w->layer, "vqa_encoder_create: null config / weights");
     VQA_REQUIRE(cfg->hidden >= 32 && cfg->hidden <= 2048 && cfg->hidden % 32 == 0,
                 "vqa_encoder_create: hidden=%d must be a multiple of 32 in [32, 2048]", cfg->hidden);
@@ -2226,6 +2534,44 @@ extern "C" int vqa_encoder_create_ex(vqa_encoder** out, int device, const vqa_en
             break;
         }
         *e->bad_ids_host = 0;
+        // the one-launch forward (encoder_persist_kernel): the reference's two model shapes, folded weights at hand, a device that can hold
+        // the grid; a failed uncached allocation only switches the path off
+        if (o.persistent && e->tiny_on && e->fold_on && ((H == 768 && F == 3072 && cfg->heads == 12) || (H == 384 && F == 1536 && cfg->heads == 12))) {
+            auto& P = e->persist;
+            hipDeviceProp_t prop;
+            int coop = 0;
+            const size_t TM = kTinyMaxM;
+#ifndef VQA_PERSIST_UC
+#define VQA_PERSIST_UC 1
+#endif
+            auto uc = [&](void** q, size_t bytes) {
+                return (VQA_PERSIST_UC ? hipExtMallocWithFlags(q, bytes, hipDeviceMallocUncached) : hipMalloc(q, bytes)) == hipSuccess && hipMemset(*q, 0, bytes) == hipSuccess;
+            };
+            bool ok = hipGetDeviceProperties(&prop, device) == hipSuccess && hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) == hipSuccess && coop;
+            ok = ok && uc((void**)&P.x, TM * H * 2) && uc((void**)&P.qkv, TM * 3 * H * 2) && uc((void**)&P.ctx, TM * H * 2) && uc((void**)&P.tmp, TM * H * 2) &&
+                 uc((void**)&P.ffn, TM * F * 2) && uc((void**)&P.tiny_x, TM * sizeof(float2)) && uc((void**)&P.tiny_tmp, TM * sizeof(float2));
+            ok = ok && hipMalloc((void**)&P.counter, 64) == hipSuccess && hipMemset(P.counter, 0, 64) == hipSuccess &&
+                 hipMalloc((void**)&P.layers, e->layers.size() * sizeof(PersistLayer)) == hipSuccess &&
+                 hipHostMalloc((void**)&P.abort_host, sizeof(unsigned), hipHostMallocMapped) == hipSuccess &&
+                 hipHostGetDevicePointer((void**)&P.abort_dev, P.abort_host, 0) == hipSuccess;
+            if (ok) {
+                std::vector<PersistLayer> hl;
+                for (const vqa_encoder::Layer& Ly : e->layers)
+                    hl.push_back(PersistLayer{Ly.wqkv_f, Ly.wo, Ly.w1_f, Ly.w2, Ly.bqkv_f, Ly.cqkv, Ly.bo, Ly.b1_f, Ly.c1, Ly.b2, Ly.ln1_g, Ly.ln1_b, Ly.ln2_g, Ly.ln2_b});
+                ok = hipMemcpy(P.layers, hl.data(), hl.size() * sizeof(PersistLayer), hipMemcpyHostToDevice) == hipSuccess;
+            }
+            if (ok) {
+                *P.abort_host = 0u;
+                // workgroups: QKV has 3 H / 16 units, FFN1 F / 16, FFN2 and the out-projection H / 16 x token tiles; a barrier costs 1.2 us at
+                // 48 workgroups and 2.9 at 192 (grid_barrier_probe): F / 32 (96 / 48) by default, options.persistent_grid overrides
+                int g = o.persistent_grid > 0 ? o.persistent_grid : (int)(F / 32);
+                g = std::min(g, prop.multiProcessorCount);
+                P.grid = std::max(g, 1);
+                P.on = true;
+            } else {
+                (void)hipGetLastError();
+            }
+        }
         {
             e->use_graphs = o.graphs != 0;
             if (e->use_graphs && hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -2562,6 +2908,99 @@ extern "C" int vqa_encoder_forward(vqa_encoder* e, const int32_t* input_ids, con
     return forward_locked(e, input_ids, attn_mask, B, L, real_tokens, pooling, normalize, out, s);
 }
 
+// ---- the one-launch forward (encoder_persist_kernel).  Returns VQA_PERSIST_DECLINED when the launches should run instead.
+constexpr int VQA_PERSIST_DECLINED = 1;
+template <int MT, bool FOUR, int NQB>
+static int persist_launch_t(vqa_encoder* e, PersistArgs& pa, hipStream_t s) {
+    constexpr int DH = FOUR ? 32 : 64;
+    const int lds = 4 * NQB * 32 * 2 * DH;  // the attention's V images: [4 heads][32 NQB keys][2 DH bytes]
+    static VqaPerDeviceOnce once;
+    int rc = once.run([&](int) -> int {
+        VQA_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(encoder_persist_kernel<MT, FOUR, NQB>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        return VQA_OK;
+    });
+    if (rc != VQA_OK) return rc;
+    void* args[] = {&pa};
+    const hipError_t err = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(encoder_persist_kernel<MT, FOUR, NQB>), dim3(e->persist.grid), dim3(512), args,
+                                                      (unsigned)lds, s);
+    if (err != hipSuccess) {  // (a grid the device cannot hold resident, ...): the launches take over for good
+        (void)hipGetLastError();
+        e->persist.on = false;
+        return VQA_PERSIST_DECLINED;
+    }
+    return VQA_OK;
+}
+
+static int persist_launch(vqa_encoder* e, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L, int32_t pooling, int32_t normalize,
+                          float* out, hipStream_t s) {
+    auto& P = e->persist;
+    if (__atomic_load_n(P.abort_host, __ATOMIC_RELAXED)) {  // an earlier launch gave up at a barrier: its output was invalid
+        __atomic_store_n(P.abort_host, 0u, __ATOMIC_RELAXED);
+        P.on = false;
+        vqa_set_error("vqa_encoder_forward: an earlier one-launch forward on this handle did not complete (a grid barrier ran out: its output is "
+                      "invalid); the handle uses the launches from now on");
+        return VQA_EHIP;
+    }
+    const int T = B * L, H = e->cfg.hidden, F = e->cfg.ffn;
+    // the call's ids and masks (device pointers, or the pinned device-mapped buffer of vqa_encoder_forward_host) -> device arrays
+    hipLaunchKernelGGL(stage_tokens_kernel, dim3((T + 255) / 256), dim3(256), 0, s, input_ids, attn_mask, T, e->g_ids, e->g_mask);
+    VQA_HIP_CHECK(hipGetLastError());
+    PersistArgs pa;
+    pa.ids = e->g_ids;
+    pa.mask = e->g_mask;
+    pa.B = B;
+    pa.L = L;
+    pa.T = T;
+    pa.H = H;
+    pa.F = F;
+    pa.heads = e->cfg.heads;
+    pa.layers = (int)e->layers.size();
+    pa.pad_id = e->cfg.pad_id;
+    pa.vocab = e->cfg.vocab_size;
+    pa.abs_pos = e->cfg.position_ids == VQA_POS_ABSOLUTE ? 1 : 0;
+    pa.bad_ids = e->bad_ids_dev;
+    pa.word = e->word;
+    pa.pos = e->pos;
+    pa.type0 = e->type0;
+    pa.emb_g = e->emb_g;
+    pa.emb_b = e->emb_b;
+    pa.eps = e->cfg.ln_eps;
+    pa.lay = P.layers;
+    pa.x = P.x;
+    pa.qkv = P.qkv;
+    pa.ctx = P.ctx;
+    pa.tmp = P.tmp;
+    pa.ffn = P.ffn;
+    pa.tiny_x = P.tiny_x;
+    pa.tiny_tmp = P.tiny_tmp;
+    pa.st_scratch = e->st_x;
+    pa.st_stride = (e->max_tokens + kTokenPad - 1) / kTokenPad * kTokenPad;
+    pa.pooling = pooling;
+    pa.normalize = normalize;
+    pa.out = out;
+    pa.counter = P.counter;
+    pa.base = P.base;
+    pa.abort = P.abort_dev;
+    const bool four = H == 384;
+    const int mt = T <= 32 ? 2 : 4, nqb = L <= 32 ? 1 : 2;
+    int rc;
+#define VQA_PERSIST(MTV, FOURV, NQBV) rc = persist_launch_t<MTV, FOURV, NQBV>(e, pa, s)
+    if (!four) {
+        if (mt == 2 && nqb == 1) VQA_PERSIST(2, false, 1);
+        else if (mt == 2) VQA_PERSIST(2, false, 2);
+        else if (nqb == 1) VQA_PERSIST(4, false, 1);
+        else VQA_PERSIST(4, false, 2);
+    } else {
+        if (mt == 2 && nqb == 1) VQA_PERSIST(2, true, 1);
+        else if (mt == 2) VQA_PERSIST(2, true, 2);
+        else if (nqb == 1) VQA_PERSIST(4, true, 1);
+        else VQA_PERSIST(4, true, 2);
+    }
+#undef VQA_PERSIST
+    if (rc == VQA_OK) P.base += persist_barriers(pa.layers) * (unsigned)P.grid;  // what the counter gains in one forward
+    return rc;
+}
+
 // the body of a forward call: arguments checked by the caller, handle held, device set
 static int forward_locked(vqa_encoder* e, const int32_t* input_ids, const int32_t* attn_mask, int32_t B, int32_t L, int32_t real_tokens,
                           int32_t pooling, int32_t normalize, float* out, hipStream_t s) {
@@ -2576,6 +3015,14 @@ static int forward_locked(vqa_encoder* e, const int32_t* input_ids, const int32_
         return VQA_EINVAL;
     }
     const int T = B * L;
+    hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap0);
+    // ONE question (<= 64 positions) on one of the reference's two model shapes: the whole forward as one cooperative launch
+    // (launch-bound sizes run the PADDED form whatever real_tokens says, as the graph path below does)
+    if (e->persist.on && e->use_graphs && cap0 == hipStreamCaptureStatusNone && T <= kTinyMaxM && L <= 64) {
+        const int prc = persist_launch(e, input_ids, attn_mask, B, L, pooling, normalize, out, s);
+        if (prc != VQA_PERSIST_DECLINED) return prc;
+    }
     // Launch-bound sizes replay a captured graph (unless the caller's stream is itself being captured: then the kernels
     // simply join the caller's capture).  Above 1024 tokens the kernels are long enough for eager launches to stay ahead of
     // the GPU (graph = eager: 1.10 / 1.28 / 1.41 ms at 2048 / 3072 / 4096 tokens), and eager calls can pack a ragged batch
