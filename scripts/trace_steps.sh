@@ -9,7 +9,7 @@ import csv, glob, sys
 rows = list(csv.DictReader(open(glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 prev = None
-for r in rows[-12:]:
+for r in rows[-16:]:
     s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
     print(f"{r['Kernel_Name'][:70]:70s} dur {(e - s) / 1e3:9.1f} us  gap {(s - prev) / 1e3 if prev else 0:7.1f} us")
     prev = e

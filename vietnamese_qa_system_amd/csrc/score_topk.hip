@@ -30,9 +30,11 @@
 #include "vqa_common.h"
 
 #ifndef VQA_ABLATE
-// dev-only timing ablations (scripts/clock_probe.sh), bit mask; results are wrong when != 0:
+// dev-only timing ablations (scripts/scan_ablation.sh), bit mask; results are wrong when != 0:
 // 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no MFMA, 8 no epilogue, 16 s_sleep in place of the MFMAs,
-// 32 no Q pieces, 64 no loop barrier
+// 32 no Q pieces, 64 no loop barrier.  Since round 6 the int8 / fp16 slot loop honours every bit (round 5's table was taken on a
+// build whose slot loop ignored them); a mask without bit 8 lets garbage accumulators flood the candidate regions: pair 2 / 4 / 32 / 64
+// with 8 (profiles/r06_scan_ablation.txt)
 #define VQA_ABLATE 0
 #endif
 #ifndef VQA_XNT
