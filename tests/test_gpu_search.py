@@ -43,6 +43,9 @@ def _search(x16, q16, k, ids=None, id_base=0):
     (5000, 768, 37, 12),
     (4097, 100, 9, 3),      # d not a multiple of 64: zero padded
     (70001, 64, 300, 10),   # more tiles than workgroups + two query tiles + ragged tail
+    (3001, 100, 257, 10),   # query tiles of equal size (129 + 128): the second tile starts at an 8-byte aligned row
+    (2000, 33, 259, 5),     # ... and at a 4-byte aligned one (66-byte rows); 130 + 129
+    (1500, 64, 777, 3),     # four tiles of 195 / 195 / 195 / 192
 ])
 def test_search_matches_oracle(native_lib, n, d, b, k):
     x, q = _mk(n, d, b, seed=n + d + b)

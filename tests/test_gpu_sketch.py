@@ -34,7 +34,8 @@ def _search(ix, q, k):
     return s.cpu().numpy(), i.cpu().numpy(), p.cpu().numpy()
 
 
-@pytest.mark.parametrize("n,d,b,k", [(300_001, 64, 41, 10), (200_000, 100, 256, 12), (150_000, 768, 64, 1), (262_144, 128, 7, 10)])
+@pytest.mark.parametrize("n,d,b,k", [(300_001, 64, 41, 10), (200_000, 100, 256, 12), (150_000, 768, 64, 1), (262_144, 128, 7, 10),
+                                     (200_000, 100, 257, 10), (150_000, 768, 300, 10)])  # (two query tiles of equal size: 129 + 128, 150 + 150)
 def test_sketch_search_equals_the_exact_scan(native_lib, monkeypatch, n, d, b, k):
     rng = np.random.default_rng(n + d)
     x, q = _unit(rng, n, d), _unit(rng, b, d)
