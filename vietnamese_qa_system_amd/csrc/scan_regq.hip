@@ -27,7 +27,8 @@
 #include "vqa_common.h"
 
 #ifndef VQA_RQ_ABLATE
-// dev-only timing ablations, bit mask; results are wrong when != 0: 1 no LDS-DMA, 2 no fragment reads, 4 no MFMA, 8 no epilogue,
+// dev-only timing ablations, bit mask; results are wrong when != 0: 1 no LDS-DMA, 2 no fragment reads, 4 no MFMA, 8 no epilogue, 16 the
+// threshold test without the append (rare path),
 // 64 no loop barriers
 #define VQA_RQ_ABLATE 0
 #endif
@@ -262,6 +263,9 @@ __global__ __launch_bounds__(kThreads, 1) void sketch_scan_regq_kernel(const voi
                     }
                     mx[ni] = max(max(max(max(r[0], r[1]), r[2]), max(max(r[3], r[4]), r[5])), max(r[6], r[7]));
                 }
+                if constexpr (bool(VQA_RQ_ABLATE & 16)) {  // the test without the append: what the rare path costs (results are wrong)
+                    asm volatile("" ::"v"(mx[0]), "v"(mx[1]), "v"(T[0]), "v"(T[1]));
+                } else
                 if (((float)mx[0] >= T[0]) | ((float)mx[1] >= T[1])) {
                     unsigned long long* region = sk.regions + (size_t)blockIdx.x * sk.cap;
                     // (rare path: nothing it needs is kept in registers across the K loop -- hipcc hoists the row offsets out of the
