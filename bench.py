@@ -390,11 +390,11 @@ def main():
         except Exception:  # noqa: BLE001 -- diagnostics only
             rccl_version = None
         one_gpu = None
-        p80 = os.path.join(ROOT, "profiles", "r05_80M_one_gpu.json")
-        if os.path.exists(p80):
+        p80 = next((f for f in (os.path.join(ROOT, "profiles", f"r0{r}_80M_one_gpu.json") for r in (6, 5)) if os.path.exists(f)), "")
+        if p80:
             with open(p80) as f:
                 j80 = json.load(f)
-            one_gpu = {"file": "profiles/r05_80M_one_gpu.json", "rows": 80_000_000,
+            one_gpu = {"file": "profiles/" + os.path.basename(p80), "rows": 80_000_000,
                        "ms_per_batch_sketch_path": j80["default_path_int8_sketch_scan_plus_exact_rescoring"]["ms_per_batch"],
                        "ms_per_batch_exact_scan": j80["exact_fp16_scan_VQA_SKETCH_0"]["ms_per_batch"],
                        "note": "the WHOLE 80M x 768 fp16 corpus of configs[3] on ONE MI355X (256 queries, top-10): the strong-scaling denominator; "
