@@ -337,9 +337,9 @@ def test_unfilled_tiles_and_a_partly_filled_shard(native_lib, monkeypatch):
 
 
 def test_overflow_in_the_first_query_tile_of_a_long_batch_is_reported(native_lib, monkeypatch):
-    """B = 300: the first query tile (256 copies of one row: every pair a candidate) overflows, the last (44 random queries) does
-    not.  The overflow of the EARLIER tile must still reach the host (the pinned mirror carries the OR over the call's tiles), and
-    every query gets the exact scan's rows."""
+    """B = 300 runs as two query tiles of 150 (capi.hip search_impl: tiles of equal size): the first (150 copies of one row: every pair a
+    candidate) overflows, the last (150 random queries) does not.  The overflow of the EARLIER tile must still reach the host (the pinned
+    mirror carries the OR over the call's tiles), and every query gets the exact scan's rows."""
     n, d, k = 180_000, 64, 10
     rng = np.random.default_rng(8)
     x = rng.standard_normal((n, d)).astype(np.float32)
@@ -350,7 +350,8 @@ def test_overflow_in_the_first_query_tile_of_a_long_batch_is_reported(native_lib
     x[70_000:170_000] = x[7]
     q = rng.standard_normal((300, d)).astype(np.float32)
     q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float16)
-    q[:256] = x[7]
+    t0 = 150  # queries of the first tile
+    q[:t0] = x[7]
     ref = _index(x, monkeypatch, sketch=False)
     ske = _index(x, monkeypatch, sketch=True)
     s0, p0 = _search(ref, q, k)
@@ -361,8 +362,8 @@ def test_overflow_in_the_first_query_tile_of_a_long_batch_is_reported(native_lib
     ref.close()
     ske.close()
     assert stats["overflow"] == 0 and stats["overflow_earlier_tiles"] == 1 and state > 0, (stats, state)
-    assert np.array_equal(p1[:256], p0[:256]) and np.array_equal(s1[:256], s0[:256])
-    assert np.abs(s1[256:] - s0[256:]).max() <= 3e-7 and np.array_equal(p1[256:], p0[256:])
+    assert np.array_equal(p1[:t0], p0[:t0]) and np.array_equal(s1[:t0], s0[:t0])
+    assert np.abs(s1[t0:] - s0[t0:]).max() <= 3e-7 and np.array_equal(p1[t0:], p0[t0:])
     assert np.array_equal(p2, p0) and np.array_equal(s2, s0)
 
 
