@@ -200,7 +200,7 @@ int vqa_index_get_sketch_split(vqa_index* index, int64_t tile, float* out_c /* [
  * the shard holds fewer than k rows the tail is padded with (-inf, -1).  out_pos_or_null [B, k] int64 receives
  * the row positions inside this shard (or NULL).  1 <= k <= VQA_MAX_K_TOTAL (k <= VQA_MAX_K: one pass over the index;
  * beyond that one verified pass, with ceil(k / VQA_MAX_K) gated exact passes as the fallback); any B >= 1 (processed in
- * tiles of VQA_QUERY_TILE queries).
+ * ceil(B / VQA_QUERY_TILE) query tiles of equal size: B = 257 as 129 + 128; a query's result does not depend on its tile).
  * Asynchronous: the launches are queued on hip_stream and the call returns.  A handle owns ONE set of workspaces (query
  * staging, candidate lists, the sketch search's buffers): its searches must be ordered on the device -- the same stream, or
  * streams joined by events -- and one host thread at a time may be inside a call on it (a second one gets VQA_EINVAL).
